@@ -1,0 +1,177 @@
+"""Container-only loader for the REAL reference implementation (test infrastructure).
+
+This file is part of the oracle tooling: it is only ever used by
+``tests/golden/gen_golden.py`` and by the in-container ``-m "not gpu"`` tests that
+pin ``oracle/w2vs_oracle.py`` against the reference.  Nothing in the product path
+(``wav2vec-s_amd/``), ``bench.py``'s GPU leg or the ``-m gpu`` tests imports it, and
+it is a no-op when ``/root/reference`` is absent (the GPU box).
+
+Why a loader is needed: ``import fairseq`` raises
+``ModuleNotFoundError: omegaconf`` from ``fairseq/dataclass/configs.py:23``.  The
+wav2vec-S model files themselves need only torch + numpy, so we register *path-only*
+parent packages in ``sys.modules`` (their heavy ``__init__`` never runs) plus three
+tiny stubs, and then import the reference's own source files unchanged from where
+they lie.  No reference source is copied into this repository.
+"""
+import dataclasses
+import enum
+import importlib
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("W2VS_REFERENCE_ROOT", "/root/reference")
+FS = os.path.join(REF_ROOT, "fairseq", "fairseq")
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(FS, "models", "wav2vec", "wav2vec_S.py"))
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    m.__package__ = name
+    sys.modules[name] = m
+    return m
+
+
+_LOADED = None
+
+
+def load():
+    """Return a namespace with the reference's hot-path symbols."""
+    global _LOADED
+    if _LOADED is not None:
+        return _LOADED
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    sys.dont_write_bytecode = True  # reference tree is read-only
+
+    import torch.nn as nn
+
+    fairseq = _pkg("fairseq", FS)
+    modules = _pkg("fairseq.modules", os.path.join(FS, "modules"))
+    data = _pkg("fairseq.data", os.path.join(FS, "data"))
+    models = _pkg("fairseq.models", os.path.join(FS, "models"))
+    w2v = _pkg("fairseq.models.wav2vec", os.path.join(FS, "models", "wav2vec"))
+    fairseq.modules, fairseq.data, fairseq.models = modules, data, models
+    models.wav2vec = w2v
+
+    # --- stub: fairseq.dataclass (ChoiceEnum, FairseqDataclass) -------------------
+    dc = types.ModuleType("fairseq.dataclass")
+
+    def ChoiceEnum(choices):
+        return enum.Enum("Choices", {k: k for k in choices})
+
+    @dataclasses.dataclass
+    class FairseqDataclass:
+        pass
+
+    dc.ChoiceEnum = ChoiceEnum
+    dc.FairseqDataclass = FairseqDataclass
+    dcu = types.ModuleType("fairseq.dataclass.utils")
+    dcu.convert_namespace_to_omegaconf = lambda a: a
+    dc.utils = dcu
+    sys.modules["fairseq.dataclass"] = dc
+    sys.modules["fairseq.dataclass.utils"] = dcu
+    fairseq.dataclass = dc
+
+    # --- stub: fairseq.models registry --------------------------------------------
+    class BaseFairseqModel(nn.Module):
+        def upgrade_state_dict_named(self, state_dict, name):
+            return state_dict
+
+        def set_num_updates(self, num_updates):
+            for m in self.modules():
+                if hasattr(m, "set_num_updates") and m is not self:
+                    m.set_num_updates(num_updates)
+
+    def _reg(*a, **k):
+        return lambda c: c
+
+    models.BaseFairseqModel = BaseFairseqModel
+    models.register_model = _reg
+    models.register_model_architecture = _reg
+
+    # --- real reference files ------------------------------------------------------
+    imp = importlib.import_module
+    imp("fairseq.file_io")
+    imp("fairseq.incremental_decoding_utils")
+    for name in ["fairseq_dropout", "quant_noise"]:
+        imp("fairseq.modules." + name)
+    futils = imp("fairseq.utils")  # pulls in modules.multihead_attention itself
+    fairseq.utils = futils
+    mha = imp("fairseq.modules.multihead_attention")
+    modules.MultiheadAttention = mha.MultiheadAttention
+    for name, syms in [
+        ("fp32_group_norm", ["Fp32GroupNorm"]),
+        ("layer_norm", ["Fp32LayerNorm", "LayerNorm"]),
+        ("grad_multiply", ["GradMultiply"]),
+        ("gumbel_vector_quantizer", ["GumbelVectorQuantizer"]),
+        ("same_pad", ["SamePad"]),
+        ("transpose_last", ["TransposeLast"]),
+        ("sinusoidal_positional_embedding", ["SinusoidalPositionalEmbedding"]),
+        ("gelu", ["gelu", "gelu_accurate"]),
+        ("fairseq_dropout", ["FairseqDropout"]),
+        ("layer_drop", ["LayerDropModuleList"]),
+        ("learned_positional_embedding", ["LearnedPositionalEmbedding"]),
+        ("positional_embedding", ["PositionalEmbedding"]),
+        ("transformer_sentence_encoder_layer", ["TransformerSentenceEncoderLayer"]),
+        ("transformer_sentence_encoder", ["TransformerSentenceEncoder"]),
+    ]:
+        m = imp("fairseq.modules." + name)
+        for s in syms:
+            setattr(modules, s, getattr(m, s))
+    du = imp("fairseq.data.data_utils")
+    data.data_utils = du
+    w2 = imp("fairseq.models.wav2vec.wav2vec2")
+    for s in dir(w2):
+        if not s.startswith("_"):
+            setattr(w2v, s, getattr(w2, s))
+    ws = imp("fairseq.models.wav2vec.wav2vec_S")
+
+    ns = types.SimpleNamespace(
+        wav2vec2=w2,
+        wav2vec_S=ws,
+        data_utils=du,
+        utils=futils,
+        modules=modules,
+        Wav2VecSModel=ws.Wav2VecSModel,
+        Wav2VecSConfig=ws.Wav2VecSConfig,
+        gen_block_attn_mask=ws.gen_block_attn_mask,
+        compute_mask_indices=du.compute_mask_indices,
+        GumbelVectorQuantizer=modules.GumbelVectorQuantizer,
+        SinusoidalPositionalEmbedding=modules.SinusoidalPositionalEmbedding,
+    )
+    _LOADED = ns
+    return ns
+
+
+def make_cfg(ref, **overrides):
+    """Wav2VecSConfig with the base yaml's model overrides
+    (fairseq/examples/wav2vec/config/pretraining/wav2vec-S_base_librispeech.yaml:50-77)."""
+    cfg = ref.Wav2VecSConfig()
+    base = dict(
+        quantize_targets=True,
+        extractor_mode="layer_norm",
+        final_dim=256,
+        encoder_layerdrop=0.05,
+        dropout_input=0.1,
+        dropout_features=0.1,
+        encoder_embed_dim=768,
+        feature_grad_mult=0.1,
+        main_context=16,
+        right_context=8,
+        context_type="sampling",
+        pos_type="sin",
+        mask_length=10,
+        mask_prob=0.65,
+        mask_selection="static",
+        conv_feature_layers="[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 2",
+    )
+    base.update(overrides)
+    for k, v in base.items():
+        assert hasattr(cfg, k), k
+        setattr(cfg, k, v)
+    return cfg

@@ -1,0 +1,466 @@
+"""CPU oracle for the wav2vec-S pre-training hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a plain fp32 PyTorch/numpy *restatement* of the reference algorithm
+(biaofuxmu/wav2vec-S, vendored fairseq).  It exists to check the HIP path; it is
+never the thing shipped or measured.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  The product package
+``wav2vec-s_amd`` must never import anything from ``oracle/``.
+
+Pinning: the reference holds NO test, golden vector or fixture for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, imported in the build container through ``oracle/ref_import.py``; the
+resulting vectors are committed under ``tests/golden/`` by
+``tests/golden/gen_golden.py`` and re-checked on every CPU test run
+(``tests/test_oracle_golden.py``; ``tests/test_oracle_vs_reference.py`` re-runs
+the live comparison whenever ``/root/reference`` is present).
+
+Every function cites the reference lines it restates; paths are relative to
+``/root/reference/fairseq/fairseq/`` ("fs/").  Parameter names are the reference's
+``state_dict`` keys so a reference checkpoint drives the oracle unchanged.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------
+# configuration (field names = fs/models/wav2vec/wav2vec_S.py:43-311 Wav2VecSConfig)
+# ----------------------------------------------------------------------------------
+@dataclass
+class OracleCfg:
+    extractor_mode: str = "layer_norm"
+    encoder_layers: int = 12
+    encoder_embed_dim: int = 768
+    encoder_ffn_embed_dim: int = 3072
+    encoder_attention_heads: int = 12
+    layer_norm_first: bool = False
+    conv_feature_layers: str = "[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 2"
+    conv_bias: bool = False
+    final_dim: int = 256
+    latent_vars: int = 320
+    latent_groups: int = 2
+    latent_dim: int = 0
+    logit_temp: float = 0.1
+    num_negatives: int = 100
+    mask_prob: float = 0.65
+    mask_length: int = 10
+    feature_grad_mult: float = 0.1
+    required_seq_len_multiple: int = 2
+    loss_weights: Tuple[float, ...] = (0.1, 10.0)
+
+    @property
+    def conv_layers(self) -> List[Tuple[int, int, int]]:
+        return eval(self.conv_feature_layers)
+
+    @property
+    def layer_norm_num(self) -> int:
+        # fs/models/wav2vec/wav2vec_S.py:325
+        return 1 if self.encoder_layers == 12 else 7
+
+
+# ----------------------------------------------------------------------------------
+# host-side integer / RNG pieces (bit-exact contracts)
+# ----------------------------------------------------------------------------------
+def conv_out_lengths(L: int, conv_layers) -> List[int]:
+    """fs/data/audio/raw_audio_dataset.py:194-202 (no padding, floor)."""
+    out = []
+    for _, k, s in conv_layers:
+        L = (L - k) // s + 1
+        out.append(L)
+    return out
+
+
+def compute_mask_indices(
+    shape,
+    padding_mask,
+    mask_prob: float,
+    mask_length: int,
+    mask_type: str = "static",
+    mask_other: float = 0.0,
+    min_masks: int = 0,
+) -> np.ndarray:
+    """Span-mask sampler, fs/data/data_utils.py:389-513 (overlap-allowed branch only;
+    the ``no_overlap`` branch uses the removed ``np.int`` and is unreachable with
+    numpy>=1.24, data_utils.py:481).  Consumes the numpy GLOBAL RandomState in the
+    reference's order: 1 rand() [+1 per row with a padding mask], one
+    choice(replace=False) per row, one more per row that is longer than the minimum."""
+    bsz, all_sz = shape
+    mask = np.full((bsz, all_sz), False)
+    all_num_mask = int(mask_prob * all_sz / float(mask_length) + np.random.rand())
+    all_num_mask = max(min_masks, all_num_mask)
+    rows = []
+    for i in range(bsz):
+        if padding_mask is not None:
+            sz = all_sz - int(padding_mask[i].long().sum().item())
+            num_mask = int(mask_prob * sz / float(mask_length) + np.random.rand())
+            num_mask = max(min_masks, num_mask)
+        else:
+            sz = all_sz
+            num_mask = all_num_mask
+        if mask_type == "static":
+            lengths = np.full(num_mask, mask_length)
+        elif mask_type == "uniform":
+            lengths = np.random.randint(mask_other, mask_length * 2 + 1, size=num_mask)
+        elif mask_type == "normal":
+            lengths = np.random.normal(mask_length, mask_other, size=num_mask)
+            lengths = [max(1, int(round(x))) for x in lengths]
+        elif mask_type == "poisson":
+            lengths = np.random.poisson(mask_length, size=num_mask)
+            lengths = [int(round(x)) for x in lengths]
+        else:
+            raise Exception("unknown mask selection " + mask_type)
+        if sum(lengths) == 0:
+            lengths[0] = min(mask_length, sz - 1)
+        min_len = min(lengths)
+        if sz - min_len <= num_mask:
+            min_len = sz - num_mask - 1
+        starts = np.random.choice(sz - min_len, num_mask, replace=False)
+        idc = np.asarray(
+            [starts[j] + off for j in range(len(starts)) for off in range(lengths[j])]
+        )
+        rows.append(np.unique(idc[idc < sz]))
+    min_len = min(len(m) for m in rows)
+    for i, idc in enumerate(rows):
+        if len(idc) > min_len:
+            idc = np.random.choice(idc, min_len, replace=False)
+        mask[i, idc] = True
+    return mask
+
+
+def sample_negative_indices(bsz: int, num: int, n_negatives: int) -> torch.Tensor:
+    """fs/models/wav2vec/wav2vec2.py:471-527, n_negatives>0 and cross_sample=0 branch.
+    One torch.randint on the CPU default generator, "+1 where >= own position",
+    then + b*num row offset.  Returns int64 (bsz, n_negatives*num) indices into the
+    flattened (bsz*num) target rows."""
+    assert num > 1, (bsz, num)
+    tszs = torch.arange(num).unsqueeze(-1).expand(-1, n_negatives).flatten()
+    neg = torch.randint(low=0, high=num - 1, size=(bsz, n_negatives * num))
+    neg[neg >= tszs] += 1
+    for i in range(1, bsz):
+        neg[i] += i * num
+    return neg
+
+
+def sinusoidal_table(num_embeddings: int, dim: int, padding_idx: int = 1) -> torch.Tensor:
+    """fs/modules/sinusoidal_positional_embedding.py:35-58: sin half then cos half,
+    freq = exp(-i*log(1e4)/(half-1)), row ``padding_idx`` zeroed."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(num_embeddings, dtype=torch.float).unsqueeze(1) * freq.unsqueeze(0)
+    emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1).view(num_embeddings, -1)
+    if dim % 2 == 1:
+        emb = torch.cat([emb, torch.zeros(num_embeddings, 1)], dim=1)
+    emb[padding_idx, :] = 0
+    return emb
+
+
+def positions_from_padding(pad: torch.Tensor, padding_idx: int = 1) -> torch.Tensor:
+    """fs/utils.py:250-260 applied to the BOOL padding mask as wav2vec_S.py:361-367
+    does: non-padded frame j gets padding_idx + (#non-padded frames up to j); padded
+    frames get padding_idx (the zero row)."""
+    nonpad = (~pad).int()
+    return (torch.cumsum(nonpad, dim=1) * nonpad).long() + padding_idx
+
+
+def block_structure(seq_len: int, main_context: int, right_context: int):
+    """Integer structure of gen_block_attn_mask, fs/models/wav2vec/wav2vec_S.py:444-489.
+
+    Returns (rc_idx int64 [R], rc_oob bool [R], masked bool [N, N]) with
+    N = seq_len + R, R = (seq_len // m) * r.  masked[q, k] True == the reference adds
+    -1e4 to that score."""
+    m, r = main_context, right_context
+    nb = seq_len // m
+    block_idx = torch.arange(seq_len) // m
+    if r == 0:
+        return (
+            torch.zeros(0, dtype=torch.long),
+            torch.zeros(0, dtype=torch.bool),
+            block_idx.unsqueeze(1) < block_idx.unsqueeze(0),
+        )
+    rc_block = torch.arange(nb).repeat_interleave(r)
+    rc_idx = ((torch.arange(nb).unsqueeze(1) + 1) * m + torch.arange(r).unsqueeze(0)).reshape(-1)
+    rc_oob = rc_idx > seq_len - 1
+    rc_idx = rc_idx.clamp(0, seq_len - 1)
+    full = torch.cat([block_idx, rc_block])
+    m1 = full.unsqueeze(1) < block_idx.unsqueeze(0)
+    m2 = full.unsqueeze(1) != rc_block.unsqueeze(0)
+    return rc_idx, rc_oob, torch.cat([m1, m2], dim=1)
+
+
+# ----------------------------------------------------------------------------------
+# floating-point pieces
+# ----------------------------------------------------------------------------------
+def conv_feature_extractor(source: torch.Tensor, P: Dict[str, torch.Tensor], cfg: OracleCfg,
+                           collect: Optional[dict] = None) -> torch.Tensor:
+    """ConvFeatureExtractionModel.forward, fs/models/wav2vec/wav2vec2.py:702-781.
+    Returns B x C x T (reference layout)."""
+    x = source.unsqueeze(1)
+    pre = "feature_extractor.conv_layers."
+    for i, (dim, k, s) in enumerate(cfg.conv_layers):
+        w = P[f"{pre}{i}.0.weight"]
+        b = P.get(f"{pre}{i}.0.bias")
+        x = F.conv1d(x, w, b, stride=s)
+        if cfg.extractor_mode == "layer_norm" and i < cfg.layer_norm_num:
+            # TransposeLast -> Fp32LayerNorm(dim) -> TransposeLast  (:733-743)
+            x = F.layer_norm(x.transpose(1, 2).float(), (dim,), P[f"{pre}{i}.2.1.weight"].float(),
+                             P[f"{pre}{i}.2.1.bias"].float(), 1e-5).transpose(1, 2)
+        elif cfg.extractor_mode == "default" and i == 0:
+            # Fp32GroupNorm(dim, dim)  (:744-750)
+            x = F.group_norm(x.float(), dim, P[f"{pre}{i}.2.weight"].float(),
+                             P[f"{pre}{i}.2.bias"].float(), 1e-5)
+        x = F.gelu(x)
+        if collect is not None:
+            collect[f"conv{i}"] = x
+    return x
+
+
+def encoder_layer(x, P, pre, cfg: OracleCfg, add_mask, collect=None):
+    """TransformerSentenceEncoderLayer.forward, fs/models/wav2vec/wav2vec2.py:921-978,
+    with MultiheadAttention's fast path (fs/modules/multihead_attention.py:161-193) spelt
+    out: q scaled by head_dim**-0.5, additive mask, softmax, P.V, out_proj.
+    x: N x B x C.  add_mask: B x 1 x N x N additive fp32 (attn mask + key padding)."""
+    N, B, C = x.shape
+    H = cfg.encoder_attention_heads
+    D = C // H
+
+    def lin(t, name):
+        return F.linear(t, P[f"{pre}{name}.weight"], P[f"{pre}{name}.bias"])
+
+    def attn(t):
+        q = lin(t, "self_attn.q_proj").view(N, B, H, D).permute(1, 2, 0, 3) * (D ** -0.5)
+        k = lin(t, "self_attn.k_proj").view(N, B, H, D).permute(1, 2, 0, 3)
+        v = lin(t, "self_attn.v_proj").view(N, B, H, D).permute(1, 2, 0, 3)
+        s = q @ k.transpose(-1, -2) + add_mask
+        p = torch.softmax(s, dim=-1)
+        o = (p @ v).permute(2, 0, 1, 3).reshape(N, B, C)
+        if collect is not None:
+            collect[pre + "attn_ctx"] = o
+        return lin(o, "self_attn.out_proj")
+
+    def ln(t, name):
+        return F.layer_norm(t, (C,), P[f"{pre}{name}.weight"], P[f"{pre}{name}.bias"], 1e-5)
+
+    if cfg.layer_norm_first:
+        x = x + attn(ln(x, "self_attn_layer_norm"))
+        h = F.gelu(lin(ln(x, "final_layer_norm"), "fc1").float())
+        x = x + lin(h, "fc2")
+    else:
+        x = ln(x + attn(x), "self_attn_layer_norm")
+        h = F.gelu(lin(x, "fc1").float())
+        x = ln(x + lin(h, "fc2"), "final_layer_norm")
+    return x
+
+
+def blockwise_encoder(x, P, cfg: OracleCfg, main_context: int, right_context: int,
+                      padding_mask=None, layer_keep: Optional[List[bool]] = None, collect=None):
+    """BlockwiseTransformerEncoder.extract_features + TransformerEncoder.forward,
+    fs/models/wav2vec/wav2vec_S.py:355-440, wav2vec2.py:828-834.  x: B x T x C (masked,
+    projected features).  Dropout is the identity here (parity runs use p=0)."""
+    B, T, C = x.shape
+    if padding_mask is not None:
+        x = x.masked_fill(padding_mask.unsqueeze(-1), 0.0)
+        pad = padding_mask
+    else:
+        pad = torch.zeros(B, T, dtype=torch.bool)
+    table = sinusoidal_table(8000 + 1 + 1, C, 1)  # wav2vec_S.py:341-347
+    pos = table.index_select(0, positions_from_padding(pad).view(-1)).view(B, T, C)
+    x = x + pos
+    if not cfg.layer_norm_first:
+        x = F.layer_norm(x, (C,), P["encoder.layer_norm.weight"], P["encoder.layer_norm.bias"], 1e-5)
+    mult = cfg.required_seq_len_multiple
+    pad_len = (-T) % mult
+    if pad_len:
+        x = F.pad(x, (0, 0, 0, pad_len))
+        # wav2vec_S.py:378-384: a fresh mask when none was given, else pad with True
+        if padding_mask is None:
+            pad = torch.zeros(B, T + pad_len, dtype=torch.bool)
+            pad[:, -pad_len:] = True
+        else:
+            pad = F.pad(pad, (0, pad_len), value=True)
+    Tp = T + pad_len
+    if collect is not None:
+        collect["enc_in"] = x
+    x = x.transpose(0, 1)  # T' x B x C
+    rc_idx, rc_oob, masked = block_structure(Tp, main_context, right_context)
+    if right_context > 0:
+        pad = torch.cat([pad, pad.index_select(1, rc_idx) | rc_oob.unsqueeze(0)], dim=1)
+        x = torch.cat([x, x.index_select(0, rc_idx)], dim=0)
+    add = torch.zeros(masked.shape).masked_fill(masked, -1e4)  # :486-487 (finite, not -inf)
+    add = add.view(1, 1, *masked.shape) + torch.zeros(B, 1, 1, masked.shape[1]).masked_fill(
+        pad.view(B, 1, 1, -1), float("-inf"))
+    for i in range(cfg.encoder_layers):
+        if layer_keep is None or layer_keep[i]:
+            x = encoder_layer(x, P, f"encoder.layers.{i}.", cfg, add, collect)
+            if collect is not None:
+                collect[f"layer{i}"] = x
+    x = x[:Tp].transpose(0, 1)
+    if pad_len:
+        x = x[:, :-pad_len]
+    if cfg.layer_norm_first:
+        x = F.layer_norm(x, (C,), P["encoder.layer_norm.weight"], P["encoder.layer_norm.bias"], 1e-5)
+    return x
+
+
+def gumbel_quantize(y, P, cfg: OracleCfg, tau: float, noise: Optional[torch.Tensor]):
+    """GumbelVectorQuantizer.forward, fs/modules/gumbel_vector_quantizer.py:141-202.
+    y: B x M x 512.  ``noise`` None = eval (hard one-hot of the argmax); otherwise the
+    Gumbel sample g (shape (B*M*G, V)) that F.gumbel_softmax would have drawn:
+    y_soft = softmax((logits+g)/tau); out = onehot(argmax y_soft) - y_soft.detach() + y_soft."""
+    B, M, Fd = y.shape
+    G, V = cfg.latent_groups, cfg.latent_vars
+    logits = F.linear(y.reshape(-1, Fd), P["quantizer.weight_proj.weight"],
+                      P["quantizer.weight_proj.bias"]).view(B * M * G, V)
+    k = logits.argmax(-1)
+    hard = torch.zeros_like(logits).scatter_(-1, k.view(-1, 1), 1.0).view(B * M, G, V)
+    hp = hard.float().mean(0)
+    code_ppl = torch.exp(-torch.sum(hp * torch.log(hp + 1e-7), dim=-1)).sum()
+    ap = torch.softmax(logits.view(B * M, G, V).float(), dim=-1).mean(0)
+    prob_ppl = torch.exp(-torch.sum(ap * torch.log(ap + 1e-7), dim=-1)).sum()
+    if noise is not None:
+        soft = torch.softmax((logits.float() + noise) / tau, dim=-1)
+        idx = soft.argmax(-1)
+        onehot = torch.zeros_like(soft).scatter_(-1, idx.view(-1, 1), 1.0)
+        sel = onehot - soft.detach() + soft
+    else:
+        idx = k
+        sel = hard.view(B * M * G, V)
+    vars_ = P["quantizer.vars"]  # 1 x (G*V) x D
+    D = vars_.shape[-1]
+    q = (sel.view(B * M, G * V, 1) * vars_).view(B * M, G, V, D).sum(-2).view(B, M, G * D)
+    return q, idx.view(B * M, G), prob_ppl, code_ppl
+
+
+def compute_logits(x, y, neg_idx, cfg: OracleCfg):
+    """sample_negatives' gather + compute_preds + get_logits,
+    fs/models/wav2vec/wav2vec2.py:521-542, 671-675.
+    x, y: B x M x C; neg_idx: B x (K*M) int64.  Returns ((K+1) x B x M preds, (M*B) x (K+1) logits)."""
+    B, M, C = y.shape
+    K = neg_idx.shape[1] // M
+    negs = y.reshape(-1, C)[neg_idx.view(-1)].view(B, M, K, C).permute(2, 0, 1, 3)
+    neg_is_pos = (y == negs).all(-1)
+    targets = torch.cat([y.unsqueeze(0), negs], dim=0)
+    preds = torch.cosine_similarity(x.float(), targets.float(), dim=-1) / cfg.logit_temp
+    if neg_is_pos.any():
+        preds[1:][neg_is_pos] = float("-inf")
+    logits = preds.transpose(0, 2).reshape(-1, K + 1)
+    return preds, logits
+
+
+def criterion(logits, prob_ppl, features_pen, num_vars: int, cfg: OracleCfg):
+    """Wav2vecCriterion.forward (infonce), fs/criterions/wav2vec_criterion.py:64-157."""
+    target = torch.zeros(logits.shape[0], dtype=torch.long)
+    loss0 = F.cross_entropy(logits.float(), target, reduction="sum")
+    sample_size = target.numel()
+    extra = [(num_vars - prob_ppl) / num_vars, features_pen]
+    losses = [loss0]
+    loss = loss0
+    for p, coef in zip(extra, cfg.loss_weights):
+        if coef != 0 and p is not None:
+            t = coef * p.float() * sample_size
+            loss = loss + t
+            losses.append(t)
+    with torch.no_grad():
+        mx = logits.argmax(-1) == 0
+        mn = logits.argmin(-1) == 0
+        correct = int(mx.long().sum().item() - (mx & mn).long().sum().item())
+    return loss, sample_size, {"losses": losses, "correct": correct, "count": float(mx.numel())}
+
+
+def forward_loss(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCfg, *,
+                 mask_indices: torch.Tensor, neg_idx: torch.Tensor, main_context: int,
+                 right_context: int, tau: float = 2.0, gumbel_noise: Optional[torch.Tensor] = None,
+                 layer_keep: Optional[List[bool]] = None, collect: Optional[dict] = None):
+    """Wav2Vec2Model.forward (fs/models/wav2vec/wav2vec2.py:544-658) + criterion, with
+    every host-RNG draw INJECTED (mask_indices B x T bool, neg_idx, context sizes,
+    gumbel noise, LayerDrop keeps) and all dropouts off, so that two implementations
+    can be compared on identical draws."""
+    feats = conv_feature_extractor(source, P, cfg, collect)
+    if cfg.feature_grad_mult != 1.0:
+        # GradMultiply (fs/modules/grad_multiply.py:9-18): identity fwd, grad * scale
+        s = cfg.feature_grad_mult
+        feats = feats * s + (feats * (1.0 - s)).detach()
+    features_pen = feats.float().pow(2).mean()
+    feats = feats.transpose(1, 2)
+    C0 = feats.shape[-1]
+    feats = F.layer_norm(feats, (C0,), P["layer_norm.weight"], P["layer_norm.bias"], 1e-5)
+    unmasked = feats.clone()
+    if "post_extract_proj.weight" in P:  # None when conv dim == embed dim (wav2vec2.py:320-324)
+        x = F.linear(feats, P["post_extract_proj.weight"], P["post_extract_proj.bias"])
+    else:
+        x = feats
+    B, T, C = x.shape
+    x = torch.where(mask_indices.unsqueeze(-1), P["mask_emb"].view(1, 1, C).expand(B, T, C), x)
+    y = unmasked[mask_indices].view(B, -1, C0)
+    if collect is not None:
+        collect.update(features=feats, x_masked=x, y_in=y)
+    x = blockwise_encoder(x, P, cfg, main_context, right_context, None, layer_keep, collect)
+    q, idx, prob_ppl, code_ppl = gumbel_quantize(y, P, cfg, tau, gumbel_noise)
+    yq = F.linear(q, P["project_q.weight"], P["project_q.bias"])
+    xm = x[mask_indices].view(B, -1, C)
+    xf = F.linear(xm, P["final_proj.weight"], P["final_proj.bias"])
+    preds, logits = compute_logits(xf, yq, neg_idx, cfg)
+    num_vars = cfg.latent_vars * cfg.latent_groups
+    loss, sample_size, log = criterion(logits, prob_ppl, features_pen, num_vars, cfg)
+    if collect is not None:
+        collect.update(enc_out=x, q=q, q_idx=idx, yq=yq, xf=xf, preds=preds, logits=logits)
+    out = dict(loss=loss, sample_size=sample_size, features_pen=features_pen,
+               prob_perplexity=prob_ppl, code_perplexity=code_ppl, logits=logits,
+               correct=log["correct"], count=log["count"], losses=log["losses"])
+    return out
+
+
+def init_params(cfg: OracleCfg, seed: int = 1) -> Dict[str, torch.Tensor]:
+    """Seeded random parameters with the reference's key names/shapes (SURVEY.md section
+    8a 'Parameter inventory') and init distributions (kaiming-normal convs
+    wav2vec2.py:724-727; N(0,0.02) linears transformer_sentence_encoder.py:21-53; quantizer
+    gumbel_vector_quantizer.py:56-75; mask_emb uniform wav2vec2.py:391-393).  Not the
+    reference's RNG stream - only shapes and scales matter for synthetic-weight runs."""
+    g = torch.Generator().manual_seed(seed)
+    P = {}
+    C = cfg.encoder_embed_dim
+    in_d = 1
+    for i, (dim, k, s) in enumerate(cfg.conv_layers):
+        std = math.sqrt(2.0 / (in_d * k))
+        P[f"feature_extractor.conv_layers.{i}.0.weight"] = torch.randn(dim, in_d, k, generator=g) * std
+        if cfg.conv_bias:
+            P[f"feature_extractor.conv_layers.{i}.0.bias"] = torch.zeros(dim)
+        if cfg.extractor_mode == "layer_norm" and i < cfg.layer_norm_num:
+            P[f"feature_extractor.conv_layers.{i}.2.1.weight"] = torch.ones(dim)
+            P[f"feature_extractor.conv_layers.{i}.2.1.bias"] = torch.zeros(dim)
+        elif cfg.extractor_mode == "default" and i == 0:
+            P[f"feature_extractor.conv_layers.{i}.2.weight"] = torch.ones(dim)
+            P[f"feature_extractor.conv_layers.{i}.2.bias"] = torch.zeros(dim)
+        in_d = dim
+    E = in_d
+    fd = cfg.final_dim if cfg.final_dim > 0 else C
+    vq = cfg.latent_dim if cfg.latent_dim > 0 else fd
+
+    def lin(name, o, i, std=0.02):
+        P[name + ".weight"] = torch.randn(o, i, generator=g) * std
+        P[name + ".bias"] = torch.zeros(o)
+
+    def lnp(name, d):
+        P[name + ".weight"] = torch.ones(d)
+        P[name + ".bias"] = torch.zeros(d)
+
+    P["mask_emb"] = torch.rand(C, generator=g)
+    lnp("layer_norm", E)
+    lin("post_extract_proj", C, E, 1.0 / math.sqrt(E))
+    P["quantizer.vars"] = torch.rand(1, cfg.latent_groups * cfg.latent_vars, vq // cfg.latent_groups, generator=g)
+    lin("quantizer.weight_proj", cfg.latent_groups * cfg.latent_vars, E, 1.0)
+    lin("project_q", fd, vq, 1.0 / math.sqrt(vq))
+    for l in range(cfg.encoder_layers):
+        pre = f"encoder.layers.{l}."
+        for n in ["q_proj", "k_proj", "v_proj", "out_proj"]:
+            lin(pre + "self_attn." + n, C, C)
+        lnp(pre + "self_attn_layer_norm", C)
+        lin(pre + "fc1", cfg.encoder_ffn_embed_dim, C)
+        lin(pre + "fc2", C, cfg.encoder_ffn_embed_dim)
+        lnp(pre + "final_layer_norm", C)
+    lnp("encoder.layer_norm", C)
+    lin("final_proj", fd, C, 1.0 / math.sqrt(C))
+    return P
