@@ -1,0 +1,179 @@
+/* libw2vs - C ABI of the MI355X (gfx950) wav2vec-S pre-training hot path.
+ *
+ * The reference (biaofuxmu/wav2vec-S) has no FFI for this path: it is Python on ATen
+ * (SURVEY.md section 8b).  This header is therefore the boundary a native replacement
+ * exports *beneath* the fairseq model API: one entry point per fused kernel, plain
+ * pointers + sizes, no torch types.  Each entry cites the reference code it replaces;
+ * paths are relative to /root/reference/fairseq/fairseq/ ("fs/").
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says host;
+ *  - activations/params are bf16 ("void*"), statistics and gradient accumulators fp32;
+ *  - layouts are channel-last / token-major: conv activations [B, L, C], encoder tokens
+ *    [B, N, C] (N = T' + R right-context copies), QKV fused [B, N, 3C];
+ *  - work is enqueued on `stream` (a hipStream_t passed as void*); no entry synchronises;
+ *  - return 0 on success, W2VS_ERR_INVALID (-1) for rejected arguments, W2VS_ERR_HIP (-2)
+ *    for a HIP runtime error; w2vs_last_error() returns the message (thread local);
+ *  - "accumulate" outputs (float* d...) are ADDED to with fp32 atomics; the caller zeroes.
+ */
+#ifndef W2VS_H
+#define W2VS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2VS_ABI_VERSION 1
+#define W2VS_ERR_INVALID (-1)
+#define W2VS_ERR_HIP (-2)
+
+int w2vs_abi_version(void);
+const char* w2vs_last_error(void);
+/* sizeof() of the descriptor structs as compiled, so a binding can verify its mirror:
+ * which = 0 gemm, 1 ln_fwd, 2 ln_bwd, 3 enc_prologue, 4 attn, 5 quant, 6 nce */
+int w2vs_sizeof(int which);
+
+/* ---- GEMM family ----------------------------------------------------------------------------
+ * Replaces every nn.Linear / Conv1d(layers 1-6) matmul on the path:
+ *   F.linear in fs/models/wav2vec/wav2vec2.py:567-568 (post_extract_proj), :613 (project_q),
+ *   :647 (final_proj); q/k/v/out_proj in fs/modules/multihead_attention.py:161-193; fc1/fc2
+ *   in wav2vec2.py:971-973; quantizer weight_proj gumbel_vector_quantizer.py:149;
+ *   nn.Conv1d in wav2vec2.py:724-727 (as a strided-A GEMM, see gemm.hip).
+ * NT: C[M,N] = epi(A[M,K] * B[N,K]^T).  TN: Cf[M,N] += alpha * A[K,M]^T * B[K,N]. */
+enum {
+  W2VS_EPI_NONE = 0,           /* C = acc                                            */
+  W2VS_EPI_BIAS = 1,           /* C = acc + bias[n]                                  */
+  W2VS_EPI_BIAS_GELU = 2,      /* C = gelu(acc + bias[n])          (exact erf GELU)  */
+  W2VS_EPI_BIAS_GELU_SAVE = 3, /* C2 = acc + bias (pre-activation), C = gelu(C2)     */
+  W2VS_EPI_DGELU = 4,          /* C = acc * gelu'(aux[m,n])                          */
+  W2VS_EPI_F32 = 5             /* Cf = alpha * acc (fp32 output)                     */
+};
+typedef struct w2vs_gemm_desc {
+  const void* A; const void* B;
+  void* C; void* C2; float* Cf;
+  const void* bias; const void* aux;
+  int32_t M, N, K, batch;
+  int64_t lda, ldb, ldc;   /* elements */
+  int64_t a_off;           /* element offset of A row 0, may be negative (reads zero) */
+  int64_t sA, sB, sC;      /* batch strides, elements */
+  int64_t a_bytes, b_bytes;/* valid bytes per batch (0 = derive) : reads beyond return 0 */
+  int64_t c_elems;         /* valid output elements per batch (0 = derive)            */
+  int32_t epi; float alpha;
+} w2vs_gemm_desc;
+int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
+int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
+
+/* ---- conv layer 0: Conv1d(1->C,k,s) + Fp32LayerNorm(C) + GELU ------------------------------
+ * fs/models/wav2vec/wav2vec2.py:733-743, 773-781 (layer 0 of ConvFeatureExtractionModel).
+ * wave [B, L] bf16 ; w [C, 1, k] ; y [B, L0, C] channel-last ; mean/rstd [B*L0] fp32.      */
+int w2vs_conv0_fwd(const void* wave, const void* w, const void* conv_bias, const void* ln_w, const void* ln_b,
+                   void* y, float* mean, float* rstd, int B, int L, int C, int k, int s, void* stream);
+int w2vs_conv0_bwd(const void* wave, const void* w, const void* conv_bias, const void* ln_w, const void* ln_b,
+                   const float* mean, const float* rstd, const void* dy, float* dw, float* dconv_bias,
+                   float* dln_w, float* dln_b, int B, int L, int C, int k, int s, void* stream);
+
+/* ---- row LayerNorm family --------------------------------------------------------------------
+ * fwd:  s = dropout(x) [+ res] ; sum_out = s ; y = [gelu] LN(s)
+ *   self.layer_norm wav2vec2.py:556-557 (+ features_pen :554 via sumsq),
+ *   dropout1/3 + residual + self_attn_layer_norm/final_layer_norm wav2vec2.py:945-976,
+ *   Fp32LayerNorm+GELU of conv layers i < layer_norm_num (large) wav2vec2.py:733-743.
+ * bwd:  ds = LNbwd(dy) [+ dsum] ; dres = ds ; dx = ((ds + 2*x*pen_coef) * out_scale) o dropmask
+ *       [o gelu'(aux)] ; dgamma/dbeta accumulate.  x is the LN input (the saved sum).            */
+typedef struct w2vs_ln_fwd_desc {
+  const void* x; const void* res; const void* gamma; const void* beta;
+  void* y; void* sum_out; float* mean; float* rstd; float* sumsq;
+  int64_t rows; int32_t C; int32_t gelu; float p_drop; uint64_t seed;
+} w2vs_ln_fwd_desc;
+typedef struct w2vs_ln_bwd_desc {
+  const void* x; const void* gamma; const void* beta; const float* mean; const float* rstd;
+  const void* dy; const void* dsum; const void* aux;
+  void* dx; void* dres; float* dgamma; float* dbeta;
+  int64_t rows; int32_t C; int32_t gelu; float p_drop; uint64_t seed; float out_scale; float pen_coef;
+} w2vs_ln_bwd_desc;
+int w2vs_ln_fwd(const w2vs_ln_fwd_desc* d, void* stream);
+int w2vs_ln_bwd(const w2vs_ln_bwd_desc* d, void* stream);
+
+/* ---- encoder prologue --------------------------------------------------------------------------
+ * dropout_input (wav2vec2.py:570) -> x[mask] = mask_emb (:446) -> zero padded frames, + sinusoid
+ * (wav2vec_S.py:357-369) -> LayerNorm (:371-372, post-LN only) -> zero pad frame (:375-384) ->
+ * dropout (:385) -> right-context copies (gen_block_attn_mask :465-484), written as [B, N, C].
+ * src [N] int32: source frame of every token row; pos [B, T] int32 sinusoid row per frame;
+ * copy_start [Tp+1], copy_list [R]: CSR of the copies of each frame (for the backward gather). */
+typedef struct w2vs_enc_prologue_desc {
+  const void* x; const uint8_t* mask; const uint8_t* pad; const int32_t* pos;
+  const void* mask_emb; const float* pos_table; const void* gamma; const void* beta;
+  void* out; float* mean; float* rstd; const int32_t* src;
+  const void* dout; void* dx; float* dmask_emb; float* dgamma; float* dbeta;
+  const int32_t* copy_start; const int32_t* copy_list;
+  float p_in; float p_enc; uint64_t seed_in; uint64_t seed_enc;
+  int32_t apply_ln, B, T, Tp, N, C;
+} w2vs_enc_prologue_desc;
+int w2vs_enc_prologue_fwd(const w2vs_enc_prologue_desc* d, void* stream);
+int w2vs_enc_prologue_bwd(const w2vs_enc_prologue_desc* d, void* stream);
+
+/* ---- block-causal attention with right-context copies ----------------------------------------
+ * gen_block_attn_mask (wav2vec_S.py:444-489) + scaled-dot-product core of
+ * F.multi_head_attention_forward (multihead_attention.py:161-193) incl. attention dropout.
+ * q/k/v: [B, N, ld] with head h at columns h*64..h*64+63 (ld = 3C for a fused QKV buffer),
+ * o: [B, N, ldo]; lse [B, H, N] fp32; kpad [B, N] (1 = padded key) or NULL.
+ * bwd: dq/dk/dv in the q/k/v layout; delta is a [B, H, N] fp32 scratch.                        */
+typedef struct w2vs_attn_desc {
+  const void* q; const void* k; const void* v; void* o; float* lse; const uint8_t* kpad;
+  const void* dout; float* delta; void* dq; void* dk; void* dv;
+  int64_t ld, ldo, sb, sbo;
+  int32_t B, H, N, Tp, m, r, head_dim;
+  float scale; float p_drop; uint64_t seed;
+} w2vs_attn_desc;
+int w2vs_attn_fwd(const w2vs_attn_desc* d, void* stream);
+int w2vs_attn_bwd(const w2vs_attn_desc* d, void* stream);
+
+/* ---- Gumbel vector quantizer ---------------------------------------------------------------------
+ * fs/modules/gumbel_vector_quantizer.py:141-202 after the weight_proj GEMM: hard argmax +
+ * code/prob perplexities (:152-169), gumbel-softmax hard sample (:173-176), codebook product
+ * (:192-195) done as a 2-row gather instead of a (B*M) x 640 x 128 broadcast product.
+ * logits [R, G*V] bf16; noise [R*G, V] fp32 Gumbel samples or NULL (device RNG from seed);
+ * vars [G*V, D]; q [R, G*D]; idx [R, G]; hard_cnt/prob_sum [G*V] fp32 scratch kept for bwd;
+ * ppl_out[2] = {prob_perplexity, code_perplexity}; cvec_out [G*V] = d prob_ppl / d avg_prob.
+ * bwd: dsoft [R, G*V] = dq . vars^T (one batched w2vs_gemm_nt per group);
+ *      ppl_grad = dLoss/d prob_perplexity.                                                        */
+typedef struct w2vs_quant_desc {
+  const void* logits; const float* noise; const void* vars;
+  void* q; int32_t* idx; float* hard_cnt; float* prob_sum; float* ppl_out; float* cvec_out;
+  const void* dq; const void* dsoft; const float* cvec; void* dlogits; float* dvars;
+  float ppl_grad; float tau; int32_t R, G, V, D, training; uint64_t seed;
+} w2vs_quant_desc;
+int w2vs_quant_fwd(const w2vs_quant_desc* d, void* stream);
+int w2vs_quant_bwd(const w2vs_quant_desc* d, void* stream);
+
+/* ---- InfoNCE logits -----------------------------------------------------------------------------
+ * sample_negatives' gather (wav2vec2.py:521-526) + compute_preds (:529-542) fused: the
+ * 100 x B x M x C negatives tensor is never materialised.  x, y [B*M, C] bf16, neg_idx [B, K*M]
+ * int64 (the reference's index tensor, rows of y.view(-1, C)), logits [B*M, K+1] fp32 with
+ * column 0 the positive; neg==pos entries are -inf.  bwd: dx, dy fp32 [B*M, C] (dy zeroed here). */
+typedef struct w2vs_nce_desc {
+  const void* x; const void* y; const int64_t* neg_idx; float* logits;
+  const float* dlogits; float* dx; float* dy;
+  int32_t B, M, K, C; float temp;
+} w2vs_nce_desc;
+int w2vs_nce_fwd(const w2vs_nce_desc* d, void* stream);
+int w2vs_nce_bwd(const w2vs_nce_desc* d, void* stream);
+
+/* ---- cross entropy (target 0, reduction=sum) + accuracy counters --------------------------------
+ * fs/criterions/wav2vec_criterion.py:68, 133-155.  out3 = {loss, #argmax==0, #(argmax==0 &&
+ * argmin==0)}; dlogits (optional) = softmax - onehot(0).                                          */
+int w2vs_ce_rows(const float* logits, int64_t R, int32_t W, float* out3, float* dlogits, void* stream);
+
+/* ---- small movers ------------------------------------------------------------------------------- */
+/* dst[i] = src[idx[i]] (scatter=0) or dst[idx[i]] = src[i] (scatter=1); rows of C bf16.
+ * x[mask_indices] / unmasked_features[mask_indices] (wav2vec2.py:590-592, 641) and their grads.  */
+int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, int32_t C, int32_t scatter, void* stream);
+int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* stream);
+int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* stream);
+/* out[n] += sum_m in[m, n] : bias gradients */
+int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2VS_H */

@@ -1,0 +1,452 @@
+"""Per-kernel parity: every C-ABI entry of libw2vs against the CPU oracle / fp32 torch math on
+the same seeded inputs.  Needs a real MI355X:  pytest -m gpu"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import w2vs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import wav2vec_s_amd  # noqa: F401
+    from wav2vec_s_amd import ops as _ops
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rel(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 320, 136), (6544, 768, 768), (1000, 2304, 768), (257, 640, 512)])
+def test_gemm_nt_bias(ops, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+    y = ops.linear_fwd(dev(x), dev(w), dev(b))
+    ref = x.float() @ w.float().t() + b.float()
+    assert rel(y, ref) < 5e-3
+
+
+def test_gemm_nt_gelu_save(ops):
+    M, N, K = 300, 256, 192
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    y, pre = ops.linear_fwd(dev(x), dev(w), dev(b), gelu=True, save_pre=True)
+    ref_pre = x.float() @ w.float().t() + b.float()
+    assert rel(pre, ref_pre) < 5e-3
+    assert rel(y, F.gelu(pre.float().cpu())) < 5e-3
+    y2 = ops.linear_fwd(dev(x), dev(w), dev(b), gelu=True)
+    assert rel(y2, F.gelu(ref_pre)) < 6e-3
+
+
+def test_gemm_nt_dgrad_dgelu(ops):
+    R, N, K = 260, 384, 256
+    dy, w, pre = rnd(R, N, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(R, K, seed=3)
+    wt = ops.transpose2d(dev(w))
+    assert torch.equal(wt.cpu(), w.t().contiguous())
+    dx = ops.linear_dgrad(dev(dy), wt)
+    assert rel(dx, dy.float() @ w.float()) < 5e-3
+    dx2 = ops.linear_dgrad(dev(dy), wt, dgelu_aux=dev(pre))
+    p = pre.float().requires_grad_(True)
+    F.gelu(p).backward(dx.float().cpu())  # gelu' applied to the bf16-rounded plain dgrad
+    assert rel(dx2, p.grad) < 6e-3
+
+
+@pytest.mark.parametrize("R,N,K", [(64, 128, 128), (1000, 256, 192), (6544, 768, 768), (333, 640, 512)])
+def test_gemm_tn_wgrad(ops, R, N, K):
+    dy, x = rnd(R, N, seed=1), rnd(R, K, seed=2)
+    dw = torch.zeros(N, K, device="cuda")
+    ops.linear_wgrad(dev(dy), dev(x), dw, alpha=0.5)
+    ref = 0.5 * dy.float().t() @ x.float()
+    assert rel(dw, ref) < 2e-3
+    db = torch.zeros(N, device="cuda")
+    ops.colsum(dev(dy), db)
+    assert rel(db, dy.float().sum(0)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ conv
+@pytest.mark.parametrize("k,s,Lin", [(3, 2, 401), (3, 2, 400), (2, 2, 300), (2, 2, 301)])
+def test_conv_channel_last(ops, k, s, Lin):
+    B, Cin, Cout = 3, 64, 128
+    x = rnd(B, Lin, Cin, seed=1)
+    w = rnd(Cout, Cin, k, seed=2, scale=0.1)
+    w2 = ops.conv_pack_weight(dev(w))
+    assert torch.equal(w2.cpu(), w.permute(0, 2, 1).reshape(Cout, k * Cin))
+    y, pre = ops.conv_cl_fwd(dev(x), w2, k, s)
+    xr = x.float().transpose(1, 2).requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    ref_pre = F.conv1d(xr, wr, stride=s)
+    assert rel(pre, ref_pre.transpose(1, 2)) < 5e-3
+    assert rel(y, F.gelu(pre.float().cpu())) < 5e-3
+    Lout = ref_pre.shape[-1]
+    dy = rnd(B, Lout, Cout, seed=3)
+    ref_pre.backward(dy.float().transpose(1, 2))
+    dx = ops.conv_cl_dgrad(dev(dy), dev(w), k, s, Lin)
+    assert rel(dx, xr.grad.transpose(1, 2)) < 5e-3
+    dw2 = torch.zeros(Cout, k * Cin, device="cuda")
+    ops.conv_cl_wgrad(dev(dy), dev(x), k, s, dw2)
+    assert rel(dw2, wr.grad.permute(0, 2, 1).reshape(Cout, k * Cin)) < 3e-3
+    # dgrad chained through the previous layer's GELU
+    aux = rnd(B, Lin, Cin, seed=4)
+    dx2 = ops.conv_cl_dgrad(dev(dy), dev(w), k, s, Lin, dgelu_aux=dev(aux))
+    a = aux.float().requires_grad_(True)
+    F.gelu(a).backward(dx.float().cpu())
+    assert rel(dx2, a.grad) < 6e-3
+
+
+def test_conv0_ln_gelu(ops):
+    B, L, Cc, k, s = 2, 4003, 512, 10, 5
+    wave = rnd(B, L, seed=1)
+    w = rnd(Cc, 1, k, seed=2, scale=0.4)
+    g, b = (1 + 0.1 * torch.randn(Cc)).to(BF), (0.1 * torch.randn(Cc)).to(BF)
+    y, mean, rstd = ops.conv0_fwd(dev(wave), dev(w), dev(g), dev(b), k, s)
+    P = {"feature_extractor.conv_layers.0.0.weight": w.float().requires_grad_(True),
+         "feature_extractor.conv_layers.0.2.1.weight": g.float().requires_grad_(True),
+         "feature_extractor.conv_layers.0.2.1.bias": b.float().requires_grad_(True)}
+    cfg = O.OracleCfg(conv_feature_layers="[(512, 10, 5)]")
+    ref = O.conv_feature_extractor(wave.float(), P, cfg)  # B x C x L0
+    assert rel(y, ref.transpose(1, 2)) < 5e-3
+    dy = rnd(*y.shape, seed=5)
+    ref.backward(dy.float().transpose(1, 2))
+    dw = torch.zeros(Cc, k, device="cuda")
+    dg = torch.zeros(Cc, device="cuda")
+    db = torch.zeros(Cc, device="cuda")
+    ops.conv0_bwd(dev(wave), dev(w), dev(g), dev(b), mean, rstd, dev(dy), k, s, dw, dg, db)
+    assert rel(dw, P["feature_extractor.conv_layers.0.0.weight"].grad.view(Cc, k)) < 5e-3
+    assert rel(dg, P["feature_extractor.conv_layers.0.2.1.weight"].grad) < 5e-3
+    assert rel(db, P["feature_extractor.conv_layers.0.2.1.bias"].grad) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("Cc", [512, 768, 1024])
+def test_layernorm_fwd_bwd(ops, Cc):
+    rows = 777
+    x, r = rnd(rows, Cc, seed=1), rnd(rows, Cc, seed=2)
+    g, b = (1 + 0.1 * torch.randn(Cc)).to(BF), (0.1 * torch.randn(Cc)).to(BF)
+    sumsq = torch.zeros(1, device="cuda")
+    y, s_out, mean, rstd = ops.ln_fwd(dev(x), dev(g), dev(b), res=dev(r), want_sum=True, sumsq=sumsq)
+    xs = (x.float() + r.float())
+    assert rel(s_out, xs) < 4e-3
+    sr = s_out.float().cpu().requires_grad_(True)
+    gr, br = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = F.layer_norm(sr, (Cc,), gr, br, 1e-5)
+    assert rel(y, ref) < 4e-3
+    assert abs(float(sumsq) - float((x.float() ** 2).sum())) / float((x.float() ** 2).sum()) < 1e-4
+    dy = rnd(rows, Cc, seed=3)
+    ref.backward(dy.float())
+    dg = torch.zeros(Cc, device="cuda")
+    db = torch.zeros(Cc, device="cuda")
+    dx, dres = ops.ln_bwd(s_out, dev(g), dev(b), mean, rstd, dg, db, dy=dev(dy), want_dres=True)
+    assert rel(dx, sr.grad) < 5e-3 and rel(dres, sr.grad) < 5e-3
+    assert rel(dg, gr.grad) < 5e-3 and rel(db, br.grad) < 5e-3
+
+
+def test_layernorm_gelu_penalty_scale(ops):
+    """feat-LN backward: GradMultiply scale, features_pen term and the producer's GELU chained."""
+    rows, Cc = 500, 512
+    pre = rnd(rows, Cc, seed=1)
+    g, b = (1 + 0.1 * torch.randn(Cc)).to(BF), (0.1 * torch.randn(Cc)).to(BF)
+    p = pre.float().requires_grad_(True)
+    x = F.gelu(p)
+    xb = x.detach().to(BF)
+    y, _, mean, rstd = ops.ln_fwd(dev(xb), dev(g), dev(b))
+    xr = xb.float().requires_grad_(True)
+    ref = F.layer_norm(xr, (Cc,), g.float(), b.float(), 1e-5)
+    assert rel(y, ref) < 4e-3
+    dy = rnd(rows, Cc, seed=2)
+    pen_coef, scale = 0.37, 0.1
+    (ref * dy.float()).sum().backward()
+    want_dx = (xr.grad + 2 * xb.float() * pen_coef) * scale
+    F.gelu(p).backward(want_dx)
+    dg = torch.zeros(Cc, device="cuda"); db = torch.zeros(Cc, device="cuda")
+    dx, _ = ops.ln_bwd(dev(xb), dev(g), dev(b), mean, rstd, dg, db, dy=dev(dy), aux=dev(pre), out_scale=scale,
+                       pen_coef=pen_coef)
+    assert rel(dx, p.grad) < 8e-3
+
+
+def test_dropout_statistics_and_consistency(ops):
+    rows, Cc, p = 2048, 768, 0.1
+    x = torch.ones(rows, Cc).to(BF)
+    zero = torch.zeros(rows, Cc).to(BF)
+    g, b = torch.ones(Cc).to(BF), torch.zeros(Cc).to(BF)
+    _, s1, _, _ = ops.ln_fwd(dev(x), dev(g), dev(b), res=dev(zero), want_y=False, want_sum=True, p_drop=p, seed=1234)
+    _, s2, _, _ = ops.ln_fwd(dev(x), dev(g), dev(b), res=dev(zero), want_y=False, want_sum=True, p_drop=p, seed=1234)
+    _, s3, _, _ = ops.ln_fwd(dev(x), dev(g), dev(b), res=dev(zero), want_y=False, want_sum=True, p_drop=p, seed=99)
+    assert torch.equal(s1, s2) and not torch.equal(s1, s3)
+    keep = (s1.float() > 0).float().mean().item()
+    assert abs(keep - 0.9) < 3e-3
+    vals = torch.unique(s1.float().cpu())
+    assert set(np.round(vals.numpy(), 3)) <= {0.0, round(float(torch.tensor(1 / 0.9).to(BF)), 3)}
+    # backward uses the same mask: d(x) = mask/(1-p) * dy with LN bypassed (dsum path)
+    y, s, mean, rstd = ops.ln_fwd(dev(x), dev(g), dev(b), res=dev(zero), want_sum=True, p_drop=p, seed=1234)
+    dg = torch.zeros(Cc, device="cuda"); db = torch.zeros(Cc, device="cuda")
+    dx, _ = ops.ln_bwd(s, dev(g), dev(b), mean, rstd, dg, db, dy=None, dsum=dev(x), p_drop=p, seed=1234)
+    assert torch.equal(dx, s1)
+
+
+# ------------------------------------------------------------------------------------------ prologue
+def _structure(Tp, m, r):
+    rc_idx, rc_oob, masked = O.block_structure(Tp, m, r)
+    src = torch.cat([torch.arange(Tp), rc_idx]).int()
+    copies = [[] for _ in range(Tp)]
+    for c, t in enumerate(rc_idx.tolist()):
+        copies[t].append(Tp + c)
+    start = np.zeros(Tp + 1, dtype=np.int32)
+    for t in range(Tp):
+        start[t + 1] = start[t] + len(copies[t])
+    lst = np.array([c for cs in copies for c in cs] or [0], dtype=np.int32)
+    return rc_idx, rc_oob, masked, src, torch.from_numpy(start), torch.from_numpy(lst)
+
+
+@pytest.mark.parametrize("T,m,r,apply_ln", [(49, 8, 4, True), (50, 16, 8, True), (33, 8, 4, False)])
+def test_enc_prologue(ops, T, m, r, apply_ln):
+    B, Cc = 2, 768
+    Tp = T + (T % 2)
+    x = rnd(B, T, Cc, seed=1)
+    mask = torch.zeros(B, T, dtype=torch.bool)
+    mask[0, 3:13] = True
+    mask[1, 20:30] = True
+    mask_emb = rnd(Cc, seed=2)
+    g, b = (1 + 0.1 * torch.randn(Cc)).to(BF), (0.1 * torch.randn(Cc)).to(BF)
+    table = O.sinusoidal_table(8002, Cc, 1)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pos = O.positions_from_padding(pad).int()
+    rc_idx, rc_oob, masked, src, cstart, clist = _structure(Tp, m, r)
+    out, mean, rstd = ops.enc_prologue_fwd(dev(x), dev(mask.to(torch.uint8)), None, dev(pos), dev(mask_emb), dev(table),
+                                           dev(g), dev(b), dev(src), Tp, apply_ln=apply_ln)
+    # oracle steps (wav2vec2.py:446, wav2vec_S.py:357-388, 465-484)
+    xr = x.float().requires_grad_(True)
+    me = mask_emb.float().requires_grad_(True)
+    gr, br = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    v = torch.where(mask.unsqueeze(-1), me.view(1, 1, Cc).expand(B, T, Cc), xr)
+    v = v + table.index_select(0, pos.long().view(-1)).view(B, T, Cc)
+    if apply_ln:
+        v = F.layer_norm(v, (Cc,), gr, br, 1e-5)
+    v = F.pad(v, (0, 0, 0, Tp - T))
+    full = torch.cat([v, v.index_select(1, rc_idx)], dim=1)
+    assert rel(out, full) < 5e-3
+    dout = rnd(*full.shape, seed=5)
+    full.backward(dout.float())
+    dme = torch.zeros(Cc, device="cuda"); dg = torch.zeros(Cc, device="cuda"); db = torch.zeros(Cc, device="cuda")
+    dx = ops.enc_prologue_bwd(dev(dout), dev(x), dev(mask.to(torch.uint8)), None, dev(pos), dev(mask_emb), dev(table),
+                              dev(g), dev(b), mean, rstd, dev(src), dev(cstart), dev(clist), Tp, dme, dg, db,
+                              apply_ln=apply_ln)
+    assert rel(dx, xr.grad) < 6e-3
+    assert rel(dme, me.grad) < 6e-3
+    if apply_ln:
+        assert rel(dg, gr.grad) < 6e-3 and rel(db, br.grad) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _dense_attention(qkv, H, Tp, m, r, kpad):
+    """Reference semantics: additive -1e4 block mask + -inf key padding, softmax, P.V (oracle encoder_layer core)."""
+    B, N, C3 = qkv.shape
+    Cc = C3 // 3
+    D = Cc // H
+    q, k, v = qkv.float().split(Cc, dim=-1)
+    q = q.view(B, N, H, D).permute(0, 2, 1, 3) * (D ** -0.5)
+    k = k.view(B, N, H, D).permute(0, 2, 1, 3)
+    v = v.view(B, N, H, D).permute(0, 2, 1, 3)
+    _, _, masked = O.block_structure(Tp, m, r)
+    add = torch.zeros(N, N).masked_fill(masked, -1e4).view(1, 1, N, N)
+    if kpad is not None:
+        add = add + torch.zeros(B, 1, 1, N).masked_fill(kpad.bool().view(B, 1, 1, N), float("-inf"))
+    p = torch.softmax(q @ k.transpose(-1, -2) + add, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B, N, Cc)
+
+
+@pytest.mark.parametrize("Tp,m,r,H", [(48, 16, 8, 2), (50, 8, 4, 3), (130, 32, 16, 2), (546, 16, 8, 2), (40, 8, 0, 1),
+                                      (10, 16, 8, 1), (300, 24, 6, 2)])
+def test_block_attention(ops, Tp, m, r, H):
+    B = 2
+    N = Tp + (Tp // m) * r
+    Cc = H * 64
+    qkv = rnd(B, N, 3 * Cc, seed=Tp)
+    rc_idx, rc_oob, _ = O.block_structure(Tp, m, r)
+    pad = torch.zeros(B, Tp, dtype=torch.bool)
+    pad[1, Tp - 1] = True
+    kpad = pad
+    if r > 0:
+        kpad = torch.cat([pad, pad.index_select(1, rc_idx) | rc_oob.unsqueeze(0)], dim=1)
+    o, lse = ops.attn_fwd(dev(qkv), H, Tp, m, r, kpad=dev(kpad.to(torch.uint8)))
+    qr = qkv.float().requires_grad_(True)
+    ref = _dense_attention(qr, H, Tp, m, r, kpad)
+    assert rel(o, ref) < 8e-3
+    dout = rnd(B, N, Cc, seed=7)
+    ref.backward(dout.float())
+    dqkv = ops.attn_bwd(dev(dout), dev(qkv), o, lse, H, Tp, m, r, kpad=dev(kpad.to(torch.uint8)))
+    Cq = Cc
+    for name, sl in [("dq", slice(0, Cq)), ("dk", slice(Cq, 2 * Cq)), ("dv", slice(2 * Cq, 3 * Cq))]:
+        e = rel(dqkv[..., sl], qr.grad[..., sl])
+        assert e < 1.5e-2, (name, e)
+
+
+def test_attention_dropout_consistency(ops):
+    """fwd and the two bwd passes regenerate the same keep-mask: finite-difference style check
+    through linearity in V (O is linear in V for a fixed mask) and dV == P_drop^T dO."""
+    B, H, Tp, m, r = 1, 1, 64, 16, 8
+    N = Tp + (Tp // m) * r
+    qkv = rnd(B, N, 192, seed=3)
+    p = 0.25
+    o1, lse = ops.attn_fwd(dev(qkv), H, Tp, m, r, p_drop=p, seed=42)
+    o2, _ = ops.attn_fwd(dev(qkv), H, Tp, m, r, p_drop=p, seed=42)
+    o3, _ = ops.attn_fwd(dev(qkv), H, Tp, m, r, p_drop=p, seed=43)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    # recover the dropped probability matrix 64 key columns at a time with one-hot V rows
+    Pd = torch.zeros(N, N)
+    for c0 in range(0, N, 64):
+        w = min(64, N - c0)
+        vv = qkv.float().clone()
+        vv[..., 128:] = 0
+        vv[0, c0:c0 + w, 128:128 + w] = torch.eye(w)
+        oc, _ = ops.attn_fwd(dev(vv.to(BF)), H, Tp, m, r, p_drop=p, seed=42)
+        Pd[:, c0:c0 + w] = oc[0].float().cpu()[:, :w]
+    _, _, masked = O.block_structure(Tp, m, r)
+    assert float(Pd[masked].abs().max()) == 0.0
+    allowed = ~masked
+    frac_zero = float((Pd[allowed] == 0).float().mean())
+    assert abs(frac_zero - p) < 0.03
+    dout = rnd(B, N, 64, seed=9)
+    dqkv = ops.attn_bwd(dev(dout), dev(qkv), o1, lse, H, Tp, m, r, p_drop=p, seed=42)
+    dv_ref = Pd.t() @ dout[0].float()
+    assert rel(dqkv[0, :, 128:], dv_ref) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------ quantizer
+@pytest.mark.parametrize("training", [True, False])
+def test_gumbel_quantizer(ops, training):
+    B, M, Fd, G, V, D = 2, 37, 512, 2, 320, 128
+    cfg = O.OracleCfg()
+    P = {"quantizer.weight_proj.weight": rnd(G * V, Fd, seed=1, scale=0.2).float(),
+         "quantizer.weight_proj.bias": rnd(G * V, seed=2, scale=0.1).float(),
+         "quantizer.vars": torch.rand(1, G * V, D).to(BF).float()}
+    y = rnd(B, M, Fd, seed=3)
+    logits = ops.linear_fwd(dev(y.view(-1, Fd)), dev(P["quantizer.weight_proj.weight"].to(BF)),
+                            dev(P["quantizer.weight_proj.bias"].to(BF)))
+    noise = None
+    if training:
+        g = torch.Generator().manual_seed(5)
+        noise = -torch.empty(B * M * G, V).exponential_(generator=g).log()
+    q, st = ops.quant_fwd(logits, dev(P["quantizer.vars"][0].to(BF)), G, V, 1.7, training,
+                          noise=dev(noise) if training else None)
+    # oracle on the SAME bf16 logits (the linear itself is checked by the GEMM tests)
+    lg = logits.float().cpu().requires_grad_(True)
+    vars_ = P["quantizer.vars"].clone().requires_grad_(True)
+    Pq = dict(P)
+    Pq["quantizer.vars"] = vars_
+
+    def from_logits(lg):
+        # gumbel_quantize with the projection replaced by identity on precomputed logits
+        Pi = dict(Pq)
+        Pi["quantizer.weight_proj.weight"] = torch.eye(G * V)
+        Pi["quantizer.weight_proj.bias"] = torch.zeros(G * V)
+        return O.gumbel_quantize(lg.view(B, M, G * V), Pi, cfg, 1.7, noise)
+
+    qr, idx, prob_ppl, code_ppl = from_logits(lg)
+    assert torch.equal(st.idx.cpu().long(), idx)
+    assert rel(q, qr.view(B * M, G * D)) < 1e-6
+    assert abs(float(st.ppl[0]) - float(prob_ppl)) / float(prob_ppl) < 1e-4
+    assert abs(float(st.ppl[1]) - float(code_ppl)) / float(code_ppl) < 1e-4
+    dq = rnd(B * M, G * D, seed=8)
+    ppl_grad = -0.3
+    ((qr.view(B * M, G * D) * dq.float()).sum() + ppl_grad * prob_ppl).backward()
+    dvars = torch.zeros(G * V, D, device="cuda")
+    dlogits = ops.quant_bwd(dev(dq), logits, dev(P["quantizer.vars"][0].to(BF)), st, G, V, 1.7, training, ppl_grad,
+                            dvars, noise=dev(noise) if training else None)
+    assert rel(dvars, vars_.grad[0]) < 2e-3
+    assert rel(dlogits, lg.grad) < 1.5e-2
+
+
+def test_gumbel_device_rng_statistics(ops):
+    R, G, V, D = 4096, 2, 320, 128
+    logits = torch.zeros(R, G * V).to(BF)
+    vars2 = torch.rand(G * V, D).to(BF)
+    q, st = ops.quant_fwd(dev(logits), dev(vars2), G, V, 2.0, True, seed=7)
+    q2, st2 = ops.quant_fwd(dev(logits), dev(vars2), G, V, 2.0, True, seed=7)
+    assert torch.equal(st.idx, st2.idx)
+    cnt = torch.bincount(st.idx[:, 0].cpu().long(), minlength=V).float()
+    # uniform logits + iid gumbel noise -> uniform argmax: chi-square well inside a loose bound
+    chi2 = float(((cnt - R / V) ** 2 / (R / V)).sum())
+    assert chi2 < 2 * V
+
+
+# ------------------------------------------------------------------------------------------ InfoNCE
+@pytest.mark.parametrize("B,M,K,Cc", [(2, 20, 10, 256), (3, 37, 100, 256), (2, 16, 7, 768)])
+def test_infonce_logits(ops, B, M, K, Cc):
+    cfg = O.OracleCfg()
+    x, y = rnd(B, M, Cc, seed=1), rnd(B, M, Cc, seed=2)
+    y[0, 3] = y[0, 5]  # a negative equal to the positive -> -inf (wav2vec2.py:531, 539-540)
+    torch.manual_seed(0)
+    neg = O.sample_negative_indices(B, M, K)
+    neg[0, 3 * K] = 5
+    logits = ops.nce_fwd(dev(x.view(-1, Cc)), dev(y.view(-1, Cc)), dev(neg), B, M, K, cfg.logit_temp)
+    xr, yr = x.float().requires_grad_(True), y.float().requires_grad_(True)
+    preds, ref = O.compute_logits(xr, yr, neg, cfg)
+    ref_bm = preds.permute(1, 2, 0).reshape(B * M, K + 1)  # rows (b, m)
+    inf_mask = torch.isinf(ref_bm)
+    assert torch.equal(torch.isinf(logits.cpu()), inf_mask) and bool(inf_mask.any())
+    assert float((logits.cpu()[~inf_mask] - ref_bm[~inf_mask]).abs().max()) < 2e-3
+    dl = torch.randn(B * M, K + 1)
+    dl[inf_mask] = 0
+    (ref_bm.masked_fill(inf_mask, 0) * dl).sum().backward()
+    dx, dy = ops.nce_bwd(dev(dl), dev(x.view(-1, Cc)), dev(y.view(-1, Cc)), dev(neg), B, M, K, cfg.logit_temp)
+    assert rel(dx, xr.grad.view(-1, Cc)) < 2e-3
+    assert rel(dy, yr.grad.view(-1, Cc)) < 2e-3
+
+
+def test_cross_entropy_rows(ops):
+    R, W = 999, 101
+    logits = torch.randn(R, W) * 3
+    logits[5, 7] = float("-inf")
+    logits[11, 0] = 50.0
+    out3, dl = ops.ce_rows(dev(logits))
+    lr = logits.clone().requires_grad_(True)
+    loss = F.cross_entropy(lr, torch.zeros(R, dtype=torch.long), reduction="sum")
+    loss.backward()
+    assert abs(float(out3[0]) - float(loss)) / float(loss) < 1e-5
+    mx = logits.argmax(-1) == 0
+    mn = logits.argmin(-1) == 0
+    assert int(out3[1]) == int(mx.sum()) and int(out3[2]) == int((mx & mn).sum())
+    assert float((dl.cpu() - lr.grad).abs().max()) < 1e-5
+
+
+def test_gather_scatter_rows(ops):
+    R, Cc, S = 100, 512, 300
+    src = rnd(S, Cc, seed=1)
+    idx = torch.randperm(S)[:R].int()
+    out = ops.gather_rows(dev(src), dev(idx), R)
+    assert torch.equal(out.cpu(), src[idx.long()])
+    back = torch.zeros(S, Cc, device="cuda", dtype=BF)
+    ops.gather_rows(out, dev(idx), R, scatter=True, out=back)
+    want = torch.zeros(S, Cc, dtype=BF)
+    want[idx.long()] = src[idx.long()]
+    assert torch.equal(back.cpu(), want)
+
+
+def test_rejects_bad_arguments(ops):
+    from wav2vec_s_amd._lib import W2vsError
+    with pytest.raises(W2vsError):
+        ops.linear_fwd(torch.zeros(4, 8, dtype=BF), torch.zeros(4, 8, dtype=BF).cuda())  # CPU tensor
+    with pytest.raises(W2vsError):
+        ops.attn_fwd(torch.zeros(1, 10, 3 * 32, dtype=BF, device="cuda"), 1, 10, 4, 0)  # head_dim 32
+    with pytest.raises(W2vsError):
+        ops.ln_fwd(torch.zeros(4, 2048, dtype=BF, device="cuda"), torch.zeros(2048, dtype=BF, device="cuda"),
+                   torch.zeros(2048, dtype=BF, device="cuda"))

@@ -1,0 +1,127 @@
+"""ctypes binding of libw2vs.so (the C ABI in include/w2vs.h).
+
+There is NO fallback: if the HIP library is missing or a call is rejected, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libw2vs.so")
+
+vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("C2", vp), ("Cf", vp), ("bias", vp), ("aux", vp),
+                ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
+                ("lda", i64), ("ldb", i64), ("ldc", i64), ("a_off", i64),
+                ("sA", i64), ("sB", i64), ("sC", i64), ("a_bytes", i64), ("b_bytes", i64), ("c_elems", i64),
+                ("epi", i32), ("alpha", f32)]
+
+
+class LnFwdDesc(C.Structure):
+    _fields_ = [("x", vp), ("res", vp), ("gamma", vp), ("beta", vp), ("y", vp), ("sum_out", vp),
+                ("mean", vp), ("rstd", vp), ("sumsq", vp), ("rows", i64), ("C", i32), ("gelu", i32),
+                ("p_drop", f32), ("seed", u64)]
+
+
+class LnBwdDesc(C.Structure):
+    _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp), ("dy", vp), ("dsum", vp),
+                ("aux", vp), ("dx", vp), ("dres", vp), ("dgamma", vp), ("dbeta", vp), ("rows", i64),
+                ("C", i32), ("gelu", i32), ("p_drop", f32), ("seed", u64), ("out_scale", f32), ("pen_coef", f32)]
+
+
+class EncPrologueDesc(C.Structure):
+    _fields_ = [("x", vp), ("mask", vp), ("pad", vp), ("pos", vp), ("mask_emb", vp), ("pos_table", vp),
+                ("gamma", vp), ("beta", vp), ("out", vp), ("mean", vp), ("rstd", vp), ("src", vp),
+                ("dout", vp), ("dx", vp), ("dmask_emb", vp), ("dgamma", vp), ("dbeta", vp),
+                ("copy_start", vp), ("copy_list", vp),
+                ("p_in", f32), ("p_enc", f32), ("seed_in", u64), ("seed_enc", u64),
+                ("apply_ln", i32), ("B", i32), ("T", i32), ("Tp", i32), ("N", i32), ("C", i32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("o", vp), ("lse", vp), ("kpad", vp),
+                ("dout", vp), ("delta", vp), ("dq", vp), ("dk", vp), ("dv", vp),
+                ("ld", i64), ("ldo", i64), ("sb", i64), ("sbo", i64),
+                ("B", i32), ("H", i32), ("N", i32), ("Tp", i32), ("m", i32), ("r", i32), ("head_dim", i32),
+                ("scale", f32), ("p_drop", f32), ("seed", u64)]
+
+
+class QuantDesc(C.Structure):
+    _fields_ = [("logits", vp), ("noise", vp), ("vars", vp), ("q", vp), ("idx", vp), ("hard_cnt", vp),
+                ("prob_sum", vp), ("ppl_out", vp), ("cvec_out", vp), ("dq", vp), ("dsoft", vp), ("cvec", vp),
+                ("dlogits", vp), ("dvars", vp), ("ppl_grad", f32), ("tau", f32),
+                ("R", i32), ("G", i32), ("V", i32), ("D", i32), ("training", i32), ("seed", u64)]
+
+
+class NceDesc(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("neg_idx", vp), ("logits", vp), ("dlogits", vp), ("dx", vp), ("dy", vp),
+                ("B", i32), ("M", i32), ("K", i32), ("C", i32), ("temp", f32)]
+
+
+_DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc]
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32 = range(6)
+
+# name -> argtypes ; every entry returns int
+_SIGS = {
+    "w2vs_gemm_nt": [C.POINTER(GemmDesc), vp],
+    "w2vs_gemm_tn": [C.POINTER(GemmDesc), i32, vp],
+    "w2vs_conv0_fwd": [vp] * 8 + [i32] * 5 + [vp],
+    "w2vs_conv0_bwd": [vp] * 12 + [i32] * 5 + [vp],
+    "w2vs_ln_fwd": [C.POINTER(LnFwdDesc), vp],
+    "w2vs_ln_bwd": [C.POINTER(LnBwdDesc), vp],
+    "w2vs_enc_prologue_fwd": [C.POINTER(EncPrologueDesc), vp],
+    "w2vs_enc_prologue_bwd": [C.POINTER(EncPrologueDesc), vp],
+    "w2vs_attn_fwd": [C.POINTER(AttnDesc), vp],
+    "w2vs_attn_bwd": [C.POINTER(AttnDesc), vp],
+    "w2vs_quant_fwd": [C.POINTER(QuantDesc), vp],
+    "w2vs_quant_bwd": [C.POINTER(QuantDesc), vp],
+    "w2vs_nce_fwd": [C.POINTER(NceDesc), vp],
+    "w2vs_nce_bwd": [C.POINTER(NceDesc), vp],
+    "w2vs_ce_rows": [vp, i64, i32, vp, vp, vp],
+    "w2vs_gather_rows": [vp, vp, vp, i64, i32, i32, vp],
+    "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],
+    "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],
+    "w2vs_colsum": [vp, vp, i64, i32, i64, vp],
+}
+EXPORTS = ["w2vs_abi_version", "w2vs_last_error", "w2vs_sizeof"] + list(_SIGS)
+
+_lib = None
+
+
+class W2vsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libw2vs.so; raise loudly if it is absent or does not match this binding."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise W2vsError(
+            "libw2vs.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C wav2vec-s_amd/csrc`). There is no CPU/eager fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.w2vs_last_error.restype = C.c_char_p
+    lib.w2vs_sizeof.argtypes = [i32]
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    if lib.w2vs_abi_version() != 1:
+        raise W2vsError("libw2vs ABI version mismatch")
+    for i, d in enumerate(_DESCS):
+        if lib.w2vs_sizeof(i) != C.sizeof(d):
+            raise W2vsError("descriptor %s: C sizeof %d != binding %d" % (d.__name__, lib.w2vs_sizeof(i), C.sizeof(d)))
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise W2vsError("%s failed (%d): %s" % (name, rc, lib.w2vs_last_error().decode()))

@@ -1,0 +1,63 @@
+// extern "C" surface of libw2vs (declared in include/w2vs.h).
+#include <string.h>
+#include <string>
+#include "w2vs_internal.h"
+
+namespace w2vs {
+static thread_local std::string g_err;
+int set_error(const char* msg) { g_err = msg; return W2VS_ERR_INVALID; }
+int hip_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return W2VS_ERR_HIP;
+}
+}  // namespace w2vs
+
+using namespace w2vs;
+#define ST(s) ((hipStream_t)(s))
+#define NONNULL(d) if (!(d)) return set_error("null descriptor")
+
+extern "C" {
+int w2vs_abi_version(void) { return W2VS_ABI_VERSION; }
+const char* w2vs_last_error(void) { return g_err.c_str(); }
+int w2vs_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(w2vs_gemm_desc);
+    case 1: return (int)sizeof(w2vs_ln_fwd_desc);
+    case 2: return (int)sizeof(w2vs_ln_bwd_desc);
+    case 3: return (int)sizeof(w2vs_enc_prologue_desc);
+    case 4: return (int)sizeof(w2vs_attn_desc);
+    case 5: return (int)sizeof(w2vs_quant_desc);
+    case 6: return (int)sizeof(w2vs_nce_desc);
+  }
+  return -1;
+}
+int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* s) { NONNULL(d); return gemm_nt(*d, ST(s)); }
+int w2vs_gemm_tn(const w2vs_gemm_desc* d, int cu, void* s) { NONNULL(d); return gemm_tn(*d, cu, ST(s)); }
+int w2vs_conv0_fwd(const void* wave, const void* w, const void* cb, const void* lw, const void* lb, void* y, float* mean,
+                   float* rstd, int B, int L, int C, int k, int st, void* s) {
+  return conv0_fwd(wave, w, cb, lw, lb, y, mean, rstd, B, L, C, k, st, ST(s));
+}
+int w2vs_conv0_bwd(const void* wave, const void* w, const void* cb, const void* lw, const void* lb, const float* mean,
+                   const float* rstd, const void* dy, float* dw, float* dcb, float* dlw, float* dlb, int B, int L, int C,
+                   int k, int st, void* s) {
+  return conv0_bwd(wave, w, cb, lw, lb, mean, rstd, dy, dw, dcb, dlw, dlb, B, L, C, k, st, ST(s));
+}
+int w2vs_ln_fwd(const w2vs_ln_fwd_desc* d, void* s) { NONNULL(d); return ln_fwd(*d, ST(s)); }
+int w2vs_ln_bwd(const w2vs_ln_bwd_desc* d, void* s) { NONNULL(d); return ln_bwd(*d, ST(s)); }
+int w2vs_enc_prologue_fwd(const w2vs_enc_prologue_desc* d, void* s) { NONNULL(d); return enc_prologue_fwd(*d, ST(s)); }
+int w2vs_enc_prologue_bwd(const w2vs_enc_prologue_desc* d, void* s) { NONNULL(d); return enc_prologue_bwd(*d, ST(s)); }
+int w2vs_attn_fwd(const w2vs_attn_desc* d, void* s) { NONNULL(d); return attn_fwd(*d, ST(s)); }
+int w2vs_attn_bwd(const w2vs_attn_desc* d, void* s) { NONNULL(d); return attn_bwd(*d, ST(s)); }
+int w2vs_quant_fwd(const w2vs_quant_desc* d, void* s) { NONNULL(d); return quant_fwd(*d, ST(s)); }
+int w2vs_quant_bwd(const w2vs_quant_desc* d, void* s) { NONNULL(d); return quant_bwd(*d, ST(s)); }
+int w2vs_nce_fwd(const w2vs_nce_desc* d, void* s) { NONNULL(d); return nce_fwd(*d, ST(s)); }
+int w2vs_nce_bwd(const w2vs_nce_desc* d, void* s) { NONNULL(d); return nce_bwd(*d, ST(s)); }
+int w2vs_ce_rows(const float* logits, int64_t R, int32_t W, float* out3, float* dl, void* s) { return ce_rows(logits, R, W, out3, dl, ST(s)); }
+int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, int32_t C, int32_t sc, void* s) {
+  return gather_rows(src, idx, dst, R, C, sc, ST(s));
+}
+int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* s) { return transpose2d(in, out, R, C, batch, ST(s)); }
+int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* s) { return f32_to_bf16(in, out, n, scale, ST(s)); }
+int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* s) { return colsum(in, out, M, N, ld, ST(s)); }
+}

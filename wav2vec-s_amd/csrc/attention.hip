@@ -1,0 +1,506 @@
+// Block-causal streaming attention with per-block right-context copies (gfx950, head_dim 64).
+//
+// Replaces gen_block_attn_mask + F.multi_head_attention_forward's core
+// (fs/models/wav2vec/wav2vec_S.py:444-489, fs/modules/multihead_attention.py:161-193).
+// The reference materialises an N x N float mask (0 / -1e4) and a B x N key-padding mask and
+// runs dense attention; here the mask is never built.  Token n < Tp is main frame n of block
+// n/m; token Tp+c is right-context copy c of block c/r.  Query q (block bq) may attend key k
+//     k <  Tp : iff k < min((bq+1)*m, Tp)
+//     k >= Tp : iff Tp + bq*r <= k < Tp + (bq+1)*r
+// and never a padded key.  exp(-1e4 + s - max) underflows to exactly 0 in fp32, so dropping
+// masked keys equals the reference's additive -1e4 for every row that has an allowed key
+// (always true: a query's own block is allowed).  Whole 64-key tiles outside a query
+// tile's allowed set are skipped.
+//
+// Flash-style: scores never touch HBM.  MFMA 32x32x16 bf16; S is computed TRANSPOSED
+// (keys on accumulator rows, queries on lanes) so that softmax statistics are per-lane scalars
+// and the bf16-converted accumulator is directly the B operand of the P.V product; V^T / K^T /
+// Q^T / dO^T operands come out of row-major LDS tiles through ds_read_b64_tr_b16.
+#include "common.h"
+#include "w2vs_internal.h"
+
+namespace w2vs {
+
+constexpr int HD = 64;         // head dim
+constexpr int QB = 128;        // queries per block (4 waves x 32)
+constexpr int KT = 64;         // keys per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnP {
+  const bf16* q; const bf16* k; const bf16* v;  // [B, N, ld] with the head at column h*64
+  bf16* o;                                      // [B, N, ldo]
+  float* lse;                                   // [B, H, N] natural-log LSE of the scaled scores
+  const uint8_t* kpad;                          // [B, N] 1 = padded key (may be null)
+  const bf16* dout; const float* delta;         // backward
+  bf16* dq; bf16* dk; bf16* dv;                 // [B, N, ld] same layout as q/k/v
+  long ld, ldo, sb, sbo;                        // row stride, batch stride (elements)
+  int B, H, N, Tp, m, r;
+  float scale; float p_drop; uint64_t seed;
+};
+
+// LDS image of a [rows][64] bf16 tile read by rows (16-B chunks): XOR swizzle as in gemm.hip
+__device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+// LDS image of a [rows][64] bf16 tile read through tr reads (8-B pieces): flip the 64-B half on
+// rows 2,3 (mod 4) so the four rows of a tr block sit on distinct banks
+__device__ __forceinline__ int vswz(int row, int col) { return row * 64 + (col ^ (((row >> 1) & 1) << 5)); }
+
+__device__ __forceinline__ s16x4 ds_tr16(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x8 tr_pair(const bf16* lo, const bf16* hi) {
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = ds_tr16(lo);
+  u.h[1] = ds_tr16(hi);
+  return u.v;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = f2bf(a[8 * s + j]);
+  return r;
+}
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+struct QLimits { int lim, clo, chi; };
+__device__ __forceinline__ QLimits q_limits(int q, int Tp, int m, int r, int N) {
+  QLimits L;
+  int bq = (q < Tp) ? q / m : (r > 0 ? (q - Tp) / r : 0);
+  L.lim = min((bq + 1) * m, Tp);
+  L.clo = r > 0 ? Tp + bq * r : N;
+  L.chi = r > 0 ? min(Tp + (bq + 1) * r, N) : N;
+  return L;
+}
+// key range a set of queries [q0, q1] can touch: main keys [0, mlim), copies [clo, chi)
+__device__ __forceinline__ void tile_ranges(int q0, int q1, int Tp, int m, int r, int N, int& mlim, int& clo, int& chi) {
+  int bmin, bmax;
+  if (q1 < Tp) { bmin = q0 / m; bmax = q1 / m; }
+  else if (q0 >= Tp) { bmin = r > 0 ? (q0 - Tp) / r : 0; bmax = r > 0 ? (q1 - Tp) / r : 0; }
+  else { bmin = 0; bmax = (Tp - 1) / m; }
+  mlim = min((bmax + 1) * m, Tp);
+  clo = r > 0 ? Tp + bmin * r : N;
+  chi = r > 0 ? min(Tp + (bmax + 1) * r, N) : N;
+}
+__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+  return hash32(seed, idx) >= thr ? inv_keep : 0.f;
+}
+
+// cooperative load of a [64][64] tile (rows row0.., zero beyond nrows) into a swizzled LDS image
+template <bool TR>
+__device__ __forceinline__ void load_tile(bf16* dst, const bf16* src, long ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int c = tid + 256 * j, row = c >> 3, ch = c & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + row < nrows) v = *(const u32x4*)(src + (long)(row0 + row) * ld + ch * 8);
+    int off = TR ? vswz(row, ch * 8) : kswz(row, ch);
+    *(u32x4*)(dst + off) = v;
+  }
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) bf16 Ks[KT * HD];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[KT * HD];
+  __shared__ __attribute__((aligned(16))) float kbias[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk0 = blockIdx.x * QB;
+  const int q = qblk0 + wid * 32 + r32;
+  const int N = p.N;
+  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* K = p.k + (long)b * p.sb + h * HD;
+  const bf16* V = p.v + (long)b * p.sb + h * HD;
+  const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (q < N) qf[s] = *(const bf16x8*)(Q + (long)q * p.ld + 16 * s + 8 * hh);
+    else
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = f2bf(0.f);
+  }
+  const QLimits L = q_limits(min(q, N - 1), p.Tp, p.m, p.r, N);
+  int mlim, bclo, bchi;
+  tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+
+  const float c = p.scale * LOG2E;
+  const uint32_t thr = drop_threshold(p.p_drop);
+  const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint64_t drow = ((uint64_t)(b * p.H + h) * N + (uint64_t)min(q, N - 1)) * N;
+
+  f32x16 O0, O1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { O0[i] = 0.f; O1[i] = 0.f; }
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int kt0 = 0; kt0 < N; kt0 += KT) {
+    const bool need = (kt0 < mlim) || (kt0 < bchi && kt0 + KT > bclo);
+    if (!need) continue;  // block-uniform
+    __syncthreads();
+    load_tile<false>(Ks, K, p.ld, kt0, N, tid);
+    load_tile<true>(Vs, V, p.ld, kt0, N, tid);
+    if (tid < KT) {
+      int key = kt0 + tid;
+      kbias[tid] = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 S;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 a = *(const bf16x8*)(Ks + kswz(sub * 32 + r32, 2 * s + hh));
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], S, 0, 0, 0);
+      }
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
+        bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
+        float sv = ok ? S[i] * c + kbias[kl] : -INFINITY;
+        S[i] = sv;
+        mloc = fmaxf(mloc, sv);
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mnew = fmaxf(mrun, mloc);
+      const float muse = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = exp2f(mrun - muse);
+      mrun = mnew;
+      float ls = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float e = exp2f(S[i] - muse);
+        ls += e;
+        if (p.p_drop > 0.f) e *= keep_scale(p.seed, drow + (uint64_t)(kt0 + sub * 32 + acc_row(i, hh)), thr, inv_keep);
+        S[i] = e;
+      }
+      lrun = lrun * alpha + ls;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pb = pack8(S, s2);
+        const int krow = sub * 32 + 16 * s2 + 4 * (g >> 1) + tq;
+        const int dcol = (g & 1) * 16 + 4 * tp;
+        bf16x8 a0 = tr_pair(Vs + vswz(krow, dcol), Vs + vswz(krow + 8, dcol));
+        bf16x8 a1 = tr_pair(Vs + vswz(krow, 32 + dcol), Vs + vswz(krow + 8, 32 + dcol));
+        O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pb, O0, 0, 0, 0);
+        O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb, O1, 0, 0, 0);
+      }
+    }
+  }
+  const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+  const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+  if (q < N) {
+    bf16* orow = p.o + (long)b * p.sbo + (long)q * p.ldo + h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      bf16x4 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = f2bf(O0[4 * gq + e] * inv); v1[e] = f2bf(O1[4 * gq + e] * inv); }
+      *(bf16x4*)(orow + 8 * gq + 4 * hh) = v0;
+      *(bf16x4*)(orow + 32 + 8 * gq + 4 * hh) = v1;
+    }
+    if (hh == 0 && p.lse) p.lse[((long)(b * p.H + h)) * N + q] = ltot > 0.f ? (mrun + log2f(ltot)) * LN2 : INFINITY;
+  }
+}
+
+// =================================================================================================
+// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+// =================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long total = (long)p.B * p.H * p.N;
+  if (i >= total) return;
+  int qn = (int)(i % p.N);
+  int h = (int)((i / p.N) % p.H);
+  int b = (int)(i / ((long)p.N * p.H));
+  const bf16* o = p.o + (long)b * p.sbo + (long)qn * p.ldo + h * HD;
+  const bf16* d = p.dout + (long)b * p.sbo + (long)qn * p.ldo + h * HD;
+  float s = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    bf16x8 a = *(const bf16x8*)(o + ch * 8), g = *(const bf16x8*)(d + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(g[e]);
+  }
+  const_cast<float*>(p.delta)[i] = s;
+}
+
+// =================================================================================================
+// backward, pass 1: dQ.  Same loop structure as the forward (one block = 128 queries).
+//   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T o drop - delta)
+//   dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+// =================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) bf16 Ks[KT * HD];   // row reads (S^T)
+  __shared__ __attribute__((aligned(16))) bf16 Kt[KT * HD];   // tr reads (K^T operand of dQ^T)
+  __shared__ __attribute__((aligned(16))) bf16 Vs[KT * HD];   // row reads (dP^T)
+  __shared__ __attribute__((aligned(16))) float kbias[KT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk0 = blockIdx.x * QB;
+  const int q = qblk0 + wid * 32 + r32;
+  const int N = p.N;
+  const int qc = min(q, N - 1);
+  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* K = p.k + (long)b * p.sb + h * HD;
+  const bf16* V = p.v + (long)b * p.sb + h * HD;
+  const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
+  const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (q < N) {
+      qf[s] = *(const bf16x8*)(Q + (long)q * p.ld + 16 * s + 8 * hh);
+      dof[s] = *(const bf16x8*)(dO + (long)q * p.ldo + 16 * s + 8 * hh);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qf[s][j] = f2bf(0.f); dof[s][j] = f2bf(0.f); }
+    }
+  }
+  const long sidx = ((long)(b * p.H + h)) * N + qc;
+  const float lse2 = p.lse[sidx] * LOG2E;
+  const float delta = p.delta[sidx];
+  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
+  int mlim, bclo, bchi;
+  tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+  const float c = p.scale * LOG2E;
+  const uint32_t thr = drop_threshold(p.p_drop);
+  const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint64_t drow = ((uint64_t)(b * p.H + h) * N + (uint64_t)qc) * N;
+  f32x16 D0, D1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { D0[i] = 0.f; D1[i] = 0.f; }
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int kt0 = 0; kt0 < N; kt0 += KT) {
+    const bool need = (kt0 < mlim) || (kt0 < bchi && kt0 + KT > bclo);
+    if (!need) continue;
+    __syncthreads();
+    load_tile<false>(Ks, K, p.ld, kt0, N, tid);
+    load_tile<true>(Kt, K, p.ld, kt0, N, tid);
+    load_tile<false>(Vs, V, p.ld, kt0, N, tid);
+    if (tid < KT) {
+      int key = kt0 + tid;
+      kbias[tid] = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 S, dP;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 a = *(const bf16x8*)(Ks + kswz(sub * 32 + r32, 2 * s + hh));
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], S, 0, 0, 0);
+        bf16x8 av = *(const bf16x8*)(Vs + kswz(sub * 32 + r32, 2 * s + hh));
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dof[s], dP, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
+        bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
+        float sv = ok ? S[i] * c + kbias[kl] : -INFINITY;
+        float pe = exp2f(sv - lse2);
+        float dp = dP[i];
+        if (p.p_drop > 0.f) dp *= keep_scale(p.seed, drow + (uint64_t)key, thr, inv_keep);
+        S[i] = pe * (dp - delta) * p.scale;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 db = pack8(S, s2);
+        const int krow = sub * 32 + 16 * s2 + 4 * (g >> 1) + tq;
+        const int dcol = (g & 1) * 16 + 4 * tp;
+        bf16x8 a0 = tr_pair(Kt + vswz(krow, dcol), Kt + vswz(krow + 8, dcol));
+        bf16x8 a1 = tr_pair(Kt + vswz(krow, 32 + dcol), Kt + vswz(krow + 8, 32 + dcol));
+        D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, db, D0, 0, 0, 0);
+        D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, db, D1, 0, 0, 0);
+      }
+    }
+  }
+  if (q < N) {
+    bf16* drow_p = p.dq + (long)b * p.sb + (long)q * p.ld + h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      bf16x4 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = f2bf(D0[4 * gq + e]); v1[e] = f2bf(D1[4 * gq + e]); }
+      *(bf16x4*)(drow_p + 8 * gq + 4 * hh) = v0;
+      *(bf16x4*)(drow_p + 32 + 8 * gq + 4 * hh) = v1;
+    }
+  }
+}
+
+// =================================================================================================
+// backward, pass 2: dK, dV.  One block = 128 keys (4 waves x 32), loops over the query tiles
+// that can see them.  S (not transposed): queries on accumulator rows, keys on lanes.
+//   S = Q K^T ; P = exp(S - lse[q]) ; dP = dO V^T ; dS = P o (dP o drop - delta[q]) * scale
+//   dV^T[d][key] += dO^T[d][q] (P o drop)[q][key]      dK^T[d][key] += Q^T[d][q] dS[q][key]
+// =================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
+  constexpr int QT = 64;  // queries per LDS tile
+  __shared__ __attribute__((aligned(16))) bf16 Qs[QT * HD];   // row reads
+  __shared__ __attribute__((aligned(16))) bf16 Qt[QT * HD];   // tr reads
+  __shared__ __attribute__((aligned(16))) bf16 Ds[QT * HD];   // dO row reads
+  __shared__ __attribute__((aligned(16))) bf16 Dt[QT * HD];   // dO tr reads
+  __shared__ __attribute__((aligned(16))) float lse_s[QT];
+  __shared__ __attribute__((aligned(16))) float del_s[QT];
+  __shared__ int qlim_s[QT], qclo_s[QT], qchi_s[QT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kblk0 = blockIdx.x * QB;
+  const int key = kblk0 + wid * 32 + r32;
+  const int N = p.N;
+  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* K = p.k + (long)b * p.sb + h * HD;
+  const bf16* V = p.v + (long)b * p.sb + h * HD;
+  const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
+  const bool key_ok = key < N && !(p.kpad && p.kpad[(long)b * N + key]);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (key < N) {
+      kf[s] = *(const bf16x8*)(K + (long)key * p.ld + 16 * s + 8 * hh);
+      vf[s] = *(const bf16x8*)(V + (long)key * p.ld + 16 * s + 8 * hh);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kf[s][j] = f2bf(0.f); vf[s][j] = f2bf(0.f); }
+    }
+  }
+  const float c = p.scale * LOG2E;
+  const uint32_t thr = drop_threshold(p.p_drop);
+  const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint64_t dbase = (uint64_t)(b * p.H + h) * N;
+  const int klo = kblk0, khi = min(kblk0 + QB, N);  // this block's keys [klo, khi)
+  f32x16 dV0, dV1, dK0, dK1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  for (int q0 = 0; q0 < N; q0 += QT) {
+    // does any query of [q0, q0+QT) see any key of [klo, khi)?  (block-uniform)
+    int mlim, bclo, bchi;
+    tile_ranges(q0, min(q0 + QT, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+    const bool need = (klo < mlim) || (klo < bchi && khi > bclo);
+    if (!need) continue;
+    __syncthreads();
+    load_tile<false>(Qs, Q, p.ld, q0, N, tid);
+    load_tile<true>(Qt, Q, p.ld, q0, N, tid);
+    load_tile<false>(Ds, dO, p.ldo, q0, N, tid);
+    load_tile<true>(Dt, dO, p.ldo, q0, N, tid);
+    if (tid < QT) {
+      int qq = q0 + tid;
+      int qcl = min(qq, N - 1);
+      lse_s[tid] = (qq < N) ? p.lse[(long)(b * p.H + h) * N + qq] * LOG2E : INFINITY;  // +inf -> P = 0
+      del_s[tid] = (qq < N) ? p.delta[(long)(b * p.H + h) * N + qq] : 0.f;
+      QLimits L = q_limits(qcl, p.Tp, p.m, p.r, N);
+      qlim_s[tid] = L.lim; qclo_s[tid] = L.clo; qchi_s[tid] = L.chi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 S, dP;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 a = *(const bf16x8*)(Qs + kswz(sub * 32 + r32, 2 * s + hh));
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], S, 0, 0, 0);
+        bf16x8 ad = *(const bf16x8*)(Ds + kswz(sub * 32 + r32, 2 * s + hh));
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[s], dP, 0, 0, 0);
+      }
+      f32x16 Pd;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int ql = sub * 32 + acc_row(i, hh), qq = q0 + ql;
+        bool ok = key_ok && ((key < qlim_s[ql]) || (key >= qclo_s[ql] && key < qchi_s[ql]));
+        float sv = ok ? S[i] * c : -INFINITY;
+        float pe = exp2f(sv - lse_s[ql]);
+        float ks = 1.f;
+        if (p.p_drop > 0.f) ks = keep_scale(p.seed, (dbase + (uint64_t)min(qq, N - 1)) * N + (uint64_t)min(key, N - 1), thr, inv_keep);
+        Pd[i] = pe * ks;
+        S[i] = pe * (dP[i] * ks - del_s[ql]) * p.scale;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pb = pack8(Pd, s2), sb = pack8(S, s2);
+        const int qrow = sub * 32 + 16 * s2 + 4 * (g >> 1) + tq;
+        const int dcol = (g & 1) * 16 + 4 * tp;
+        bf16x8 d0 = tr_pair(Dt + vswz(qrow, dcol), Dt + vswz(qrow + 8, dcol));
+        bf16x8 d1 = tr_pair(Dt + vswz(qrow, 32 + dcol), Dt + vswz(qrow + 8, 32 + dcol));
+        dV0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, pb, dV0, 0, 0, 0);
+        dV1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, pb, dV1, 0, 0, 0);
+        bf16x8 q0f = tr_pair(Qt + vswz(qrow, dcol), Qt + vswz(qrow + 8, dcol));
+        bf16x8 q1f = tr_pair(Qt + vswz(qrow, 32 + dcol), Qt + vswz(qrow + 8, 32 + dcol));
+        dK0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0f, sb, dK0, 0, 0, 0);
+        dK1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1f, sb, dK1, 0, 0, 0);
+      }
+    }
+  }
+  if (key < N) {
+    bf16* dkr = p.dk + (long)b * p.sb + (long)key * p.ld + h * HD;
+    bf16* dvr = p.dv + (long)b * p.sb + (long)key * p.ld + h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      bf16x4 a0, a1, b0, b1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] = f2bf(dK0[4 * gq + e]); a1[e] = f2bf(dK1[4 * gq + e]);
+        b0[e] = f2bf(dV0[4 * gq + e]); b1[e] = f2bf(dV1[4 * gq + e]);
+      }
+      *(bf16x4*)(dkr + 8 * gq + 4 * hh) = a0;
+      *(bf16x4*)(dkr + 32 + 8 * gq + 4 * hh) = a1;
+      *(bf16x4*)(dvr + 8 * gq + 4 * hh) = b0;
+      *(bf16x4*)(dvr + 32 + 8 * gq + 4 * hh) = b1;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+static int attn_fill(const AttnDesc& d, AttnP& p) {
+  p.q = (const bf16*)d.q; p.k = (const bf16*)d.k; p.v = (const bf16*)d.v; p.o = (bf16*)d.o; p.lse = d.lse; p.kpad = d.kpad;
+  p.dout = (const bf16*)d.dout; p.delta = d.delta; p.dq = (bf16*)d.dq; p.dk = (bf16*)d.dk; p.dv = (bf16*)d.dv;
+  p.ld = d.ld; p.ldo = d.ldo; p.sb = d.sb; p.sbo = d.sbo; p.B = d.B; p.H = d.H; p.N = d.N; p.Tp = d.Tp; p.m = d.m; p.r = d.r;
+  p.scale = d.scale; p.p_drop = d.p_drop; p.seed = d.seed;
+  if (!p.q || !p.k || !p.v || !p.o || !p.lse) return set_error("attention: null pointer");
+  if (d.head_dim != HD) return set_error("attention: only head_dim 64 is built");
+  if (p.B <= 0 || p.H <= 0 || p.N <= 0) return set_error("attention: bad B/H/N");
+  if (p.m <= 0 || p.r < 0 || p.Tp <= 0 || p.Tp > p.N) return set_error("attention: bad block structure (m>0, r>=0, 0<Tp<=N)");
+  if (p.N != p.Tp + (p.Tp / p.m) * p.r) return set_error("attention: N must equal Tp + (Tp/m)*r");
+  if ((p.ld % 8) || (p.ldo % 8) || (p.sb % 8) || (p.sbo % 8)) return set_error("attention: strides must be multiples of 8 elements");
+  if (p.p_drop < 0.f || p.p_drop >= 1.f) return set_error("attention: dropout must be in [0,1)");
+  if ((long)p.B * p.H * p.N * (long)p.N >= (1L << 62)) return set_error("attention: too large");
+  return 0;
+}
+
+int attn_fwd(const AttnDesc& d, hipStream_t st) {
+  AttnP p{};
+  if (int e = attn_fill(d, p)) return e;
+  dim3 grid((p.N + QB - 1) / QB, p.H, p.B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "attn_fwd");
+}
+
+int attn_bwd(const AttnDesc& d, hipStream_t st) {
+  AttnP p{};
+  if (int e = attn_fill(d, p)) return e;
+  if (!p.dout || !p.delta || !p.dq || !p.dk || !p.dv) return set_error("attn_bwd: null pointer");
+  long total = (long)p.B * p.H * p.N;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+  dim3 grid((p.N + QB - 1) / QB, p.H, p.B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "attn_bwd");
+}
+
+}  // namespace w2vs

@@ -1,0 +1,77 @@
+// Device-side helpers shared by every kernel of libw2vs (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace w2vs {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32, RNE, NaN-safe
+
+// ---- buffer resources: hardware bounds checking gives zero-fill loads and dropped stores ----
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+
+// ---- wave / block reductions -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based RNG for dropout / gumbel noise ----------------------------------------
+// One 32-bit hash per (seed, element index).  The same (seed, index) is re-evaluated in
+// the backward kernels, so no mask is ever stored.
+__device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t idx) {
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x85EBCA77u;
+  x ^= (uint32_t)seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  x += (uint32_t)(seed >> 32);
+  x ^= x >> 15; x *= 0x2C1B3C6Du;
+  x ^= x >> 12; x *= 0x297A2D39u;
+  x ^= x >> 15;
+  return x;
+}
+// keep-mask threshold for drop probability p: keep iff hash >= thr
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+__device__ __forceinline__ float u01(uint32_t h) {  // (0,1]
+  return ((float)(h >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float gelu_exact(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float c = 0.3989422804014327f;  // 1/sqrt(2*pi)
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * c * __expf(-0.5f * x * x);
+}
+
+}  // namespace w2vs

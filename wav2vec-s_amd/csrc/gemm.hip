@@ -1,0 +1,376 @@
+// bf16 MFMA GEMMs for the wav2vec-S hot path (gfx950).
+//
+//   NT:  C[M,N] = epi( A[M,K] . B[N,K]^T )        linear fwd, dgrad (with pre-transposed W),
+//                                                  conv1-6 fwd/dgrad as strided-A GEMM
+//   TN:  C[M,N] (+)= A[K,M]^T . B[K,N]            weight gradients (contraction over tokens)
+//
+// Layout notes
+//  * A rows may OVERLAP: row m starts at element (a_off + m*lda).  With channel-last
+//    activations [L, C] a 1-D conv (kernel k, stride s, no padding) is exactly the NT
+//    GEMM with lda = s*C and K = k*C - no im2col buffer exists anywhere.
+//  * All global reads go through buffer descriptors sized to the valid extent, so tile
+//    overhang (row >= M, k >= K, and the "row -1" of the k3/s2 dgrad form) reads zeros
+//    in hardware instead of branching.
+//  * 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
+//    LDS rows are 128 B; 16-B chunk c of row r lives at chunk (c ^ ((r>>1)&7)) which makes
+//    the ds_read_b128 fragment reads and the ds_write_b128 staging writes conflict free.
+#include "common.h"
+#include "w2vs_internal.h"
+
+namespace w2vs {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_ELEMS = BM * BK;  // == BN*BK
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+struct GemmP {
+  const bf16* A; const bf16* B; bf16* C; bf16* C2; float* Cf;
+  const bf16* bias; const bf16* aux;
+  int M, N, K;
+  long lda, ldb, ldc;
+  long a_off;                 // element offset of row 0 (may be negative)
+  long sA, sB, sC;            // batch strides (elements), blockIdx.z
+  uint32_t a_bytes, b_bytes;  // valid bytes per batch for the A / B descriptors
+  long c_elems;               // valid output elements per batch
+  int k_split, n_split;       // TN only: K range per split, splits per batch
+  float alpha;
+};
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5 };
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+  // A0 A1 B0 B1 during the K loop (64 KiB); two padded [128][136] output tiles in the epilogue
+  __shared__ __attribute__((aligned(16))) bf16 lds[2 * 128 * 136];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bz = blockIdx.z;
+
+  const bf16* Ab = p.A + (long)bz * p.sA;
+  const bf16* Bb = p.B + (long)bz * p.sB;
+  __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, p.a_bytes);
+  __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, p.b_bytes);
+
+  // staging assignment: thread t owns chunks t + 256*j (row = c>>3, kc = c&7), j = 0..3
+  // Byte offsets are kept modulo 2^32: a row that starts before the buffer (the "row -1" of
+  // the k3/s2 dgrad form) wraps to a huge offset = out of range = zeros, and walks back
+  // into range exactly where its window re-enters the buffer.
+  uint32_t a_goff[4], b_goff[4];
+  int l_off[4];
+  bool a_ok[4], b_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int c = tid + 256 * j, row = c >> 3, kc = c & 7;
+    long ae = p.a_off + (long)(m0 + row) * p.lda + kc * 8;
+    a_ok[j] = (m0 + row < p.M);  // rows >= M must read zero even if still inside the descriptor
+    a_goff[j] = (uint32_t)(ae * 2);
+    long be = (long)(n0 + row) * p.ldb + kc * 8;
+    b_ok[j] = (n0 + row < p.N);
+    b_goff[j] = (uint32_t)(be * 2);
+    l_off[j] = swz(row, kc);
+  }
+  const int nk = (p.K + BK - 1) / BK;
+  // the k tail (K % 64 != 0) is handled by clamping per-chunk: chunk kc of tile kt is valid iff kt*64+kc*8 < K
+  u32x4 ra_reg[4], rb_reg[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int kc = (tid + 256 * j) & 7;
+      bool kok = (kt * BK + kc * 8) < p.K;
+      uint32_t ao = (kok && a_ok[j]) ? a_goff[j] + (uint32_t)(kt * BK * 2) : 0xFFFFFFF0u;
+      uint32_t bo = (kok && b_ok[j]) ? b_goff[j] + (uint32_t)(kt * BK * 2) : 0xFFFFFFF0u;
+      ra_reg[j] = buf_load16(ra, ao);
+      rb_reg[j] = buf_load16(rb, bo);
+    }
+  };
+  auto lstore = [&](int buf) {
+    bf16* sa = lds + buf * TILE_ELEMS;
+    bf16* sb = lds + (2 + buf) * TILE_ELEMS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(u32x4*)(sa + l_off[j]) = ra_reg[j];
+      *(u32x4*)(sb + l_off[j]) = rb_reg[j];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const bf16* sa = lds + buf * TILE_ELEMS;
+    const bf16* sb = lds + (2 + buf) * TILE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + swz(wm * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + swz(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: registers -> (fp32 math) -> LDS bf16 tile -> 16-B row-contiguous stores ----
+  bf16* Cb = p.C + (long)bz * p.sC;
+  if (EPI == EPI_F32) {
+    float* Cf = p.Cf + (long)bz * p.sC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
+          if (row < p.M && col < p.N) Cf[(long)row * p.ldc + col] = acc[i][j][r] * p.alpha;
+        }
+    return;
+  }
+  // staging tile [128][128] bf16 with a 16-B pad per row (row pitch 272 B) to spread banks
+  constexpr int CP = 136;
+  bf16* st = lds;            // 128*136*2 = 34816 B
+  bf16* st2 = lds + 128 * CP;  // second output (pre-activation) when saving both
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int col = n0 + wn * 64 + j * 16 + fr;
+    float bv = 0.f;
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE)
+      if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int lr = wm * 64 + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
+        float v = acc[i][j][r] + bv;
+        if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+          if (EPI == EPI_BIAS_GELU_SAVE) {
+            bf16 pre = f2bf(v);
+            st2[lr * CP + lc] = pre;
+            v = bf2f(pre);  // the activation is taken of the value that is actually saved
+          }
+          v = gelu_exact(v);
+        }
+        st[lr * CP + lc] = f2bf(v);
+      }
+  }
+  __syncthreads();
+  // 128 rows x 16 chunks of 16 B; thread t handles chunks t + 256*j, j=0..7
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int c = tid + 256 * j, lr = c >> 4, cc = c & 15;
+    int row = m0 + lr, col = n0 + cc * 8;
+    long o = (long)row * p.ldc + col;
+    if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
+      if (EPI == EPI_DGELU) {
+        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+        bf16x8 outv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * gelu_grad(bf2f(a[e])));
+        *(bf16x8*)(Cb + o) = outv;
+      } else {
+        *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
+        if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: C[M,N] += alpha * sum_k A[k,M] * B[k,N];  A,B row-major with the contraction index as the
+// ROW index (tokens).  grid.z splits K; partial sums are combined with fp32 atomics into Cf
+// (which the caller zeroes), so a step's dW for every layer lands in one fp32 gradient arena.
+// LDS tiles keep the global [k][m] orientation; MFMA fragments come out of LDS through
+// ds_read_b64_tr_b16 (hardware transpose), two reads per 8-deep k group.
+// ---------------------------------------------------------------------------------------------
+constexpr int TK = 64;  // k rows per tile
+// tile [64 k][128 m] bf16: row pitch 256 B + 16 B pad -> 272 B (136 elems) keeps tr reads spread
+constexpr int TP = 136;
+
+__device__ __forceinline__ s16x4 ds_tr(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) bf16 lds[4 * TK * TP];  // A0 A1 B0 B1 : 4*64*136*2 = 69632 B
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bz = blockIdx.z / p.n_split, sp = blockIdx.z % p.n_split;
+  const int k_begin = sp * p.k_split;
+  const int k_end = min(p.K, k_begin + p.k_split);
+  if (k_begin >= k_end) return;
+  __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long)bz * p.sA, p.a_bytes);
+  __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
+  // staging: tile = 64 rows x 16 chunks (16 B); thread t owns chunks t + 256*j, j = 0..3
+  int l_off[4];
+  uint32_t a_col[4], b_col[4];
+  int krow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int c = tid + 256 * j, row = c >> 4, cc = c & 15;
+    krow[j] = row;
+    l_off[j] = row * TP + cc * 8;
+    a_col[j] = (m0 + cc * 8 < p.M) ? (uint32_t)((m0 + cc * 8) * 2) : 0xFFFFFFF0u;
+    b_col[j] = (n0 + cc * 8 < p.N) ? (uint32_t)((n0 + cc * 8) * 2) : 0xFFFFFFF0u;
+  }
+  u32x4 ra_reg[4], rb_reg[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int k = k0 + krow[j];
+      bool ok = k < k_end;
+      uint32_t ao = (ok && a_col[j] != 0xFFFFFFF0u) ? (uint32_t)(((long)p.a_off + (long)k * p.lda) * 2) + a_col[j] : 0xFFFFFFF0u;
+      uint32_t bo = (ok && b_col[j] != 0xFFFFFFF0u) ? (uint32_t)((long)k * p.ldb * 2) + b_col[j] : 0xFFFFFFF0u;
+      ra_reg[j] = buf_load16(ra, ao);
+      rb_reg[j] = buf_load16(rb, bo);
+    }
+  };
+  auto lstore = [&](int buf) {
+    bf16* sa = lds + buf * TK * TP;
+    bf16* sb = lds + (2 + buf) * TK * TP;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(u32x4*)(sa + l_off[j]) = ra_reg[j];
+      *(u32x4*)(sb + l_off[j]) = rb_reg[j];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (k_end - k_begin + TK - 1) / TK;
+  gload(k_begin);
+  lstore(0);
+  __syncthreads();
+  // tr-read addressing: 16-lane group g = lane>>4 owns k rows 8g..8g+7 of a 32-deep k step;
+  // inside the group lane i = 4q+pp supplies row q, columns 4pp..4pp+3 and receives column i.
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(k_begin + (kt + 1) * TK);
+    const bf16* sa = lds + buf * TK * TP;
+    const bf16* sb = lds + (2 + buf) * TK * TP;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+      const int kr = ks * 32 + g * 8 + q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16* base = sa + kr * TP + wm * 64 + i * 16 + pp * 4;
+        s16x4 lo = ds_tr(base), hi = ds_tr(base + 4 * TP);
+        union { bf16x8 v; s16x4 h[2]; } u; u.h[0] = lo; u.h[1] = hi; af[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16* base = sb + kr * TP + wn * 64 + j * 16 + pp * 4;
+        s16x4 lo = ds_tr(base), hi = ds_tr(base + 4 * TP);
+        union { bf16x8 v; s16x4 h[2]; } u; u.h[0] = lo; u.h[1] = hi; bfr[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
+        if (row < p.M && col < p.N) atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
+      }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_common(const GemmDesc& d) {
+  if (!d.A || !d.B) return set_error("gemm: null operand");
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0) return set_error("gemm: non-positive dimension");
+  if ((d.lda % 8) || (d.ldb % 8) || (d.a_off % 8)) return set_error("gemm: lda/ldb/a_off must be multiples of 8 elements (16-B loads)");
+  if (((uintptr_t)d.A % 16) || ((uintptr_t)d.B % 16)) return set_error("gemm: operands must be 16-B aligned");
+  return 0;
+}
+
+int gemm_nt(const GemmDesc& d, hipStream_t s) {
+  if (int e = check_common(d)) return e;
+  if (d.epi == EPI_F32 ? !d.Cf : !d.C) return set_error("gemm_nt: null output");
+  if ((d.ldc % 8) || (d.N % 8)) return set_error("gemm_nt: N and ldc must be multiples of 8");
+  if (d.K % 8) return set_error("gemm_nt: K must be a multiple of 8");
+  if (d.epi == EPI_DGELU && !d.aux) return set_error("gemm_nt: DGELU needs aux");
+  if (d.epi == EPI_BIAS_GELU_SAVE && !d.C2) return set_error("gemm_nt: GELU_SAVE needs C2");
+  GemmP p{};
+  p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.C = (bf16*)d.C; p.C2 = (bf16*)d.C2; p.Cf = d.Cf;
+  p.bias = (const bf16*)d.bias; p.aux = (const bf16*)d.aux;
+  p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.a_off = d.a_off;
+  p.sA = d.sA; p.sB = d.sB; p.sC = d.sC; p.alpha = d.alpha;
+  p.c_elems = d.c_elems ? d.c_elems : (long)(d.M - 1) * d.ldc + d.N;
+  long a_ext = d.a_bytes ? d.a_bytes : ((long)d.a_off + (long)(d.M - 1) * d.lda + d.K) * 2;
+  long b_ext = d.b_bytes ? d.b_bytes : ((long)(d.N - 1) * d.ldb + d.K) * 2;
+  if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_nt: operand extent must be < 2 GiB per batch");
+  p.a_bytes = (uint32_t)a_ext; p.b_bytes = (uint32_t)b_ext;
+  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch > 0 ? d.batch : 1), block(256);
+  switch (d.epi) {
+    case EPI_NONE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_NONE>, grid, block, 0, s, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS>, grid, block, 0, s, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS_GELU>, grid, block, 0, s, p); break;
+    case EPI_BIAS_GELU_SAVE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS_GELU_SAVE>, grid, block, 0, s, p); break;
+    case EPI_DGELU: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DGELU>, grid, block, 0, s, p); break;
+    case EPI_F32: hipLaunchKernelGGL(gemm_nt_kernel<EPI_F32>, grid, block, 0, s, p); break;
+    default: return set_error("gemm_nt: unknown epilogue");
+  }
+  return hip_check(hipGetLastError(), "gemm_nt launch");
+}
+
+int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
+  if (int e = check_common(d)) return e;
+  if (!d.Cf) return set_error("gemm_tn: needs an fp32 accumulation target");
+  if ((d.M % 8) || (d.N % 8)) return set_error("gemm_tn: M and N must be multiples of 8");
+  GemmP p{};
+  p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.Cf = d.Cf;
+  p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.a_off = d.a_off; p.alpha = d.alpha;
+  long a_ext = d.a_bytes ? d.a_bytes : ((long)d.a_off + (long)(d.K - 1) * d.lda + d.M) * 2;
+  long b_ext = d.b_bytes ? d.b_bytes : ((long)(d.K - 1) * d.ldb + d.N) * 2;
+  if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_tn: operand extent must be < 2 GiB per batch");
+  p.a_bytes = (uint32_t)a_ext; p.b_bytes = (uint32_t)b_ext;
+  const int nb = d.batch > 0 ? d.batch : 1;
+  p.sA = d.sA; p.sB = d.sB;
+  int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * nb;
+  int target = (num_cu_hint > 0 ? num_cu_hint : 256) * 2;
+  int splits = (target + tiles - 1) / tiles;
+  int max_splits = (d.K + TK - 1) / TK;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int ks = (d.K + splits - 1) / splits;
+  ks = ((ks + TK - 1) / TK) * TK;
+  splits = (d.K + ks - 1) / ks;
+  p.k_split = ks; p.n_split = splits;
+  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, splits * nb), block(256);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, s, p);
+  return hip_check(hipGetLastError(), "gemm_tn launch");
+}
+
+}  // namespace w2vs

@@ -1,0 +1,503 @@
+// Loss-head kernels: Gumbel vector quantizer, InfoNCE logits, cross-entropy, row gathers.
+// All HBM / latency bound, one wave per row, fp32 math, wavefront-shuffle reductions.
+//
+//   gumbel_quantize   a14  fs/modules/gumbel_vector_quantizer.py:141-202
+//   infonce_logits    a16 gather + a17 compute_preds   fs/models/wav2vec/wav2vec2.py:521-542
+//   ce_rows           a19  fs/criterions/wav2vec_criterion.py:64-68, 133-155
+#include "common.h"
+#include "w2vs_internal.h"
+
+namespace w2vs {
+
+// ------------------------------------------------------------------------------------------------
+// argmax with torch's tie rule (first index wins)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+struct QuantP {
+  const bf16* logits;   // [R, G*V]
+  const float* noise;   // [R*G, V] gumbel samples or null (then seed is used when training)
+  const bf16* vars;     // [G*V, D]
+  bf16* q;              // [R, G*D]
+  int* idx;             // [R, G] chosen code
+  float* hard_cnt;      // [G*V] histogram of argmax(logits)
+  float* prob_sum;      // [G*V] sum over rows of softmax(logits)
+  // backward
+  const bf16* dq;       // [R, G*D]
+  const bf16* dsoft;    // [R, G*V]  dq . vars^T  (from the GEMM)
+  const float* cvec;    // [G*V] d(prob_ppl)/d(avg_prob)
+  bf16* dlogits;        // [R, G*V]
+  float* dvars;         // [G*V, D] fp32 accumulators
+  float ppl_grad;       // dLoss/d(prob_ppl)
+  int R, G, V, D;
+  float tau; int training; uint64_t seed;
+};
+
+constexpr int QV_MAX = 5;  // V <= 320 : up to 5 codes per lane
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void quant_kernel(QuantP p) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const int V = p.V, G = p.G, D = p.D;
+  const long rows = (long)p.R * G;
+  for (long rg = wave_id; rg < rows; rg += nwaves) {
+    const long row = rg / G;
+    const int g = (int)(rg % G);
+    const bf16* lp = p.logits + row * (long)(G * V) + (long)g * V;
+    float x[QV_MAX], y[QV_MAX];
+    float xmax = -INFINITY;
+    int xarg = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < QV_MAX; ++j) {
+      int v = lane + 64 * j;
+      x[j] = (v < V) ? bf2f(lp[v]) : -INFINITY;
+      if (x[j] > xmax) { xmax = x[j]; xarg = v; }
+    }
+    wave_argmax(xmax, xarg);
+    // softmax(logits) for the average-probability perplexity
+    float ps[QV_MAX], se = 0.f;
+#pragma unroll
+    for (int j = 0; j < QV_MAX; ++j) { ps[j] = __expf(x[j] - xmax); se += ps[j]; }
+    se = wave_sum(se);
+    const float inv_se = 1.f / se;
+    int sel = xarg;
+    float ys[QV_MAX], yinv = 0.f;
+    if (p.training) {
+      float ymax = -INFINITY;
+      int yarg = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < QV_MAX; ++j) {
+        int v = lane + 64 * j;
+        float gn = 0.f;
+        if (v < V) {
+          if (p.noise) gn = p.noise[rg * V + v];
+          else {
+            float e = -__logf(u01(hash32(p.seed, (uint64_t)rg * V + v)));  // Exp(1)
+            gn = -__logf(fmaxf(e, 1e-20f));
+          }
+        }
+        y[j] = (v < V) ? (x[j] + gn) / p.tau : -INFINITY;
+        if (y[j] > ymax) { ymax = y[j]; yarg = v; }
+      }
+      wave_argmax(ymax, yarg);
+      sel = yarg;
+      float sy = 0.f;
+#pragma unroll
+      for (int j = 0; j < QV_MAX; ++j) { ys[j] = __expf(y[j] - ymax); sy += ys[j]; }
+      yinv = 1.f / wave_sum(sy);
+    }
+    if (!BWD) {
+#pragma unroll
+      for (int j = 0; j < QV_MAX; ++j) {
+        int v = lane + 64 * j;
+        if (v < V) atomicAdd(&p.prob_sum[g * V + v], ps[j] * inv_se);
+      }
+      if (lane == 0) {
+        atomicAdd(&p.hard_cnt[g * V + xarg], 1.0f);
+        p.idx[rg] = sel;
+      }
+      // codebook row copy: D bf16 = D/8 chunks of 16 B
+      const bf16* src = p.vars + ((long)g * V + sel) * D;
+      bf16* dst = p.q + row * (long)(G * D) + (long)g * D;
+      for (int ch = lane; ch < D / 8; ch += 64) *(u32x4*)(dst + ch * 8) = *(const u32x4*)(src + ch * 8);
+    } else {
+      // d logits = [softmax-bwd of the straight-through gumbel path] / tau
+      //          + ppl_grad/R * p o (c - <p, c>)          (diversity term through avg_probs)
+      const bf16* dsp = p.dsoft + row * (long)(G * V) + (long)g * V;
+      float ds[QV_MAX], dot1 = 0.f, dot2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < QV_MAX; ++j) {
+        int v = lane + 64 * j;
+        float soft = p.training ? ys[j] * yinv : 0.f;
+        ds[j] = (v < V && p.training) ? bf2f(dsp[v]) : 0.f;
+        dot1 += soft * ds[j];
+        float pj = ps[j] * inv_se;
+        dot2 += (v < V) ? pj * p.cvec[g * V + v] : 0.f;
+      }
+      dot1 = wave_sum(dot1);
+      dot2 = wave_sum(dot2);
+      bf16* dl = p.dlogits + row * (long)(G * V) + (long)g * V;
+      const float sc = p.ppl_grad / (float)p.R;
+#pragma unroll
+      for (int j = 0; j < QV_MAX; ++j) {
+        int v = lane + 64 * j;
+        if (v < V) {
+          float soft = p.training ? ys[j] * yinv : 0.f;
+          float pj = ps[j] * inv_se;
+          float gr = soft * (ds[j] - dot1) / p.tau + sc * pj * (p.cvec[g * V + v] - dot2);
+          dl[v] = f2bf(gr);
+        }
+      }
+      // d vars[g*V + sel] += dq[row, g]
+      const bf16* dqp = p.dq + row * (long)(G * D) + (long)g * D;
+      float* dv = p.dvars + ((long)g * V + sel) * D;
+      for (int e = lane; e < D; e += 64) atomicAdd(&dv[e], bf2f(dqp[e]));
+    }
+  }
+}
+
+// perplexities from the two histograms; also the vector c = d(prob_ppl)/d(avg_prob)
+__global__ void quant_finalize_kernel(const float* hard_cnt, const float* prob_sum, int R, int G, int V, float* out2,
+                                      float* cvec) {
+  __shared__ float red[2][64];
+  const int tid = threadIdx.x;  // 256 threads, one block
+  float code_ppl = 0.f, prob_ppl = 0.f;
+  for (int g = 0; g < G; ++g) {
+    float hc = 0.f, hp = 0.f;
+    for (int v = tid; v < V; v += 256) {
+      float a = hard_cnt[g * V + v] / (float)R;
+      float b = prob_sum[g * V + v] / (float)R;
+      hc += a * logf(a + 1e-7f);
+      hp += b * logf(b + 1e-7f);
+    }
+    hc = wave_sum(hc); hp = wave_sum(hp);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = hc; red[1][tid >> 6] = hp; }
+    __syncthreads();
+    float tc = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    float tp = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    __syncthreads();
+    const float eg = expf(-tp);
+    code_ppl += expf(-tc);
+    prob_ppl += eg;
+    if (cvec)
+      for (int v = tid; v < V; v += 256) {
+        float b = prob_sum[g * V + v] / (float)R;
+        cvec[g * V + v] = -eg * (logf(b + 1e-7f) + b / (b + 1e-7f));
+      }
+  }
+  if (tid == 0) { out2[0] = prob_ppl; out2[1] = code_ppl; }
+}
+
+static int quant_fill(const QuantDesc& d, QuantP& p) {
+  p.logits = (const bf16*)d.logits; p.noise = d.noise; p.vars = (const bf16*)d.vars; p.q = (bf16*)d.q; p.idx = d.idx;
+  p.hard_cnt = d.hard_cnt; p.prob_sum = d.prob_sum; p.dq = (const bf16*)d.dq; p.dsoft = (const bf16*)d.dsoft; p.cvec = d.cvec;
+  p.dlogits = (bf16*)d.dlogits; p.dvars = d.dvars; p.ppl_grad = d.ppl_grad; p.R = d.R; p.G = d.G; p.V = d.V; p.D = d.D;
+  p.tau = d.tau; p.training = d.training; p.seed = d.seed;
+  if (!p.logits || !p.vars) return set_error("quantizer: null pointer");
+  if (p.V > 64 * QV_MAX || p.V < 1) return set_error("quantizer: num_vars per group must be in [1, 320]");
+  if (p.D % 8) return set_error("quantizer: var_dim must be a multiple of 8");
+  if (p.R <= 0 || p.G <= 0) return set_error("quantizer: bad R/G");
+  if (p.training && !(p.tau > 0.f)) return set_error("quantizer: tau must be positive");
+  return 0;
+}
+
+int quant_fwd(const QuantDesc& d, hipStream_t st) {
+  QuantP p{};
+  if (int e = quant_fill(d, p)) return e;
+  if (!p.q || !p.idx || !p.hard_cnt || !p.prob_sum || !d.ppl_out) return set_error("quant_fwd: null pointer");
+  if (int e = hip_check(hipMemsetAsync(p.hard_cnt, 0, sizeof(float) * p.G * p.V, st), "memset")) return e;
+  if (int e = hip_check(hipMemsetAsync(p.prob_sum, 0, sizeof(float) * p.G * p.V, st), "memset")) return e;
+  long rows = (long)p.R * p.G;
+  int grid = (int)std::min<long>((rows + 3) / 4, 2048);
+  hipLaunchKernelGGL(quant_kernel<false>, dim3(grid), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(quant_finalize_kernel, dim3(1), dim3(256), 0, st, p.hard_cnt, p.prob_sum, p.R, p.G, p.V, d.ppl_out,
+                     d.cvec_out);
+  return hip_check(hipGetLastError(), "quant_fwd");
+}
+
+int quant_bwd(const QuantDesc& d, hipStream_t st) {
+  QuantP p{};
+  if (int e = quant_fill(d, p)) return e;
+  if (!p.dq || !p.cvec || !p.dlogits || !p.dvars || !p.prob_sum) return set_error("quant_bwd: null pointer");
+  if (p.training && !p.dsoft) return set_error("quant_bwd: dsoft required in training mode");
+  long rows = (long)p.R * p.G;
+  int grid = (int)std::min<long>((rows + 3) / 4, 2048);
+  hipLaunchKernelGGL(quant_kernel<true>, dim3(grid), dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "quant_bwd");
+}
+
+// ================================================================================================
+// InfoNCE logits.  Row i = (b, j): targets t_0 = y[i], t_k = y[neg_idx[b, j*K + k-1]].
+// 16 lanes per target (4 targets in flight per wave), C <= 1024.
+// ================================================================================================
+struct NceP {
+  const bf16* x; const bf16* y; const long long* neg;  // neg: [B, K*M] int64 (the reference's tensor)
+  float* logits;                                       // [R, K+1]
+  const float* dlogits; float* dx; float* dy;          // bwd: fp32 accumulators [R, C]
+  int B, M, K, C; float inv_temp;
+};
+
+__device__ __forceinline__ float sum16(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <bool BWD, int PER>
+__global__ __launch_bounds__(256) void nce_kernel(NceP p) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const int C = p.C, K = p.K, M = p.M;
+  const long R = (long)p.B * M;
+  constexpr float EPS = 1e-8f;
+  constexpr int per = PER;  // elements per lane within a 16-lane group (C = 16*PER, PER % 8 == 0)
+  for (long row = wave_id; row < R; row += nwaves) {
+    const int b = (int)(row / M), j = (int)(row % M);
+    // each 16-lane group holds the full x row and the positive y row
+    float xs[PER], ys[PER];
+    float xx = 0.f;
+#pragma unroll
+    for (int e8 = 0; e8 < per / 8; ++e8) {
+      bf16x8 t = *(const bf16x8*)(p.x + row * C + gl * per + e8 * 8);
+      bf16x8 u = *(const bf16x8*)(p.y + row * C + gl * per + e8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xs[e8 * 8 + e] = bf2f(t[e]); ys[e8 * 8 + e] = bf2f(u[e]); xx += xs[e8 * 8 + e] * xs[e8 * 8 + e]; }
+    }
+    xx = sum16(xx);
+    const float xn = fmaxf(sqrtf(xx), EPS);
+    float gx[PER];
+    if (BWD) {
+#pragma unroll
+      for (int e = 0; e < per; ++e) gx[e] = 0.f;
+    }
+    for (int k0 = 0; k0 <= K; k0 += 4) {
+      const int k = k0 + grp;
+      const bool valid = k <= K;
+      long trow = row;
+      if (valid && k > 0) trow = (long)p.neg[(long)b * K * M + (long)j * K + (k - 1)];
+      float dot = 0.f, tt = 0.f;
+      bool same = true;
+      float ts[PER];
+#pragma unroll
+      for (int e8 = 0; e8 < per / 8; ++e8) {
+        bf16x8 t = *(const bf16x8*)(p.y + trow * C + gl * per + e8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float tv = bf2f(t[e]);
+          ts[e8 * 8 + e] = tv;
+          dot += xs[e8 * 8 + e] * tv;
+          tt += tv * tv;
+          same = same && (tv == ys[e8 * 8 + e]);
+        }
+      }
+      dot = sum16(dot);
+      tt = sum16(tt);
+      // all-lanes-equal within the 16-lane group
+      unsigned long long bal = __ballot(same);
+      const bool all_same = ((bal >> (grp * 16)) & 0xFFFFull) == 0xFFFFull;
+      const float tn = fmaxf(sqrtf(tt), EPS);
+      const float cosv = dot / (xn * tn);
+      const bool neg_is_pos = (k > 0) && all_same;
+      if (!BWD) {
+        if (valid && gl == 0) p.logits[row * (K + 1) + k] = neg_is_pos ? -INFINITY : cosv * p.inv_temp;
+      } else if (valid && !neg_is_pos) {
+        const float gl_ = p.dlogits[row * (K + 1) + k] * p.inv_temp;  // d/dcos
+        if (gl_ != 0.f) {
+          // d cos/dx = t/(|x||t|) - cos * x/|x|^2 ; d cos/dt = x/(|x||t|) - cos * t/|t|^2
+          const float a = gl_ / (xn * tn), bx = gl_ * cosv / (xn * xn), bt = gl_ * cosv / (tn * tn);
+          float* dyr = p.dy + trow * C + gl * per;
+#pragma unroll
+          for (int e = 0; e < per; ++e) {
+            gx[e] += a * ts[e] - bx * xs[e];
+            atomicAdd(&dyr[e], a * xs[e] - bt * ts[e]);
+          }
+        }
+      }
+    }
+    if (BWD) {
+      // combine the four groups' partial dx and store (row is owned by this wave: plain store)
+#pragma unroll
+      for (int e = 0; e < per; ++e) {
+        float v = gx[e];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (grp == 0) p.dx[row * C + gl * per + e] = v;
+      }
+    }
+  }
+}
+
+static int nce_fill(const NceDesc& d, NceP& p) {
+  p.x = (const bf16*)d.x; p.y = (const bf16*)d.y; p.neg = (const long long*)d.neg_idx; p.logits = d.logits;
+  p.dlogits = d.dlogits; p.dx = d.dx; p.dy = d.dy; p.B = d.B; p.M = d.M; p.K = d.K; p.C = d.C;
+  if (!p.x || !p.y || !p.neg) return set_error("infonce: null pointer");
+  if (p.C != 128 && p.C != 256 && p.C != 512 && p.C != 768) return set_error("infonce: final_dim must be one of 128, 256, 512, 768");
+  if (p.B <= 0 || p.M <= 1 || p.K < 0) return set_error("infonce: need B>0, M>1, K>=0");
+  if (!(d.temp > 0.f)) return set_error("infonce: logit_temp must be positive");
+  p.inv_temp = 1.0f / d.temp;
+  return 0;
+}
+
+int nce_fwd(const NceDesc& d, hipStream_t st) {
+  NceP p{};
+  if (int e = nce_fill(d, p)) return e;
+  if (!p.logits) return set_error("infonce_fwd: null logits");
+  long R = (long)p.B * p.M;
+  int grid = (int)std::min<long>((R + 3) / 4, 4096);
+  switch (p.C) {
+    case 128: hipLaunchKernelGGL((nce_kernel<false, 8>), dim3(grid), dim3(256), 0, st, p); break;
+    case 256: hipLaunchKernelGGL((nce_kernel<false, 16>), dim3(grid), dim3(256), 0, st, p); break;
+    case 512: hipLaunchKernelGGL((nce_kernel<false, 32>), dim3(grid), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((nce_kernel<false, 48>), dim3(grid), dim3(256), 0, st, p); break;
+  }
+  return hip_check(hipGetLastError(), "infonce_fwd");
+}
+
+int nce_bwd(const NceDesc& d, hipStream_t st) {
+  NceP p{};
+  if (int e = nce_fill(d, p)) return e;
+  if (!p.dlogits || !p.dx || !p.dy) return set_error("infonce_bwd: null pointer");
+  long R = (long)p.B * p.M;
+  if (int e = hip_check(hipMemsetAsync(p.dy, 0, sizeof(float) * R * p.C, st), "memset")) return e;
+  int grid = (int)std::min<long>((R + 3) / 4, 4096);
+  switch (p.C) {
+    case 128: hipLaunchKernelGGL((nce_kernel<true, 8>), dim3(grid), dim3(256), 0, st, p); break;
+    case 256: hipLaunchKernelGGL((nce_kernel<true, 16>), dim3(grid), dim3(256), 0, st, p); break;
+    case 512: hipLaunchKernelGGL((nce_kernel<true, 32>), dim3(grid), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((nce_kernel<true, 48>), dim3(grid), dim3(256), 0, st, p); break;
+  }
+  return hip_check(hipGetLastError(), "infonce_bwd");
+}
+
+// ================================================================================================
+// Cross entropy with target class 0 over rows of fp32 logits (reduction = sum), accuracy
+// counters as the criterion computes them, and dlogits = softmax - onehot(0).
+// out[0] = loss sum, out[1] = #(argmax==0), out[2] = #(argmax==0 && argmin==0)
+// ================================================================================================
+__global__ __launch_bounds__(256) void ce_kernel(const float* logits, long R, int W, float* out, float* dlogits) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  float loss_acc = 0.f, max0 = 0.f, both0 = 0.f;
+  for (long row = wave_id; row < R; row += nwaves) {
+    const float* lp = logits + row * W;
+    float mx = -INFINITY, mn = INFINITY;
+    int amx = 0x7fffffff, amn = 0x7fffffff;
+    for (int v = lane; v < W; v += 64) {
+      float x = lp[v];
+      if (x > mx) { mx = x; amx = v; }
+      if (x < mn) { mn = x; amn = v; }
+    }
+    wave_argmax(mx, amx);
+    float nmn = -mn;
+    wave_argmax(nmn, amn);
+    float se = 0.f;
+    for (int v = lane; v < W; v += 64) se += __expf(lp[v] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    if (dlogits)
+      for (int v = lane; v < W; v += 64) dlogits[row * W + v] = __expf(lp[v] - lse) - (v == 0 ? 1.f : 0.f);
+    if (lane == 0) {
+      loss_acc += lse - lp[0];
+      if (amx == 0) { max0 += 1.f; if (amn == 0) both0 += 1.f; }
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(&out[0], loss_acc);
+    atomicAdd(&out[1], max0);
+    atomicAdd(&out[2], both0);
+  }
+}
+
+int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hipStream_t st) {
+  if (!logits || !out3) return set_error("ce_rows: null pointer");
+  if (R <= 0 || W <= 0) return set_error("ce_rows: bad shape");
+  if (int e = hip_check(hipMemsetAsync(out3, 0, 3 * sizeof(float), st), "memset")) return e;
+  int grid = (int)std::min<long>((R + 3) / 4, 1024);
+  hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, st, logits, R, W, out3, dlogits);
+  return hip_check(hipGetLastError(), "ce_rows");
+}
+
+// ================================================================================================
+// misc: row gather / scatter by index, transpose, fp32 -> bf16, column sums
+// ================================================================================================
+__global__ void gather_rows_kernel(const bf16* src, const int* idx, bf16* dst, long R, int C, int scatter) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  int cpr = C / 8;
+  if (i >= R * cpr) return;
+  long row = i / cpr;
+  int ch = (int)(i % cpr);
+  long s = scatter ? row : idx[row], d = scatter ? idx[row] : row;
+  *(u32x4*)(dst + d * C + ch * 8) = *(const u32x4*)(src + s * C + ch * 8);
+}
+int gather_rows(const void* src, const int* idx, void* dst, long R, int C, int scatter, hipStream_t st) {
+  if (!src || !idx || !dst) return set_error("gather_rows: null pointer");
+  if (C % 8 || R <= 0) return set_error("gather_rows: C must be a multiple of 8 and R positive");
+  long n = R * (C / 8);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16*)src, idx, (bf16*)dst, R, C, scatter);
+  return hip_check(hipGetLastError(), "gather_rows");
+}
+
+// out[c][r] = in[r][c]  (bf16, 32x32 LDS tiles) ; batched over blockIdx.z
+__global__ void transpose_kernel(const bf16* in, bf16* out, int R, int C, long sin, long sout) {
+  __shared__ bf16 t[32][33];
+  in += (long)blockIdx.z * sin; out += (long)blockIdx.z * sout;
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + threadIdx.x;
+    t[i][threadIdx.x] = (r < R && c < C) ? in[(long)r * C + c] : f2bf(0.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) out[(long)c * R + r] = t[threadIdx.x][i];
+  }
+}
+int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t st) {
+  if (!in || !out) return set_error("transpose2d: null pointer");
+  if (R <= 0 || C <= 0 || batch <= 0) return set_error("transpose2d: bad shape");
+  dim3 grid((C + 31) / 32, (R + 31) / 32, batch), block(32, 8);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, (const bf16*)in, (bf16*)out, R, C, (long)R * C, (long)R * C);
+  return hip_check(hipGetLastError(), "transpose2d");
+}
+
+__global__ void f32_to_bf16_kernel(const float* in, bf16* out, long n, float scale) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    f32x4 v = *(const f32x4*)(in + i);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e] * scale);
+    *(bf16x4*)(out + i) = o;
+  } else {
+    for (; i < n; ++i) out[i] = f2bf(in[i] * scale);
+  }
+}
+int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st) {
+  if (!in || !out || n <= 0) return set_error("f32_to_bf16: bad arguments");
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, in, (bf16*)out, n, scale);
+  return hip_check(hipGetLastError(), "f32_to_bf16");
+}
+
+// out[n] += sum_m in[m][n]  (bf16 in, fp32 atomics out): bias gradients
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* in, float* out, long M, int N, long ld, int rows_per_block) {
+  __shared__ float red[8][33][8];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;  // 32 column chunks x 8 row lanes
+  const int col = (blockIdx.x * 32 + cx) * 8;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < N)
+    for (long r = r0 + ry; r < r1; r += 8) {
+      bf16x8 v = *(const bf16x8*)(in + r * ld + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ry][cx][e] = acc[e];
+  __syncthreads();
+  if (ry == 0 && col < N) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += red[k][cx][e];
+      atomicAdd(&out[col + e], s);
+    }
+  }
+}
+int colsum(const void* in, float* out, long M, int N, long ld, hipStream_t st) {
+  if (!in || !out) return set_error("colsum: null pointer");
+  if (N % 8 || ld % 8 || M <= 0) return set_error("colsum: N and ld must be multiples of 8");
+  int rpb = 256;
+  dim3 grid((N / 8 + 31) / 32, (unsigned)((M + rpb - 1) / rpb));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, (const bf16*)in, out, M, N, ld, rpb);
+  return hip_check(hipGetLastError(), "colsum");
+}
+
+}  // namespace w2vs

@@ -1,0 +1,650 @@
+// Row-wise (channel-last) HBM-bound kernels: one 64-lane wave per row, 16-B vector access,
+// fp32 statistics via wavefront shuffles.  Every tensor here is [rows, C] bf16 with C in
+// {512, 768, 1024} (C % 8 == 0, C <= 1024): a lane owns chunks {lane, lane+64} of 8 channels.
+//
+//   conv0_ln_gelu      a1 layer 0   (wav2vec2.py:733-743)   waveform -> [B, L0, 512]
+//   feat_ln            a3 + a4      (wav2vec2.py:554-558)   features_pen + LayerNorm(512)
+//   enc_prologue       a6 a7 a8 a10 (wav2vec2.py:446, wav2vec_S.py:355-388, 465-484)
+//   add_dropout_ln     a11 glue     (wav2vec2.py:965-976)
+#include "common.h"
+#include "w2vs_internal.h"
+
+namespace w2vs {
+
+constexpr float LN_EPS = 1e-5f;
+constexpr int ROWS_PER_BLOCK = 4;  // 256 threads = 4 waves = 4 rows in flight per block
+
+struct Row {  // up to 1024 channels: 2 chunks of 8 per lane
+  float v[2][8];
+};
+
+__device__ __forceinline__ int nchunks(int C) { return C >> 3; }
+
+__device__ __forceinline__ void load_row(const bf16* p, int C, int lane, Row& r) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int ch = lane + 64 * h;
+    if (ch < nchunks(C)) {
+      bf16x8 t = *(const bf16x8*)(p + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[h][e] = bf2f(t[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[h][e] = 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void store_row(bf16* p, int C, int lane, const Row& r) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int ch = lane + 64 * h;
+    if (ch < nchunks(C)) {
+      bf16x8 t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = f2bf(r.v[h][e]);
+      *(bf16x8*)(p + ch * 8) = t;
+    }
+  }
+}
+__device__ __forceinline__ void row_stats(const Row& r, int C, int lane, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += r.v[h][e];  // chunks beyond C hold zeros
+  mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (lane + 64 * h < nchunks(C)) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { float d = r.v[h][e] - mean; q += d * d; }
+    }
+  }
+  rstd = rsqrtf(wave_sum(q) / (float)C + LN_EPS);
+}
+
+// dropout: element index = row_id*C + channel; identical in fwd and bwd
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+  return hash32(seed, idx) >= thr ? inv_keep : 0.f;
+}
+
+// =====================================================================================
+// conv layer 0: Conv1d(1->C, k=10, s=5, no pad) -> LayerNorm(C) over channels -> GELU
+// =====================================================================================
+struct Conv0P {
+  const bf16* wave; const bf16* w; const bf16* cbias; const bf16* lnw; const bf16* lnb;
+  bf16* y; float* mean; float* rstd;
+  const bf16* dy; float* dw; float* dcbias; float* dlnw; float* dlnb;
+  int B, L, L0, C, k, s;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void conv0_kernel(Conv0P p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int C = p.C, K = p.k;
+  const bool act = lane < nchunks(C);  // C <= 512 for the conv stack: one chunk per lane
+  // per-lane weights for its 8 channels (k <= 16 taps)
+  float w[8][10];
+  float cb[8], g[8], bb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = lane * 8 + e;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w[e][j] = (act && j < K) ? bf2f(p.w[c * K + j]) : 0.f;
+    cb[e] = (act && p.cbias) ? bf2f(p.cbias[c]) : 0.f;
+    g[e] = act ? bf2f(p.lnw[c]) : 0.f;
+    bb[e] = act ? bf2f(p.lnb[c]) : 0.f;
+  }
+  float dw[8][10], dg[8], db[8], dcb[8];
+  if (BWD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[e] = db[e] = dcb[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) dw[e][j] = 0.f;
+    }
+  }
+  const long rows = (long)p.B * p.L0;
+  for (long row = wave_id; row < rows; row += nwaves) {
+    const int b = (int)(row / p.L0), t = (int)(row % p.L0);
+    const bf16* xw = p.wave + (long)b * p.L + (long)t * p.s;
+    float x[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) x[j] = (j < K) ? bf2f(xw[j]) : 0.f;
+    float c0[8];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = cb[e];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) a = fmaf(w[e][j], x[j], a);
+      c0[e] = act ? a : 0.f;
+      s += c0[e];
+    }
+    float mean, rstd;
+    if (!BWD) {
+      mean = wave_sum(s) / (float)C;
+      float q = 0.f;
+      if (act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = c0[e] - mean; q += d * d; }
+      }
+      rstd = rsqrtf(wave_sum(q) / (float)C + LN_EPS);
+      if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+      if (act) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(gelu_exact((c0[e] - mean) * rstd * g[e] + bb[e]));
+        *(bf16x8*)(p.y + row * C + lane * 8) = o;
+      }
+    } else {
+      mean = p.mean[row]; rstd = p.rstd[row];
+      float dxh[8], xh[8];
+      float s1 = 0.f, s2 = 0.f;
+      bf16x8 dyv;
+      if (act) dyv = *(const bf16x8*)(p.dy + row * C + lane * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[e] = (c0[e] - mean) * rstd;
+        float z = xh[e] * g[e] + bb[e];
+        float dz = act ? bf2f(dyv[e]) * gelu_grad(z) : 0.f;
+        dg[e] += dz * xh[e];
+        db[e] += dz;
+        dxh[e] = dz * g[e];
+        s1 += dxh[e];
+        s2 += dxh[e] * xh[e];
+      }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dc = act ? rstd * (dxh[e] - s1 - xh[e] * s2) : 0.f;
+        dcb[e] += dc;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) dw[e][j] = fmaf(dc, x[j], dw[e][j]);
+      }
+    }
+  }
+  if (BWD && act) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = lane * 8 + e;
+      atomicAdd(&p.dlnw[c], dg[e]);
+      atomicAdd(&p.dlnb[c], db[e]);
+      if (p.dcbias) atomicAdd(&p.dcbias[c], dcb[e]);
+#pragma unroll
+      for (int j = 0; j < 10; ++j)
+        if (j < K) atomicAdd(&p.dw[c * K + j], dw[e][j]);
+    }
+  }
+}
+
+int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, void* y,
+              float* mean, float* rstd, int B, int L, int C, int k, int s, hipStream_t st) {
+  if (!wave || !w || !lnw || !lnb || !y || !mean || !rstd) return set_error("conv0_fwd: null pointer");
+  if (C % 8 || C > 512 || k > 10 || k < 1 || s < 1 || L < k) return set_error("conv0_fwd: need C%8==0, C<=512, k<=10, L>=k");
+  Conv0P p{};
+  p.wave = (const bf16*)wave; p.w = (const bf16*)w; p.cbias = (const bf16*)cbias; p.lnw = (const bf16*)lnw; p.lnb = (const bf16*)lnb;
+  p.y = (bf16*)y; p.mean = mean; p.rstd = rstd; p.B = B; p.L = L; p.L0 = (L - k) / s + 1; p.C = C; p.k = k; p.s = s;
+  long rows = (long)B * p.L0;
+  int grid = (int)std::min<long>((rows + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(conv0_kernel<false>, dim3(grid), dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "conv0_fwd");
+}
+
+int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, const float* mean,
+              const float* rstd, const void* dy, float* dw, float* dcbias, float* dlnw, float* dlnb, int B, int L, int C,
+              int k, int s, hipStream_t st) {
+  if (!wave || !w || !lnw || !lnb || !dy || !mean || !rstd || !dw || !dlnw || !dlnb) return set_error("conv0_bwd: null pointer");
+  if (C % 8 || C > 512 || k > 10 || k < 1 || s < 1 || L < k) return set_error("conv0_bwd: need C%8==0, C<=512, k<=10, L>=k");
+  Conv0P p{};
+  p.wave = (const bf16*)wave; p.w = (const bf16*)w; p.cbias = (const bf16*)cbias; p.lnw = (const bf16*)lnw; p.lnb = (const bf16*)lnb;
+  p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.dy = (const bf16*)dy;
+  p.dw = dw; p.dcbias = dcbias; p.dlnw = dlnw; p.dlnb = dlnb;
+  p.B = B; p.L = L; p.L0 = (L - k) / s + 1; p.C = C; p.k = k; p.s = s;
+  long rows = (long)B * p.L0;
+  int grid = (int)std::min<long>((rows + 3) / 4, 256 * 2);  // fewer, longer waves: fewer final atomics
+  hipLaunchKernelGGL(conv0_kernel<true>, dim3(grid), dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "conv0_bwd");
+}
+
+// =====================================================================================
+// Generic LayerNorm forward / backward over rows (used by feat_ln, conv LN layers of the
+// large model, add_dropout_ln).  Modes are compile-time flags.
+// =====================================================================================
+struct LnP {
+  const bf16* x;      // main input  [rows, C]
+  const bf16* res;    // residual (added) or nullptr
+  const bf16* g; const bf16* b;
+  bf16* y;            // LN output (may be null when only the sum is wanted)
+  bf16* sum_out;      // x(+dropout) + res, bf16 (pre-LN residual stream) or nullptr
+  float* mean; float* rstd;
+  float* sumsq;       // features_pen accumulator (sum of x^2), or nullptr
+  // dropout on x before the add
+  float p_drop; uint64_t seed;
+  // backward
+  const bf16* dy; const bf16* dsum; const bf16* aux;  // aux: pre-activation for the fused gelu'
+  bf16* dx; bf16* dres; float* dg; float* db;
+  float out_scale;    // multiplies dx (GradMultiply)
+  float pen_coef;     // d(loss)/d(sum x^2) : adds 2*x*pen_coef to dx
+  int gelu;           // fwd: apply GELU after LN; bwd: dy is grad wrt GELU output
+  long rows; int C;
+};
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int C = p.C;
+  const uint32_t thr = drop_threshold(p.p_drop);
+  const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+  Row g, b;
+  load_row(p.g, C, lane, g);
+  load_row(p.b, C, lane, b);
+  float sq = 0.f;
+  for (long row = wave_id; row < p.rows; row += nwaves) {
+    Row x;
+    load_row(p.x + row * C, C, lane, x);
+    if (p.sumsq) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sq += x.v[h][e] * x.v[h][e];
+    }
+    if (p.p_drop > 0.f) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          x.v[h][e] *= drop_scale(p.seed, (uint64_t)row * C + (lane + 64 * h) * 8 + e, thr, inv_keep);
+    }
+    if (p.res) {
+      Row r;
+      load_row(p.res + row * C, C, lane, r);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x.v[h][e] += r.v[h][e];
+    }
+    if (p.sum_out) {
+      store_row(p.sum_out + row * C, C, lane, x);
+      // the LN below sees the value that was stored (bf16), as a two-kernel pipeline would
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x.v[h][e] = bf2f(f2bf(x.v[h][e]));
+    }
+    if (p.y) {
+      float mean, rstd;
+      row_stats(x, C, lane, mean, rstd);
+      if (lane == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = (x.v[h][e] - mean) * rstd * g.v[h][e] + b.v[h][e];
+          x.v[h][e] = p.gelu ? gelu_exact(z) : z;
+        }
+      store_row(p.y + row * C, C, lane, x);
+    }
+  }
+  if (p.sumsq) {
+    sq = wave_sum(sq);
+    if (lane == 0) atomicAdd(p.sumsq, sq);
+  }
+}
+
+// dx = LNbwd(dy) [+ dsum];   dres = dx;   d(x) = dx * dropmask/(1-p)
+// `x` here must be the LN *input* (sum).  When gelu: dy is wrt gelu(LN(x)).
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int C = p.C;
+  const uint32_t thr = drop_threshold(p.p_drop);
+  const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+  Row g, b, dg, db;
+  load_row(p.g, C, lane, g);
+  load_row(p.b, C, lane, b);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg.v[h][e] = db.v[h][e] = 0.f;
+  for (long row = wave_id; row < p.rows; row += nwaves) {
+    Row x, dy;
+    load_row(p.x + row * C, C, lane, x);
+    if (p.dy) load_row(p.dy + row * C, C, lane, dy);
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    Row dxh;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xh = (x.v[h][e] - mean) * rstd;
+        float d = p.dy ? dy.v[h][e] : 0.f;
+        if (p.gelu) d *= gelu_grad(xh * g.v[h][e] + b.v[h][e]);
+        if (lane + 64 * h >= nchunks(C)) { d = 0.f; xh = 0.f; }
+        dg.v[h][e] += d * xh;
+        db.v[h][e] += d;
+        float t = d * g.v[h][e];
+        dxh.v[h][e] = t;
+        s1 += t;
+        s2 += t * xh;
+        x.v[h][e] = xh;
+      }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    Row dx;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dx.v[h][e] = rstd * (dxh.v[h][e] - s1 - x.v[h][e] * s2);
+    if (p.dsum) {
+      Row ds;
+      load_row(p.dsum + row * C, C, lane, ds);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dx.v[h][e] += ds.v[h][e];
+    }
+    if (p.dres) store_row(p.dres + row * C, C, lane, dx);
+    if (p.dx) {
+      if (p.pen_coef != 0.f || p.out_scale != 1.f) {
+        // x.v currently holds xhat: rebuild the raw input for the penalty term
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float raw = x.v[h][e] / rstd + mean;
+            dx.v[h][e] = (dx.v[h][e] + 2.f * raw * p.pen_coef) * p.out_scale;
+          }
+      }
+      if (p.p_drop > 0.f) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            dx.v[h][e] *= drop_scale(p.seed, (uint64_t)row * C + (lane + 64 * h) * 8 + e, thr, inv_keep);
+      }
+      if (p.aux) {  // chain through the producing layer's GELU: dx *= gelu'(pre)
+        Row a;
+        load_row(p.aux + row * C, C, lane, a);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dx.v[h][e] *= gelu_grad(a.v[h][e]);
+      }
+      store_row(p.dx + row * C, C, lane, dx);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int ch = lane + 64 * h;
+    if (ch < nchunks(C)) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&p.dg[ch * 8 + e], dg.v[h][e]);
+        atomicAdd(&p.db[ch * 8 + e], db.v[h][e]);
+      }
+    }
+  }
+}
+
+static int ln_check(const LnP& p, const char* who) {
+  if (p.C % 8 || p.C > 1024 || p.C < 8) return set_error("layernorm: need C % 8 == 0 and C <= 1024");
+  if (p.rows <= 0) return set_error("layernorm: rows must be positive");
+  (void)who;
+  return 0;
+}
+
+int ln_fwd(const LnFwdDesc& d, hipStream_t st) {
+  LnP p{};
+  p.x = (const bf16*)d.x; p.res = (const bf16*)d.res; p.g = (const bf16*)d.gamma; p.b = (const bf16*)d.beta;
+  p.y = (bf16*)d.y; p.sum_out = (bf16*)d.sum_out; p.mean = d.mean; p.rstd = d.rstd; p.sumsq = d.sumsq;
+  p.p_drop = d.p_drop; p.seed = d.seed; p.gelu = d.gelu; p.rows = d.rows; p.C = d.C;
+  if (!p.x || !p.g || !p.b) return set_error("ln_fwd: null pointer");
+  if (p.y && !p.mean) return set_error("ln_fwd: mean/rstd buffers required");
+  if (int e = ln_check(p, "ln_fwd")) return e;
+  int grid = (int)std::min<long>((p.rows + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "ln_fwd");
+}
+
+int ln_bwd(const LnBwdDesc& d, hipStream_t st) {
+  LnP p{};
+  p.x = (const bf16*)d.x; p.g = (const bf16*)d.gamma; p.b = (const bf16*)d.beta; p.mean = const_cast<float*>(d.mean);
+  p.rstd = const_cast<float*>(d.rstd); p.dy = (const bf16*)d.dy; p.dsum = (const bf16*)d.dsum; p.aux = (const bf16*)d.aux;
+  p.dx = (bf16*)d.dx; p.dres = (bf16*)d.dres; p.dg = d.dgamma; p.db = d.dbeta; p.p_drop = d.p_drop; p.seed = d.seed;
+  p.out_scale = d.out_scale; p.pen_coef = d.pen_coef; p.gelu = d.gelu; p.rows = d.rows; p.C = d.C;
+  if (!p.x || !p.g || !p.b || !p.mean || !p.rstd || !p.dg || !p.db) return set_error("ln_bwd: null pointer");
+  if (int e = ln_check(p, "ln_bwd")) return e;
+  int grid = (int)std::min<long>((p.rows + 3) / 4, 256 * 2);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "ln_bwd");
+}
+
+// =====================================================================================
+// Encoder prologue: mask fill + sinusoidal position + LayerNorm + dropout + pad frame +
+// right-context copies, written straight into the [B, N, C] token layout the encoder uses.
+// =====================================================================================
+struct EncProP {
+  const bf16* x;          // [B, T, C] projected features (before dropout_input)
+  const uint8_t* mask;    // [B, T] 1 = replace by mask_emb ; may be null
+  const uint8_t* pad;     // [B, T] 1 = padded frame ; may be null
+  const int* pos;         // [B, T] row of the sinusoid table (host: 1 + cumsum of non-pad, 1 for pad)
+  const bf16* mask_emb; const float* pos_table;  // [n_pos, C] fp32
+  const bf16* g; const bf16* b;
+  bf16* out;              // [B, N, C]
+  float* mean; float* rstd;  // [B, T]
+  const int* src;         // [N] source frame of every token row (0..Tp-1)
+  float p_in; uint64_t seed_in; float p_enc; uint64_t seed_enc;
+  int apply_ln;           // 0 for the pre-LN (large) variant
+  int B, T, Tp, N, C;
+  // backward
+  const bf16* dout; bf16* dx; float* dmask_emb; float* dg; float* db;
+  const int* copy_start; const int* copy_list;  // CSR: copies of frame t are copy_list[copy_start[t]..copy_start[t+1])
+};
+
+__global__ __launch_bounds__(256) void enc_prologue_fwd_kernel(EncProP p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int C = p.C;
+  const uint32_t thr_in = drop_threshold(p.p_in), thr_enc = drop_threshold(p.p_enc);
+  const float ik_in = p.p_in > 0.f ? 1.f / (1.f - p.p_in) : 1.f, ik_enc = p.p_enc > 0.f ? 1.f / (1.f - p.p_enc) : 1.f;
+  Row g, b, me;
+  load_row(p.g, C, lane, g);
+  load_row(p.b, C, lane, b);
+  load_row(p.mask_emb, C, lane, me);
+  const long rows = (long)p.B * p.N;
+  for (long row = wave_id; row < rows; row += nwaves) {
+    const int bi = (int)(row / p.N), n = (int)(row % p.N);
+    const int t = p.src[n];
+    Row x;
+    if (t >= p.T) {  // the zero frame appended by pad_to_multiple (after the LN, wav2vec_S.py:375-377)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x.v[h][e] = 0.f;
+      store_row(p.out + row * C, C, lane, x);
+      continue;
+    }
+    const long fr = (long)bi * p.T + t;
+    const bool is_pad = p.pad && p.pad[fr];
+    const bool is_mask = p.mask && p.mask[fr];
+    load_row(p.x + fr * C, C, lane, x);
+    const float* pt = p.pos_table + (long)p.pos[fr] * C;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ch = lane + 64 * h;
+      if (ch >= nchunks(C)) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = x.v[h][e];
+        if (p.p_in > 0.f) v = bf2f(f2bf(v * drop_scale(p.seed_in, (uint64_t)fr * C + ch * 8 + e, thr_in, ik_in)));
+        if (is_mask) v = me.v[h][e];
+        if (is_pad) v = 0.f;
+        x.v[h][e] = bf2f(f2bf(v + pt[ch * 8 + e]));
+      }
+    }
+    if (p.apply_ln) {
+      float mean, rstd;
+      row_stats(x, C, lane, mean, rstd);
+      if (lane == 0 && n < p.T) { p.mean[fr] = mean; p.rstd[fr] = rstd; }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x.v[h][e] = bf2f(f2bf((x.v[h][e] - mean) * rstd * g.v[h][e] + b.v[h][e]));
+    }
+    if (p.p_enc > 0.f) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          x.v[h][e] *= drop_scale(p.seed_enc, (uint64_t)fr * C + (lane + 64 * h) * 8 + e, thr_enc, ik_enc);
+    }
+    store_row(p.out + row * C, C, lane, x);
+  }
+}
+
+// one wave per source frame (b, t): gathers the gradient of the frame and of all its copies
+__global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int C = p.C;
+  const uint32_t thr_in = drop_threshold(p.p_in), thr_enc = drop_threshold(p.p_enc);
+  const float ik_in = p.p_in > 0.f ? 1.f / (1.f - p.p_in) : 1.f, ik_enc = p.p_enc > 0.f ? 1.f / (1.f - p.p_enc) : 1.f;
+  Row g, me, dgm, dbt, dme;
+  load_row(p.g, C, lane, g);
+  load_row(p.mask_emb, C, lane, me);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dgm.v[h][e] = dbt.v[h][e] = dme.v[h][e] = 0.f;
+  const long rows = (long)p.B * p.T;
+  for (long fr = wave_id; fr < rows; fr += nwaves) {
+    const int bi = (int)(fr / p.T), t = (int)(fr % p.T);
+    const bool is_pad = p.pad && p.pad[fr];
+    const bool is_mask = p.mask && p.mask[fr];
+    Row d;
+    load_row(p.dout + ((long)bi * p.N + t) * C, C, lane, d);
+    for (int ci = p.copy_start[t]; ci < p.copy_start[t + 1]; ++ci) {
+      Row dc;
+      load_row(p.dout + ((long)bi * p.N + p.copy_list[ci]) * C, C, lane, dc);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d.v[h][e] += dc.v[h][e];
+    }
+    if (p.p_enc > 0.f) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          d.v[h][e] *= drop_scale(p.seed_enc, (uint64_t)fr * C + (lane + 64 * h) * 8 + e, thr_enc, ik_enc);
+    }
+    Row dx = d;
+    if (p.apply_ln) {
+      // rebuild the LN input exactly as the forward did
+      Row x;
+      load_row(p.x + fr * C, C, lane, x);
+      const float* pt = p.pos_table + (long)p.pos[fr] * C;
+      const float mean = p.mean[fr], rstd = p.rstd[fr];
+      float s1 = 0.f, s2 = 0.f;
+      Row dxh;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int ch = lane + 64 * h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = x.v[h][e], xh = 0.f, t1 = 0.f;
+          if (ch < nchunks(C)) {
+            if (p.p_in > 0.f) v = bf2f(f2bf(v * drop_scale(p.seed_in, (uint64_t)fr * C + ch * 8 + e, thr_in, ik_in)));
+            if (is_mask) v = me.v[h][e];
+            if (is_pad) v = 0.f;
+            v = bf2f(f2bf(v + pt[ch * 8 + e]));
+            xh = (v - mean) * rstd;
+            dgm.v[h][e] += d.v[h][e] * xh;
+            dbt.v[h][e] += d.v[h][e];
+            t1 = d.v[h][e] * g.v[h][e];
+          }
+          x.v[h][e] = xh;
+          dxh.v[h][e] = t1;
+          s1 += t1;
+          s2 += t1 * xh;
+        }
+      }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dx.v[h][e] = rstd * (dxh.v[h][e] - s1 - x.v[h][e] * s2);
+    }
+    // through the mask fill / padding zero / dropout_input
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ch = lane + 64 * h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = dx.v[h][e];
+        if (is_pad) v = 0.f;
+        if (is_mask) { dme.v[h][e] += v; v = 0.f; }
+        if (p.p_in > 0.f && ch < nchunks(C)) v *= drop_scale(p.seed_in, (uint64_t)fr * C + ch * 8 + e, thr_in, ik_in);
+        dx.v[h][e] = v;
+      }
+    }
+    store_row(p.dx + fr * C, C, lane, dx);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int ch = lane + 64 * h;
+    if (ch < nchunks(C)) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (p.apply_ln) {
+          atomicAdd(&p.dg[ch * 8 + e], dgm.v[h][e]);
+          atomicAdd(&p.db[ch * 8 + e], dbt.v[h][e]);
+        }
+        atomicAdd(&p.dmask_emb[ch * 8 + e], dme.v[h][e]);
+      }
+    }
+  }
+}
+
+static int encpro_fill(const EncPrologueDesc& d, EncProP& p) {
+  p.x = (const bf16*)d.x; p.mask = d.mask; p.pad = d.pad; p.pos = d.pos; p.mask_emb = (const bf16*)d.mask_emb;
+  p.pos_table = d.pos_table; p.g = (const bf16*)d.gamma; p.b = (const bf16*)d.beta; p.out = (bf16*)d.out;
+  p.mean = d.mean; p.rstd = d.rstd; p.src = d.src; p.p_in = d.p_in; p.seed_in = d.seed_in; p.p_enc = d.p_enc;
+  p.seed_enc = d.seed_enc; p.apply_ln = d.apply_ln; p.B = d.B; p.T = d.T; p.Tp = d.Tp; p.N = d.N; p.C = d.C;
+  p.dout = (const bf16*)d.dout; p.dx = (bf16*)d.dx; p.dmask_emb = d.dmask_emb; p.dg = d.dgamma; p.db = d.dbeta;
+  p.copy_start = d.copy_start; p.copy_list = d.copy_list;
+  if (!p.x || !p.pos || !p.mask_emb || !p.pos_table || !p.g || !p.b || !p.src || !p.mean || !p.rstd)
+    return set_error("enc_prologue: null pointer");
+  if (p.C % 8 || p.C > 1024) return set_error("enc_prologue: need C % 8 == 0 and C <= 1024");
+  if (p.B <= 0 || p.T <= 0 || p.Tp < p.T || p.N < p.Tp) return set_error("enc_prologue: bad B/T/Tp/N");
+  return 0;
+}
+
+int enc_prologue_fwd(const EncPrologueDesc& d, hipStream_t st) {
+  EncProP p{};
+  if (int e = encpro_fill(d, p)) return e;
+  if (!p.out) return set_error("enc_prologue_fwd: null output");
+  long rows = (long)p.B * p.N;
+  int grid = (int)std::min<long>((rows + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(enc_prologue_fwd_kernel, dim3(grid), dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "enc_prologue_fwd");
+}
+
+int enc_prologue_bwd(const EncPrologueDesc& d, hipStream_t st) {
+  EncProP p{};
+  if (int e = encpro_fill(d, p)) return e;
+  if (!p.dout || !p.dx || !p.dmask_emb || !p.dg || !p.db || !p.copy_start || !p.copy_list)
+    return set_error("enc_prologue_bwd: null pointer");
+  long rows = (long)p.B * p.T;
+  int grid = (int)std::min<long>((rows + 3) / 4, 256 * 2);
+  hipLaunchKernelGGL(enc_prologue_bwd_kernel, dim3(grid), dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "enc_prologue_bwd");
+}
+
+}  // namespace w2vs

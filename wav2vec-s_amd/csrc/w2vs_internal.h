@@ -1,0 +1,44 @@
+// Host-side internal declarations shared by the translation units of libw2vs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "../../include/w2vs.h"
+
+namespace w2vs {
+
+int set_error(const char* msg);                 // records msg, returns W2VS_ERR_INVALID
+int hip_check(hipError_t e, const char* what);  // 0, or records + returns W2VS_ERR_HIP
+
+typedef w2vs_gemm_desc GemmDesc;
+typedef w2vs_ln_fwd_desc LnFwdDesc;
+typedef w2vs_ln_bwd_desc LnBwdDesc;
+typedef w2vs_enc_prologue_desc EncPrologueDesc;
+typedef w2vs_attn_desc AttnDesc;
+typedef w2vs_quant_desc QuantDesc;
+typedef w2vs_nce_desc NceDesc;
+
+int gemm_nt(const GemmDesc& d, hipStream_t s);
+int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s);
+int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, void* y,
+              float* mean, float* rstd, int B, int L, int C, int k, int s, hipStream_t st);
+int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, const float* mean,
+              const float* rstd, const void* dy, float* dw, float* dcbias, float* dlnw, float* dlnb, int B, int L, int C,
+              int k, int s, hipStream_t st);
+int ln_fwd(const LnFwdDesc& d, hipStream_t st);
+int ln_bwd(const LnBwdDesc& d, hipStream_t st);
+int enc_prologue_fwd(const EncPrologueDesc& d, hipStream_t st);
+int enc_prologue_bwd(const EncPrologueDesc& d, hipStream_t st);
+int attn_fwd(const AttnDesc& d, hipStream_t st);
+int attn_bwd(const AttnDesc& d, hipStream_t st);
+int quant_fwd(const QuantDesc& d, hipStream_t st);
+int quant_bwd(const QuantDesc& d, hipStream_t st);
+int nce_fwd(const NceDesc& d, hipStream_t st);
+int nce_bwd(const NceDesc& d, hipStream_t st);
+int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hipStream_t st);
+int gather_rows(const void* src, const int* idx, void* dst, long R, int C, int scatter, hipStream_t st);
+int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t st);
+int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st);
+int colsum(const void* in, float* out, long M, int N, long ld, hipStream_t st);
+
+}  // namespace w2vs

@@ -1,0 +1,420 @@
+"""Tensor-level wrappers of the libw2vs kernels (one Python function per C-ABI entry).
+
+torch is used here only for device memory and the current HIP stream; every computation is a
+hand-written HIP kernel.  Nothing falls back to torch ops or to the CPU: a missing library or a
+rejected call raises ``W2vsError``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_NONE, AttnDesc,
+                   EncPrologueDesc, GemmDesc, LnBwdDesc, LnFwdDesc, NceDesc, QuantDesc, W2vsError)
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise W2vsError("%s must live on the GPU (no CPU path exists)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise W2vsError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise W2vsError("%s must be contiguous" % name)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, bias=None, aux=None,
+            epi=EPI_NONE, a_off=0, batch=1, sA=0, sB=0, sC=0, a_bytes=0, b_bytes=0, c_elems=0, alpha=1.0):
+    d = GemmDesc()
+    d.A, d.B, d.C, d.C2, d.Cf, d.bias, d.aux = _p(a), _p(b), _p(out), _p(out2), _p(out_f32), _p(bias), _p(aux)
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.lda, d.ldb, d.ldc, d.a_off = lda, ldb, ldc, a_off
+    d.sA, d.sB, d.sC = sA, sB, sC
+    d.a_bytes, d.b_bytes, d.c_elems = a_bytes, b_bytes, c_elems
+    d.epi, d.alpha = epi, alpha
+    _lib.call("w2vs_gemm_nt", C.byref(d), _stream())
+
+
+def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB=0, a_bytes=0, b_bytes=0,
+            alpha=1.0, num_cu=256):
+    d = GemmDesc()
+    d.A, d.B, d.Cf = _p(a), _p(b), _p(out_f32)
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    d.lda, d.ldb, d.ldc, d.a_off = lda, ldb, ldc, a_off
+    d.sA, d.sB = sA, sB
+    d.a_bytes, d.b_bytes = a_bytes, b_bytes
+    d.alpha = alpha
+    _lib.call("w2vs_gemm_tn", C.byref(d), num_cu, _stream())
+
+
+def linear_fwd(x, w, bias=None, *, gelu=False, save_pre=False):
+    """y = x @ w.T (+ bias) [gelu].  x [R, K] bf16, w [N, K] bf16.  Returns y (and pre if save_pre)."""
+    _chk(x, BF16, "x"); _chk(w, BF16, "w"); _chk(bias, BF16, "bias")
+    R, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(R, N, device=x.device, dtype=BF16)
+    pre = torch.empty_like(y) if save_pre else None
+    epi = EPI_BIAS if not gelu else (EPI_BIAS_GELU_SAVE if save_pre else EPI_BIAS_GELU)
+    gemm_nt(x, w, M=R, N=N, K=K, lda=K, ldb=K, ldc=N, out=y, out2=pre, bias=bias, epi=epi)
+    return (y, pre) if save_pre else y
+
+
+def linear_dgrad(dy, w_t, *, dgelu_aux=None):
+    """dx = dy @ w  given w_t = w.T contiguous ([K, N]).  Optionally dx *= gelu'(aux)."""
+    _chk(dy, BF16, "dy"); _chk(w_t, BF16, "w_t")
+    R, N = dy.shape
+    K = w_t.shape[0]
+    dx = torch.empty(R, K, device=dy.device, dtype=BF16)
+    gemm_nt(dy, w_t, M=R, N=K, K=N, lda=N, ldb=N, ldc=K, out=dx, aux=dgelu_aux,
+            epi=EPI_DGELU if dgelu_aux is not None else EPI_NONE)
+    return dx
+
+
+def linear_wgrad(dy, x, dw_f32, alpha=1.0):
+    """dw[N, K] += alpha * dy[R, N]^T @ x[R, K]   (fp32 accumulate, atomics)."""
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw_f32, torch.float32, "dw")
+    R, N = dy.shape
+    K = x.shape[1]
+    gemm_tn(dy, x, dw_f32, M=N, N=K, K=R, lda=N, ldb=K, ldc=K, alpha=alpha)
+
+
+def colsum(x, out_f32):
+    _chk(x, BF16, "x"); _chk(out_f32, torch.float32, "out")
+    M, N = x.shape
+    _lib.call("w2vs_colsum", _p(x), _p(out_f32), M, N, N, _stream())
+
+
+def transpose2d(x, batch=1):
+    """[batch, R, C] -> [batch, C, R] (bf16)."""
+    _chk(x, BF16, "x")
+    R, Cc = x.shape[-2], x.shape[-1]
+    out = torch.empty(*x.shape[:-2], Cc, R, device=x.device, dtype=BF16)
+    _lib.call("w2vs_transpose2d", _p(x), _p(out), R, Cc, batch, _stream())
+    return out
+
+
+def f32_to_bf16(x, scale=1.0):
+    _chk(x, torch.float32, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _lib.call("w2vs_f32_to_bf16", _p(x), _p(out), x.numel(), scale, _stream())
+    return out
+
+
+# -------------------------------------------------------------------------------- conv as GEMM
+def conv_pack_weight(w):
+    """[Cout, Cin, k] -> [Cout, k*Cin] (tap-major) so a channel-last window is one GEMM row."""
+    _chk(w, BF16, "w")
+    Cout, Cin, k = w.shape
+    return transpose2d(w.view(Cout, Cin, k), batch=Cout).view(Cout, k * Cin)
+
+
+def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True):
+    """Channel-last Conv1d (no padding): x [B, Lin, Cin], w2 [Cout, k*Cin] -> [B, Lout, Cout]."""
+    _chk(x, BF16, "x"); _chk(w2, BF16, "w2")
+    B, Lin, Cin = x.shape
+    Cout = w2.shape[0]
+    Lout = (Lin - k) // s + 1
+    y = torch.empty(B, Lout, Cout, device=x.device, dtype=BF16)
+    pre = torch.empty_like(y) if save_pre else None
+    if gelu:
+        epi = EPI_BIAS_GELU_SAVE if save_pre else EPI_BIAS_GELU
+    else:
+        epi = EPI_BIAS
+    gemm_nt(x, w2, M=Lout, N=Cout, K=k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, out=y, out2=pre, bias=bias,
+            epi=epi, batch=B, sA=Lin * Cin, sC=Lout * Cout, a_bytes=Lin * Cin * 2)
+    return (y, pre) if save_pre else y
+
+
+def conv_cl_dgrad(dy, w, k, s, Lin, *, dgelu_aux=None):
+    """Gradient wrt the channel-last input of conv_cl_fwd.  dy [B, Lout, Cout]; w [Cout, Cin, k] bf16.
+    (k, s) = (2, 2): non-overlapping windows -> plain GEMM into [B, Lout, 2*Cin].
+    (k, s) = (3, 2): input rows pair up, pair p = [dy[p-1] | dy[p]] @ [[W2, 0], [W0, W1]]."""
+    _chk(dy, BF16, "dy"); _chk(w, BF16, "w")
+    B, Lout, Cout = dy.shape
+    Cin = w.shape[1]
+    dx = torch.empty(B, Lin, Cin, device=dy.device, dtype=BF16)
+    epi = EPI_DGELU if dgelu_aux is not None else EPI_NONE
+    if (k, s) == (2, 2):
+        # B operand [N = 2*Cin, K = Cout]: row (j*Cin + ci) = w[:, ci, j]
+        bt = dgrad_pack_k2(w)
+        if Lin > 2 * Lout:
+            dx[:, 2 * Lout:].zero_()
+        gemm_nt(dy, bt, M=Lout, N=2 * Cin, K=Cout, lda=Cout, ldb=Cout, ldc=2 * Cin, out=dx, aux=dgelu_aux, epi=epi,
+                batch=B, sA=Lout * Cout, sC=Lin * Cin, a_bytes=Lout * Cout * 2, c_elems=Lin * Cin)
+    elif (k, s) == (3, 2):
+        bt = dgrad_pack_k3(w)
+        P = (Lin + 1) // 2
+        gemm_nt(dy, bt, M=P, N=2 * Cin, K=2 * Cout, lda=Cout, ldb=2 * Cout, ldc=2 * Cin, out=dx, aux=dgelu_aux,
+                epi=epi, a_off=-Cout, batch=B, sA=Lout * Cout, sC=Lin * Cin, a_bytes=Lout * Cout * 2,
+                c_elems=Lin * Cin)
+    else:
+        raise W2vsError("conv dgrad is built for (k,s) in {(2,2),(3,2)}; got (%d,%d)" % (k, s))
+    return dx
+
+
+def dgrad_pack_k2(w):
+    Cout, Cin, k = w.shape
+    # [Cout, Cin, 2] -> [2, Cin, Cout] -> [2*Cin, Cout]
+    return transpose2d(w.view(Cout, Cin * k), batch=1).view(Cin, k, Cout).transpose(0, 1).contiguous().view(k * Cin, Cout)
+
+
+def dgrad_pack_k3(w):
+    """B operand [N = 2*Cin, K = 2*Cout] with blocks  row-half 0: [W2^T | W0^T], row-half 1: [0 | W1^T]
+    (K index 0..Cout-1 multiplies dy[p-1], Cout..2Cout-1 multiplies dy[p])."""
+    Cout, Cin, k = w.shape
+    wt = transpose2d(w.view(Cout, Cin * k), batch=1).view(Cin, k, Cout)  # [Cin, k, Cout]
+    bt = torch.zeros(2, Cin, 2, Cout, device=w.device, dtype=BF16)
+    bt[0, :, 0] = wt[:, 2]
+    bt[0, :, 1] = wt[:, 0]
+    bt[1, :, 1] = wt[:, 1]
+    return bt.view(2 * Cin, 2 * Cout)
+
+
+def conv_cl_wgrad(dy, x, k, s, dw2_f32, alpha=1.0):
+    """dw2[Cout, k*Cin] += sum_{b,t} dy[b,t,:]^T x_window[b,t,:]  (fp32 accumulate)."""
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw2_f32, torch.float32, "dw2")
+    B, Lout, Cout = dy.shape
+    _, Lin, Cin = x.shape
+    gemm_tn(dy, x, dw2_f32, M=Cout, N=k * Cin, K=Lout, lda=Cout, ldb=s * Cin, ldc=k * Cin, batch=B,
+            sA=Lout * Cout, sB=Lin * Cin, a_bytes=Lout * Cout * 2, b_bytes=Lin * Cin * 2, alpha=alpha)
+
+
+# ---------------------------------------------------------------------------------- conv0
+def conv0_fwd(wave, w, ln_w, ln_b, k, s, conv_bias=None):
+    _chk(wave, BF16, "wave"); _chk(w, BF16, "w"); _chk(ln_w, BF16, "ln_w"); _chk(ln_b, BF16, "ln_b")
+    B, L = wave.shape
+    Cc = w.shape[0]
+    L0 = (L - k) // s + 1
+    y = torch.empty(B, L0, Cc, device=wave.device, dtype=BF16)
+    mean = torch.empty(B * L0, device=wave.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    _lib.call("w2vs_conv0_fwd", _p(wave), _p(w), _p(conv_bias), _p(ln_w), _p(ln_b), _p(y), _p(mean), _p(rstd),
+              B, L, Cc, k, s, _stream())
+    return y, mean, rstd
+
+
+def conv0_bwd(wave, w, ln_w, ln_b, mean, rstd, dy, k, s, dw, dln_w, dln_b, conv_bias=None, dconv_bias=None):
+    _chk(dy, BF16, "dy")
+    B, L = wave.shape
+    Cc = w.shape[0]
+    _lib.call("w2vs_conv0_bwd", _p(wave), _p(w), _p(conv_bias), _p(ln_w), _p(ln_b), _p(mean), _p(rstd), _p(dy),
+              _p(dw), _p(dconv_bias), _p(dln_w), _p(dln_b), B, L, Cc, k, s, _stream())
+
+
+# ------------------------------------------------------------------------------ LayerNorm rows
+def ln_fwd(x, gamma, beta, *, res=None, want_y=True, want_sum=False, sumsq=None, gelu=False, p_drop=0.0, seed=0):
+    _chk(x, BF16, "x"); _chk(res, BF16, "res"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x) if want_y else None
+    s_out = torch.empty_like(x) if want_sum else None
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if want_y else None
+    rstd = torch.empty_like(mean) if want_y else None
+    d = LnFwdDesc()
+    d.x, d.res, d.gamma, d.beta, d.y, d.sum_out = _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(s_out)
+    d.mean, d.rstd, d.sumsq = _p(mean), _p(rstd), _p(sumsq)
+    d.rows, d.C, d.gelu, d.p_drop, d.seed = rows, Cc, int(gelu), p_drop, seed
+    _lib.call("w2vs_ln_fwd", C.byref(d), _stream())
+    return y, s_out, mean, rstd
+
+
+def ln_bwd(x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy=None, dsum=None, aux=None, want_dx=True,
+           want_dres=False, gelu=False, p_drop=0.0, seed=0, out_scale=1.0, pen_coef=0.0):
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(dsum, BF16, "dsum"); _chk(aux, BF16, "aux")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx = torch.empty_like(x) if want_dx else None
+    dres = torch.empty_like(x) if want_dres else None
+    d = LnBwdDesc()
+    d.x, d.gamma, d.beta, d.mean, d.rstd = _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd)
+    d.dy, d.dsum, d.aux, d.dx, d.dres, d.dgamma, d.dbeta = _p(dy), _p(dsum), _p(aux), _p(dx), _p(dres), _p(dgamma), _p(dbeta)
+    d.rows, d.C, d.gelu, d.p_drop, d.seed, d.out_scale, d.pen_coef = rows, Cc, int(gelu), p_drop, seed, out_scale, pen_coef
+    _lib.call("w2vs_ln_bwd", C.byref(d), _stream())
+    return dx, dres
+
+
+# ------------------------------------------------------------------------------ encoder prologue
+def _encpro_desc(x, mask, pad, pos, mask_emb, pos_table, gamma, beta, mean, rstd, src, p_in, seed_in, p_enc, seed_enc,
+                 apply_ln, B, T, Tp, N, Cc):
+    d = EncPrologueDesc()
+    d.x, d.mask, d.pad, d.pos, d.mask_emb, d.pos_table = _p(x), _p(mask), _p(pad), _p(pos), _p(mask_emb), _p(pos_table)
+    d.gamma, d.beta, d.mean, d.rstd, d.src = _p(gamma), _p(beta), _p(mean), _p(rstd), _p(src)
+    d.p_in, d.p_enc, d.seed_in, d.seed_enc = p_in, p_enc, seed_in, seed_enc
+    d.apply_ln, d.B, d.T, d.Tp, d.N, d.C = int(apply_ln), B, T, Tp, N, Cc
+    return d
+
+
+def enc_prologue_fwd(x, mask, pad, pos, mask_emb, pos_table, gamma, beta, src, Tp, *, apply_ln=True, p_in=0.0,
+                     seed_in=0, p_enc=0.0, seed_enc=0):
+    _chk(x, BF16, "x"); _chk(mask, torch.uint8, "mask"); _chk(pad, torch.uint8, "pad"); _chk(pos, torch.int32, "pos")
+    _chk(pos_table, torch.float32, "pos_table"); _chk(src, torch.int32, "src")
+    B, T, Cc = x.shape
+    N = src.numel()
+    out = torch.empty(B, N, Cc, device=x.device, dtype=BF16)
+    mean = torch.empty(B * T, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    d = _encpro_desc(x, mask, pad, pos, mask_emb, pos_table, gamma, beta, mean, rstd, src, p_in, seed_in, p_enc,
+                     seed_enc, apply_ln, B, T, Tp, N, Cc)
+    d.out = _p(out)
+    _lib.call("w2vs_enc_prologue_fwd", C.byref(d), _stream())
+    return out, mean, rstd
+
+
+def enc_prologue_bwd(dout, x, mask, pad, pos, mask_emb, pos_table, gamma, beta, mean, rstd, src, copy_start, copy_list,
+                     Tp, dmask_emb, dgamma, dbeta, *, apply_ln=True, p_in=0.0, seed_in=0, p_enc=0.0, seed_enc=0):
+    _chk(dout, BF16, "dout")
+    B, T, Cc = x.shape
+    N = src.numel()
+    dx = torch.empty_like(x)
+    d = _encpro_desc(x, mask, pad, pos, mask_emb, pos_table, gamma, beta, mean, rstd, src, p_in, seed_in, p_enc,
+                     seed_enc, apply_ln, B, T, Tp, N, Cc)
+    d.dout, d.dx, d.dmask_emb, d.dgamma, d.dbeta = _p(dout), _p(dx), _p(dmask_emb), _p(dgamma), _p(dbeta)
+    d.copy_start, d.copy_list = _p(copy_start), _p(copy_list)
+    _lib.call("w2vs_enc_prologue_bwd", C.byref(d), _stream())
+    return dx
+
+
+# -------------------------------------------------------------------------------------- attention
+def _attn_desc(qkv, o, lse, kpad, H, Tp, m, r, p_drop, seed):
+    B, N, C3 = qkv.shape
+    Cc = C3 // 3
+    d = AttnDesc()
+    base = qkv.data_ptr()
+    d.q, d.k, d.v = C.c_void_p(base), C.c_void_p(base + 2 * Cc), C.c_void_p(base + 4 * Cc)
+    d.o, d.lse, d.kpad = _p(o), _p(lse), _p(kpad)
+    d.ld, d.ldo, d.sb, d.sbo = C3, Cc, N * C3, N * Cc
+    d.B, d.H, d.N, d.Tp, d.m, d.r, d.head_dim = B, H, N, Tp, m, r, Cc // H
+    d.scale, d.p_drop, d.seed = float(Cc // H) ** -0.5, p_drop, seed
+    return d
+
+
+def attn_fwd(qkv, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
+    """qkv [B, N, 3C] bf16 (q | k | v).  Returns ctx [B, N, C] and lse [B, H, N]."""
+    _chk(qkv, BF16, "qkv"); _chk(kpad, torch.uint8, "kpad")
+    B, N, C3 = qkv.shape
+    o = torch.empty(B, N, C3 // 3, device=qkv.device, dtype=BF16)
+    lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    d = _attn_desc(qkv, o, lse, kpad, H, Tp, m, r, p_drop, seed)
+    _lib.call("w2vs_attn_fwd", C.byref(d), _stream())
+    return o, lse
+
+
+def attn_bwd(dout, qkv, o, lse, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
+    _chk(dout, BF16, "dout"); _chk(qkv, BF16, "qkv"); _chk(o, BF16, "o")
+    B, N, C3 = qkv.shape
+    Cc = C3 // 3
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    d = _attn_desc(qkv, o, lse, kpad, H, Tp, m, r, p_drop, seed)
+    base = dqkv.data_ptr()
+    d.dout, d.delta = _p(dout), _p(delta)
+    d.dq, d.dk, d.dv = C.c_void_p(base), C.c_void_p(base + 2 * Cc), C.c_void_p(base + 4 * Cc)
+    _lib.call("w2vs_attn_bwd", C.byref(d), _stream())
+    return dqkv
+
+
+# -------------------------------------------------------------------------------------- quantizer
+class QuantState:
+    __slots__ = ("idx", "hard_cnt", "prob_sum", "ppl", "cvec")
+
+
+def quant_fwd(logits, vars2d, G, V, tau, training, noise=None, seed=0):
+    """logits [R, G*V] bf16, vars2d [G*V, D] bf16 -> q [R, G*D], state (ppl = [prob_ppl, code_ppl])."""
+    _chk(logits, BF16, "logits"); _chk(vars2d, BF16, "vars"); _chk(noise, torch.float32, "noise")
+    R = logits.shape[0]
+    D = vars2d.shape[1]
+    dev = logits.device
+    q = torch.empty(R, G * D, device=dev, dtype=BF16)
+    st = QuantState()
+    st.idx = torch.empty(R, G, device=dev, dtype=torch.int32)
+    st.hard_cnt = torch.empty(G * V, device=dev, dtype=torch.float32)
+    st.prob_sum = torch.empty(G * V, device=dev, dtype=torch.float32)
+    st.ppl = torch.empty(2, device=dev, dtype=torch.float32)
+    st.cvec = torch.empty(G * V, device=dev, dtype=torch.float32)
+    d = QuantDesc()
+    d.logits, d.noise, d.vars, d.q, d.idx = _p(logits), _p(noise), _p(vars2d), _p(q), _p(st.idx)
+    d.hard_cnt, d.prob_sum, d.ppl_out, d.cvec_out = _p(st.hard_cnt), _p(st.prob_sum), _p(st.ppl), _p(st.cvec)
+    d.tau, d.R, d.G, d.V, d.D, d.training, d.seed = tau, R, G, V, D, int(training), seed
+    _lib.call("w2vs_quant_fwd", C.byref(d), _stream())
+    return q, st
+
+
+def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, noise=None, seed=0):
+    """Returns dlogits [R, G*V] bf16; accumulates dvars (fp32 [G*V, D])."""
+    _chk(dq, BF16, "dq")
+    R = logits.shape[0]
+    D = vars2d.shape[1]
+    dsoft = None
+    if training:
+        dsoft = torch.empty(R, G * V, device=dq.device, dtype=BF16)
+        # dsoft[:, g] = dq[:, g] @ vars_g^T : batched over groups through column-offset strides
+        gemm_nt(dq, vars2d, M=R, N=V, K=D, lda=G * D, ldb=D, ldc=G * V, out=dsoft, batch=G, sA=D, sB=V * D, sC=V,
+                a_bytes=(R * G * D) * 2, b_bytes=V * D * 2, c_elems=R * G * V)
+    dlogits = torch.empty(R, G * V, device=dq.device, dtype=BF16)
+    d = QuantDesc()
+    d.logits, d.noise, d.vars = _p(logits), _p(noise), _p(vars2d)
+    d.prob_sum, d.dq, d.dsoft, d.cvec, d.dlogits, d.dvars = _p(st.prob_sum), _p(dq), _p(dsoft), _p(st.cvec), _p(dlogits), _p(dvars_f32)
+    d.ppl_grad, d.tau, d.R, d.G, d.V, d.D, d.training, d.seed = ppl_grad, tau, R, G, V, D, int(training), seed
+    _lib.call("w2vs_quant_bwd", C.byref(d), _stream())
+    return dlogits
+
+
+# ---------------------------------------------------------------------------------------- InfoNCE
+def nce_fwd(x, y, neg_idx, B, M, K, temp):
+    """x, y [B*M, C] bf16; neg_idx [B, K*M] int64 -> logits [B*M, K+1] fp32."""
+    _chk(x, BF16, "x"); _chk(y, BF16, "y"); _chk(neg_idx, torch.int64, "neg_idx")
+    Cc = x.shape[1]
+    logits = torch.empty(B * M, K + 1, device=x.device, dtype=torch.float32)
+    d = NceDesc()
+    d.x, d.y, d.neg_idx, d.logits = _p(x), _p(y), _p(neg_idx), _p(logits)
+    d.B, d.M, d.K, d.C, d.temp = B, M, K, Cc, temp
+    _lib.call("w2vs_nce_fwd", C.byref(d), _stream())
+    return logits
+
+
+def nce_bwd(dlogits, x, y, neg_idx, B, M, K, temp):
+    _chk(dlogits, torch.float32, "dlogits")
+    Cc = x.shape[1]
+    dx = torch.empty(B * M, Cc, device=x.device, dtype=torch.float32)
+    dy = torch.empty(B * M, Cc, device=x.device, dtype=torch.float32)
+    d = NceDesc()
+    d.x, d.y, d.neg_idx, d.dlogits, d.dx, d.dy = _p(x), _p(y), _p(neg_idx), _p(dlogits), _p(dx), _p(dy)
+    d.B, d.M, d.K, d.C, d.temp = B, M, K, Cc, temp
+    _lib.call("w2vs_nce_bwd", C.byref(d), _stream())
+    return dx, dy
+
+
+def ce_rows(logits, want_grad=True):
+    """Cross entropy (target 0, sum) of fp32 logits [R, W].  Returns out3 = [loss, n_max0, n_both0], dlogits."""
+    _chk(logits, torch.float32, "logits")
+    R, W = logits.shape
+    out3 = torch.empty(3, device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits) if want_grad else None
+    _lib.call("w2vs_ce_rows", _p(logits), R, W, _p(out3), _p(dl), _stream())
+    return out3, dl
+
+
+def gather_rows(src, idx, R, scatter=False, out=None):
+    """out[i] = src[idx[i]]  or (scatter) out[idx[i]] = src[i]; rows of bf16."""
+    _chk(src, BF16, "src"); _chk(idx, torch.int32, "idx")
+    Cc = src.shape[-1]
+    if out is None:
+        if scatter:
+            raise W2vsError("scatter needs a pre-zeroed destination")
+        out = torch.empty(R, Cc, device=src.device, dtype=BF16)
+    _lib.call("w2vs_gather_rows", _p(src), _p(idx), _p(out), R, Cc, int(scatter), _stream())
+    return out
