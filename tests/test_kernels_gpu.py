@@ -194,7 +194,7 @@ def test_dropout_statistics_and_consistency(ops):
     keep = (s1.float() > 0).float().mean().item()
     assert abs(keep - 0.9) < 3e-3
     vals = torch.unique(s1.float().cpu())
-    assert set(np.round(vals.numpy(), 3)) <= {0.0, round(float(torch.tensor(1 / 0.9).to(BF)), 3)}
+    assert vals.tolist() == [0.0, float(torch.tensor(1 / 0.9).to(BF))]
     # backward uses the same mask: d(x) = mask/(1-p) * dy with LN bypassed (dsum path)
     y, s, mean, rstd = ops.ln_fwd(dev(x), dev(g), dev(b), res=dev(zero), want_sum=True, p_drop=p, seed=1234)
     dg = torch.zeros(Cc, device="cuda"); db = torch.zeros(Cc, device="cuda")
