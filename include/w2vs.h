@@ -47,7 +47,8 @@ enum {
   W2VS_EPI_BIAS_GELU = 2,      /* C = gelu(acc + bias[n])          (exact erf GELU)  */
   W2VS_EPI_BIAS_GELU_SAVE = 3, /* C2 = acc + bias (pre-activation), C = gelu(C2)     */
   W2VS_EPI_DGELU = 4,          /* C = acc * gelu'(aux[m,n])                          */
-  W2VS_EPI_F32 = 5             /* Cf = alpha * acc (fp32 output)                     */
+  W2VS_EPI_F32 = 5,            /* Cf = alpha * acc (fp32 output)                     */
+  W2VS_EPI_ADD = 6             /* C = acc + aux[m,n]                                 */
 };
 typedef struct w2vs_gemm_desc {
   const void* A; const void* B;
@@ -170,6 +171,9 @@ int w2vs_ce_rows(const float* logits, int64_t R, int32_t W, float* out3, float* 
 int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, int32_t C, int32_t scatter, void* stream);
 int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* stream);
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* stream);
+/* out[i] = in[i] * keep(seed, i) / (1 - p) : nn.Dropout (dropout_features, wav2vec2.py:571);
+ * the backward is the same call on the gradient with the same seed. */
+int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* stream);
 /* out[n] += sum_m in[m, n] : bias gradients */
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* stream);
 

@@ -1,0 +1,160 @@
+"""CPU-side product code: host RNG pieces against the reference-generated golden vectors, the
+config/state_dict surface, and the C ABI (library loads, exports every declared symbol; no
+compute calls - there is no GPU here)."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import wav2vec_s_amd as w
+from wav2vec_s_amd import host_rng, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _g(golden_dir):
+    return np.load(os.path.join(golden_dir, "host_rng.npz"))
+
+
+@pytest.mark.parametrize("B,T", [(2, 499), (8, 546), (5, 781), (3, 999), (2, 49)])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_product_mask_indices_bit_exact(golden_dir, B, T, seed):
+    z = _g(golden_dir)
+    np.random.seed(seed)
+    m = host_rng.compute_mask_indices((B, T), None, 0.65, 10, "static", 0, min_masks=2, no_overlap=False, min_space=1)
+    want = np.unpackbits(z[f"mask_{B}_{T}_s{seed}"], axis=1)[:, :T].astype(bool)
+    assert np.array_equal(m, want)
+    assert np.random.rand() == z[f"mask_{B}_{T}_s{seed}_next"][0]
+
+
+def test_product_mask_with_padding(golden_dir):
+    z = _g(golden_dir)
+    np.random.seed(3)
+    pm = torch.zeros(3, 200, dtype=torch.bool)
+    pm[1, 150:] = True
+    pm[2, 90:] = True
+    m = host_rng.compute_mask_indices((3, 200), pm, 0.65, 10, "static", 0, min_masks=2)
+    assert np.array_equal(m, np.unpackbits(z["mask_pad_3_200_s3"], axis=1)[:, :200].astype(bool))
+
+
+@pytest.mark.parametrize("B,M,seed", [(2, 20, 0), (2, 247, 1), (8, 245, 2)])
+def test_product_negative_indices_bit_exact(golden_dir, B, M, seed):
+    z = _g(golden_dir)
+    torch.manual_seed(seed)
+    idx = host_rng.sample_negative_indices(B, M, 100).numpy()
+    assert hashlib.sha256(np.ascontiguousarray(idx).tobytes()).digest() == bytes(z[f"neg_{B}_{M}_s{seed}_sha"])
+
+
+@pytest.mark.parametrize("Tp,m,r", [(500, 16, 8), (546, 16, 8), (34, 8, 4), (40, 32, 16), (10, 16, 8), (50, 8, 0), (48, 16, 8)])
+def test_block_layout_and_mask_helper(golden_dir, Tp, m, r):
+    z = _g(golden_dir)
+    lay = host_rng.block_layout(Tp, m, r)
+    assert np.array_equal(lay.src, z[f"blk_{Tp}_{m}_{r}_src"])
+    pad = np.zeros((2, Tp), dtype=bool)
+    pad[1, Tp - 1] = True
+    kp = lay.key_padding(pad, 2)
+    assert np.array_equal(kp.astype(bool), z[f"blk_{Tp}_{m}_{r}_pad"])
+    # CSR of copies is the inverse of src on the appended rows
+    for t in range(Tp):
+        rows = lay.copy_list[lay.copy_start[t]:lay.copy_start[t + 1]]
+        assert all(lay.src[c] == t for c in rows)
+    assert lay.copy_start[-1] == lay.R
+    # API-compatible gen_block_attn_mask
+    x = torch.arange(Tp, dtype=torch.float).view(Tp, 1, 1).repeat(1, 2, 1)
+    xo, po, am = w.gen_block_attn_mask(x, torch.from_numpy(pad), m, r)
+    N = Tp + lay.R
+    assert np.array_equal((am != 0).numpy(), np.unpackbits(z[f"blk_{Tp}_{m}_{r}_mask"], axis=1)[:, :N].astype(bool))
+    assert np.array_equal(po.numpy(), z[f"blk_{Tp}_{m}_{r}_pad"])
+    assert np.array_equal(xo[:, 0, 0].numpy().astype(np.int32), z[f"blk_{Tp}_{m}_{r}_src"])
+    assert set(torch.unique(am).tolist()) <= {0.0, -1e4}
+
+
+def test_sinusoid_and_positions(golden_dir):
+    z = _g(golden_dir)
+    t = host_rng.sinusoidal_table(8002, 768, 1)
+    assert np.array_equal(t[[0, 1, 2, 3, 500, 8001]].numpy(), z["sin768_rows"])
+    pad = torch.tensor([[False, False, True, False], [False, False, False, False]])
+    assert host_rng.positions_from_padding(pad, 2, 4).tolist() == [[2, 3, 1, 4], [2, 3, 4, 5]]
+    assert host_rng.positions_from_padding(None, 2, 4).tolist() == [[2, 3, 4, 5]] * 2
+
+
+def test_context_sampling_and_layerdrop_draws():
+    import random
+    random.seed(9)
+    m, r = host_rng.sample_context("sampling", 16, 8)
+    random.seed(9)
+    a, b = random.randint(4, 16) * 2, random.randint(2, 8) * 2
+    assert (m, r) == (a, min(b, a // 2))
+    assert host_rng.sample_context("constant", 16, 8) == (16, 8)
+    with pytest.raises(ValueError):
+        host_rng.sample_context("bogus", 16, 8)
+    np.random.seed(4)
+    keep = host_rng.layerdrop_keep(12, 0.05, True)
+    np.random.seed(4)
+    assert keep == [np.random.random() > 0.05 for _ in range(12)]
+    st = np.random.get_state()[1][:4].tolist()
+    host_rng.layerdrop_keep(12, 0.0, True)          # layerdrop 0: no draw at all (wav2vec_S.py:415)
+    assert np.random.get_state()[1][:4].tolist() == st
+
+
+def test_config_defaults_and_yaml_overrides():
+    c = w.Wav2VecSConfig()
+    assert (c.encoder_layers, c.encoder_embed_dim, c.encoder_ffn_embed_dim, c.encoder_attention_heads) == (12, 768, 3072, 12)
+    assert c.right_context == 16 and c.main_context == 16 and c.context_type == "constant" and c.pos_type == "sin"
+    b = w.base_librispeech_config()
+    assert b.layer_norm_num == 1 and b.latent_temp_tuple == (2, 0.5, 0.999995) and b.right_context == 8
+    assert b.conv_layers == [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
+    lg = w.large_librivox_config()
+    assert lg.layer_norm_num == 7 and lg.layer_norm_first and lg.conv_bias and lg.latent_temp_tuple == (2.0, 0.1, 0.999995)
+    import argparse
+    ns = argparse.Namespace(encoder_layers=24, bogus=1)
+    assert w.Wav2VecSConfig.from_namespace(ns).encoder_layers == 24
+
+
+def test_state_dict_surface_matches_reference_inventory():
+    """SURVEY.md section 8a 'Parameter inventory' (90.33 M parameters, key names)."""
+    m = w.Wav2VecSModel(w.base_librispeech_config())
+    sd = m.state_dict()
+    assert abs(sum(p.numel() for p in m.parameters()) - 90.33e6) < 0.01e6
+    for k, shp in {"mask_emb": (768,), "feature_extractor.conv_layers.0.0.weight": (512, 1, 10),
+                   "feature_extractor.conv_layers.0.2.1.weight": (512,), "feature_extractor.conv_layers.4.0.weight": (512, 512, 3),
+                   "feature_extractor.conv_layers.6.0.weight": (512, 512, 2), "layer_norm.bias": (512,),
+                   "post_extract_proj.weight": (768, 512), "quantizer.vars": (1, 640, 128),
+                   "quantizer.weight_proj.weight": (640, 512), "project_q.weight": (256, 256),
+                   "encoder.pos_conv._float_tensor": (1,), "encoder.layers.11.self_attn.q_proj.weight": (768, 768),
+                   "encoder.layers.0.fc1.weight": (3072, 768), "encoder.layers.0.final_layer_norm.bias": (768,),
+                   "encoder.layer_norm.weight": (768,), "final_proj.weight": (256, 768)}.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert not any("pos_conv.0" in k for k in sd)
+    m.set_num_updates(1000)
+    assert m.quantizer.curr_temp == max(2 * 0.999995 ** 1000, 0.5)
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 16000))       # CPU tensors are refused loudly: no fallback path
+
+
+def test_c_abi_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "w2vs.h")).read()
+    declared = set(re.findall(r"\b(w2vs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.EXPORTS)
+    assert lib.w2vs_abi_version() == 1
+    # argument validation works without a GPU (rejected before any launch)
+    import ctypes as C
+    d = _lib.GemmDesc()
+    assert lib.w2vs_gemm_nt(C.byref(d), None) == -1
+    assert b"null" in lib.w2vs_last_error()
+    assert lib.w2vs_gemm_nt(None, None) == -1
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "wav2vec-s_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "w2vs_oracle" not in src and "ref_import" not in src, fn

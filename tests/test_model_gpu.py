@@ -1,0 +1,198 @@
+"""End-to-end parity of the HIP model (wav2vec_s_amd.Wav2VecSModel, bf16) against the fp32 CPU
+oracle on identical weights and identical injected host draws.  Needs an MI355X: pytest -m gpu
+
+Tolerances (north_star): loss within 1e-3 relative; bit-exact integers (mask / negatives / code
+indices where the logits are not near-tied); activations within 2e-2 relative Frobenius."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import w2vs_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def rel(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _setup(cfg_kw, B, L, seed, m_ctx, r_ctx, train=True):
+    import wav2vec_s_amd as w
+    from wav2vec_s_amd import engine, host_rng
+    cfg = w.Wav2VecSConfig(**cfg_kw)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    model = w.Wav2VecSModel(cfg)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias") or "layer_norm" in n or ".2.1." in n:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    model = model.to(BF)
+    # oracle sees exactly the bf16-rounded parameters, in fp32
+    P = {k: v.float().clone().requires_grad_(v.dtype == BF and train) for k, v in model.state_dict().items()}
+    source = torch.randn(B, L, generator=g).to(BF)
+    ocfg = O.OracleCfg(**{k: v for k, v in cfg_kw.items() if k in O.OracleCfg.__dataclass_fields__})
+    T = O.conv_out_lengths(L, ocfg.conv_layers)[-1]
+    mask = host_rng.compute_mask_indices((B, T), None, cfg.mask_prob, cfg.mask_length, "static", 0, min_masks=2)
+    M = int(mask[0].sum())
+    neg = host_rng.sample_negative_indices(B, M, cfg.num_negatives)
+    G, V = cfg.latent_groups, cfg.latent_vars
+    noise = -torch.empty(B * M * G, V).exponential_(generator=g).log() if train else None
+    draws = engine.Draws(mask_indices=mask, neg_idx=neg, context=(m_ctx, r_ctx), layer_keep=[True] * cfg.encoder_layers,
+                         gumbel_noise=noise)
+    return w, model, P, ocfg, source, draws, mask, neg, noise
+
+
+BASE = dict(quantize_targets=True, extractor_mode="layer_norm", final_dim=256, encoder_layerdrop=0.0,
+            dropout_input=0.0, dropout_features=0.0, dropout=0.0, attention_dropout=0.0, encoder_embed_dim=768,
+            feature_grad_mult=0.1, context_type="constant",
+            conv_feature_layers="[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 2")
+
+
+def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
+    w, model, P, ocfg, source, draws, mask, neg, noise = _setup(cfg_kw, B, L, seed, m_ctx, r_ctx)
+    ocfg.loss_weights = tuple(loss_weights)
+    col = {}
+    ref = O.forward_loss(P, source.float(), ocfg, mask_indices=torch.from_numpy(mask), neg_idx=neg, main_context=m_ctx,
+                         right_context=r_ctx, tau=2.0, gumbel_noise=noise, collect=col)
+    ref["loss"].backward()
+    model = model.cuda().train()
+    model.inject_draws(draws)
+    crit = w.Wav2vecCriterion(infonce=True, loss_weights=list(loss_weights), log_keys=["prob_perplexity", "code_perplexity", "temp"])
+    loss, sample_size, log = crit(model, {"net_input": {"source": source.cuda()}})
+    loss.backward()
+    st = model._last_state
+    rep = {"tag": tag, "loss_hip": float(loss), "loss_ref": float(ref["loss"]), "sample_size": sample_size}
+    rep["loss_rel"] = abs(rep["loss_hip"] - rep["loss_ref"]) / abs(rep["loss_ref"])
+    B_, T, N = st.B, st.T, st.N
+    rep["conv0"] = rel(st.conv[0]["y"], col["conv0"].transpose(1, 2))
+    rep["conv_out"] = rel(st.y_last, col[f"conv{len(ocfg.conv_layers) - 1}"].transpose(1, 2))
+    rep["features"] = rel(st.feats, col["features"])
+    enc = st.enc.view(B_, N, -1)[:, :T]
+    rep["enc_out"] = rel(enc, col["enc_out"])
+    rep["q"] = rel(st.q.view(B_, -1, st.q.shape[-1]), col["q"])
+    rep["code_idx_equal"] = float((st.qst.idx.cpu().long() == col["q_idx"]).float().mean())
+    logits_ref = col["preds"].permute(1, 2, 0).reshape(-1, st.K + 1)
+    fin = torch.isfinite(logits_ref)
+    rep["logits_maxabs"] = float((st.logits.cpu()[fin] - logits_ref[fin]).abs().max())
+    rep["features_pen_rel"] = abs(float(st.pen_acc) / (B_ * T * st.C0) - float(ref["features_pen"])) / float(ref["features_pen"])
+    rep["prob_ppl_rel"] = abs(float(st.qst.ppl[0]) - float(ref["prob_perplexity"])) / float(ref["prob_perplexity"])
+    rep["correct"] = (log["correct"], ref["correct"])
+    grads = {}
+    for n, p in model.named_parameters():
+        want = P[n].grad
+        if want is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, n
+            continue
+        assert p.grad is not None, n
+        grads[n] = rel(p.grad, want) if float(want.norm()) > 1e-6 else float(p.grad.float().norm())
+    rep["grad_worst"] = sorted(grads.items(), key=lambda kv: -kv[1])[:8]
+    rep["grad_median"] = float(np.median(list(grads.values())))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, f"parity_{tag}.json"), "w") as f:
+        json.dump(rep, f, indent=1, default=str)
+    return rep, grads
+
+
+def test_base_model_step_matches_oracle():
+    """Full-width base (12 x 768, conv 512, 320x2 codes, 100 negatives), post-LN, short audio."""
+    rep, grads = _run_both(BASE, B=2, L=24000, seed=1, m_ctx=16, r_ctx=8, loss_weights=(0.1, 10.0), tag="base")
+    assert rep["loss_rel"] < 1e-3, rep
+    assert rep["conv0"] < 1e-2 and rep["conv_out"] < 2e-2 and rep["features"] < 2e-2, rep
+    assert rep["enc_out"] < 2e-2, rep
+    assert rep["code_idx_equal"] > 0.97, rep       # bf16 logits can flip near-tied argmaxes
+    assert rep["logits_maxabs"] < 0.15, rep        # logits are cos/0.1 in [-10, 10]
+    assert rep["features_pen_rel"] < 1e-2 and rep["prob_ppl_rel"] < 1e-2, rep
+    # k_proj.bias has an analytically zero gradient (softmax shift invariance): skip relative check
+    bad = {n: e for n, e in grads.items() if e > 0.08 and "k_proj.bias" not in n}
+    assert not bad, bad
+    assert rep["grad_median"] < 3e-2, rep
+
+
+def test_large_style_model_step_matches_oracle():
+    """pre-LN encoder, conv bias, LayerNorm in every conv layer (layer_norm_num=7), odd T, no grad mult."""
+    kw = dict(BASE, encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,
+              layer_norm_first=True, conv_bias=True, feature_grad_mult=1.0, final_dim=128, latent_vars=40,
+              num_negatives=20, conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
+    rep, grads = _run_both(kw, B=3, L=16400, seed=2, m_ctx=8, r_ctx=4, loss_weights=(0.1, 0.0), tag="large_style")
+    assert rep["loss_rel"] < 2e-3, rep
+    assert rep["enc_out"] < 2e-2 and rep["features"] < 2e-2, rep
+    bad = {n: e for n, e in grads.items() if e > 0.1 and "k_proj.bias" not in n}
+    assert not bad, bad
+
+
+def test_layerdrop_and_sampled_context_draw_order():
+    """Host RNG consumption order (a21): numpy -> mask, then one random() per layer; python random ->
+    two randints.  The HIP model must consume exactly what the oracle's restatement does."""
+    import wav2vec_s_amd as w
+    kw = dict(BASE, encoder_layers=12, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,
+              encoder_layerdrop=0.3, context_type="sampling", final_dim=128, latent_vars=40, num_negatives=20,
+              conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
+    cfg = w.Wav2VecSConfig(**kw)
+    model = w.Wav2VecSModel(cfg).to(BF).cuda().train()
+    src = torch.randn(2, 16000).to(BF).cuda()
+    np.random.seed(5); random.seed(5); torch.manual_seed(5)
+    out = model(src)
+    st = model._last_state
+    after = (np.random.rand(), random.random(), float(torch.rand(1)))
+    # replay the draws on the host alone
+    np.random.seed(5); random.seed(5); torch.manual_seed(5)
+    T = st.T
+    mask = O.compute_mask_indices((2, T), None, 0.65, 10, "static", 0, min_masks=2)
+    a, b = random.randint(4, 16) * 2, random.randint(2, 8) * 2
+    m, r = a, min(b, a // 2)
+    keep = [np.random.random() > 0.3 for _ in range(12)]
+    neg = O.sample_negative_indices(2, int(mask[0].sum()), 20)
+    assert np.array_equal(st.mask_np, mask)
+    assert (st.m, st.r) == (m, r)
+    assert st.kept == [i for i in range(12) if keep[i]]
+    assert torch.equal(st.neg.cpu(), neg)
+    assert after == (np.random.rand(), random.random(), float(torch.rand(1)))
+    out["x"].float().logsumexp(0).sum().backward()
+    for i in range(12):
+        gq = model.encoder.layers[i].fc1.weight.grad
+        assert (gq is None) == (i not in st.kept)
+
+
+def test_features_only_and_padding_mask():
+    """extract_features path (fine-tune callers): padded batch, mask=False, eval mode."""
+    import wav2vec_s_amd as w
+    from wav2vec_s_amd import engine
+    kw = dict(BASE, encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,
+              final_dim=128, latent_vars=40, num_negatives=20,
+              conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
+    cfg = w.Wav2VecSConfig(**kw)
+    torch.manual_seed(3)
+    model = w.Wav2VecSModel(cfg).to(BF)
+    P = {k: v.float() for k, v in model.state_dict().items()}
+    B, L = 2, 12000
+    source = torch.randn(B, L).to(BF)
+    pm = torch.zeros(B, L, dtype=torch.bool)
+    pm[1, 8000:] = True
+    source[1, 8000:] = 0
+    model = model.cuda().eval()
+    model.inject_draws(engine.Draws(context=(8, 4)))
+    x, pad = model.extract_features(source.cuda(), pm.cuda(), mask=False)
+    # oracle: same steps through blockwise_encoder with the frame-level padding mask
+    ocfg = O.OracleCfg(**{k: v for k, v in kw.items() if k in O.OracleCfg.__dataclass_fields__})
+    feats = O.conv_feature_extractor(source.float(), P, ocfg).transpose(1, 2)
+    T = feats.shape[1]
+    feats = torch.nn.functional.layer_norm(feats, (64,), P["layer_norm.weight"], P["layer_norm.bias"], 1e-5)
+    extra = pm.size(1) % T
+    pmf = pm[:, :-extra] if extra > 0 else pm
+    pmf = pmf.view(B, T, -1).all(-1)
+    xr = torch.nn.functional.linear(feats, P["post_extract_proj.weight"], P["post_extract_proj.bias"])
+    ref = O.blockwise_encoder(xr, P, ocfg, 8, 4, padding_mask=pmf)
+    assert torch.equal(pad.cpu(), pmf)
+    valid = ~pmf
+    assert rel(x.cpu()[valid], ref[valid]) < 2e-2

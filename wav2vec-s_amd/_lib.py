@@ -62,7 +62,7 @@ class NceDesc(C.Structure):
 
 _DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc]
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32 = range(6)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_ADD = range(7)
 
 # name -> argtypes ; every entry returns int
 _SIGS = {
@@ -85,6 +85,7 @@ _SIGS = {
     "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],
     "w2vs_colsum": [vp, vp, i64, i32, i64, vp],
+    "w2vs_dropout": [vp, vp, i64, f32, u64, vp],
 }
 EXPORTS = ["w2vs_abi_version", "w2vs_last_error", "w2vs_sizeof"] + list(_SIGS)
 

@@ -37,7 +37,7 @@ struct GemmP {
   float alpha;
 };
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6 };
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
@@ -184,6 +184,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * gelu_grad(bf2f(a[e])));
         *(bf16x8*)(Cb + o) = outv;
+      } else if (EPI == EPI_ADD) {
+        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+        bf16x8 outv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) + bf2f(a[e]));
+        *(bf16x8*)(Cb + o) = outv;
       } else {
         *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
         if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
@@ -320,7 +327,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   if (d.epi == EPI_F32 ? !d.Cf : !d.C) return set_error("gemm_nt: null output");
   if ((d.ldc % 8) || (d.N % 8)) return set_error("gemm_nt: N and ldc must be multiples of 8");
   if (d.K % 8) return set_error("gemm_nt: K must be a multiple of 8");
-  if (d.epi == EPI_DGELU && !d.aux) return set_error("gemm_nt: DGELU needs aux");
+  if ((d.epi == EPI_DGELU || d.epi == EPI_ADD) && !d.aux) return set_error("gemm_nt: DGELU/ADD need aux");
   if (d.epi == EPI_BIAS_GELU_SAVE && !d.C2) return set_error("gemm_nt: GELU_SAVE needs C2");
   GemmP p{};
   p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.C = (bf16*)d.C; p.C2 = (bf16*)d.C2; p.Cf = d.Cf;
@@ -340,6 +347,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     case EPI_BIAS_GELU_SAVE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS_GELU_SAVE>, grid, block, 0, s, p); break;
     case EPI_DGELU: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DGELU>, grid, block, 0, s, p); break;
     case EPI_F32: hipLaunchKernelGGL(gemm_nt_kernel<EPI_F32>, grid, block, 0, s, p); break;
+    case EPI_ADD: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ADD>, grid, block, 0, s, p); break;
     default: return set_error("gemm_nt: unknown epilogue");
   }
   return hip_check(hipGetLastError(), "gemm_nt launch");

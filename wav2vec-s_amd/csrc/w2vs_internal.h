@@ -39,6 +39,7 @@ int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hip
 int gather_rows(const void* src, const int* idx, void* dst, long R, int C, int scatter, hipStream_t st);
 int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t st);
 int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st);
+int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream_t st);
 int colsum(const void* in, float* out, long M, int N, long ld, hipStream_t st);
 
 }  // namespace w2vs

@@ -1,0 +1,513 @@
+"""Forward / backward schedule of one wav2vec-S pre-training micro-step on one MI355X.
+
+This is the hand-written replacement of autograd over the reference's forward
+(fs/models/wav2vec/wav2vec2.py:544-658 + wav2vec_S.py:355-440): an explicit sequence of
+libw2vs kernel launches on the current HIP stream, with every saved activation chosen by hand
+(bf16, channel-last / token-major) and all parameter gradients accumulated in ONE flat fp32
+arena (the buffer the data-parallel all-reduce later works on).  No torch math op is used on
+the path; torch allocates buffers and carries views.
+"""
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import host_rng, ops
+from ._lib import W2vsError
+
+BF16 = torch.bfloat16
+_GOLD = 0x9E3779B97F4A7C15
+_MASK64 = (1 << 64) - 1
+
+
+def _site_seed(base: int, site: int) -> int:
+    x = (base + site * _GOLD) & _MASK64
+    x ^= x >> 31
+    x = (x * 0xBF58476D1CE4E5B9) & _MASK64
+    x ^= x >> 29
+    return x & _MASK64
+
+
+class Draws:
+    """All host-side random decisions of one forward, injectable for parity runs."""
+
+    def __init__(self, mask_indices=None, neg_idx=None, context=None, layer_keep=None, gumbel_noise=None):
+        self.mask_indices = mask_indices   # np.bool [B, T] or None (-> sampled)
+        self.neg_idx = neg_idx             # torch int64 [B, K*M] (CPU) or None
+        self.context = context             # (m, r) or None
+        self.layer_keep = layer_keep       # list[bool] or None
+        self.gumbel_noise = gumbel_noise   # torch fp32 [B*M*G, V] (CPU/GPU) or None (-> device RNG)
+
+
+class Arena:
+    """Flat fp32 gradient arena with named views."""
+
+    def __init__(self, shapes: Dict[str, tuple], device):
+        self.offsets = {}
+        off = 0
+        for n, shp in shapes.items():
+            numel = int(np.prod(shp))
+            self.offsets[n] = (off, numel, shp)
+            off += (numel + 3) // 4 * 4  # keep 16-B alignment of every view
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+
+    def view(self, n):
+        off, numel, shp = self.offsets[n]
+        return self.flat[off:off + numel].view(shp)
+
+    def __contains__(self, n):
+        return n in self.offsets
+
+
+class State:
+    pass
+
+
+def _pname(i, tail):
+    return f"feature_extractor.conv_layers.{i}.{tail}"
+
+
+def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: bool, mask: bool,
+            features_only: bool, padding_mask: Optional[torch.Tensor], draws: Draws, rng_base: int,
+            tau: float) -> State:
+    """W: name -> bf16 contiguous device tensor (reference state_dict names).  source [B, L] bf16."""
+    st = State()
+    st.cfg, st.W, st.training, st.features_only = cfg, W, training, features_only
+    dev = source.device
+    B, L = source.shape
+    convs = cfg.conv_layers
+    if cfg.extractor_mode != "layer_norm":
+        raise W2vsError("extractor_mode='default' (GroupNorm on conv layer 0) is not built yet; wav2vec-S "
+                        "configs use 'layer_norm'")
+    if cfg.activation_dropout != 0.0 and training:
+        raise W2vsError("activation_dropout > 0 is not built (wav2vec-S configs use 0.0)")
+    if cfg.quantize_input or cfg.target_glu or cfg.negatives_from_everywhere or cfg.cross_sample_negatives \
+            or cfg.codebook_negatives or cfg.mask_channel_prob > 0:
+        raise W2vsError("quantize_input / target_glu / negatives_from_everywhere / cross_sample / codebook "
+                        "negatives / channel masks are not part of the wav2vec-S hot path and are not built")
+    p_in = cfg.dropout_input if training else 0.0
+    p_feat = cfg.dropout_features if training else 0.0
+    p_enc = cfg.dropout if training else 0.0
+    p_att = cfg.attention_dropout if training else 0.0
+    seed = lambda site: _site_seed(rng_base, site)  # noqa: E731
+    st.seed = seed
+    st.p = (p_in, p_feat, p_enc, p_att)
+
+    # ------------------------------------------------------------------ feature extractor (a1)
+    ln_num = cfg.layer_norm_num
+    st.conv = []
+    dim0, k0, s0 = convs[0]
+    y, mean, rstd = ops.conv0_fwd(source, W[_pname(0, "0.weight")], W[_pname(0, "2.1.weight")],
+                                  W[_pname(0, "2.1.bias")], k0, s0, conv_bias=W.get(_pname(0, "0.bias")))
+    st.source = source
+    st.conv.append(dict(y=y, mean=mean, rstd=rstd))
+    x = y
+    for i in range(1, len(convs)):
+        dim, k, s = convs[i]
+        w = W[_pname(i, "0.weight")]
+        w2 = ops.conv_pack_weight(w)
+        bias = W.get(_pname(i, "0.bias"))
+        rec = dict(x_in=x, k=k, s=s, ln=(i < ln_num))
+        if rec["ln"]:
+            c = ops.conv_cl_fwd(x, w2, k, s, bias, gelu=False, save_pre=False)
+            y, _, mean, rstd = ops.ln_fwd(c, W[_pname(i, "2.1.weight")], W[_pname(i, "2.1.bias")], gelu=True)
+            rec.update(c=c, mean=mean, rstd=rstd)
+        else:
+            y, pre = ops.conv_cl_fwd(x, w2, k, s, bias, gelu=True, save_pre=True)
+            rec.update(pre=pre)
+        st.conv.append(rec)
+        x = y
+    y_last = x                                   # [B, T, C0] post-GELU features
+    _, T, C0 = y_last.shape
+    st.B, st.T, st.C0 = B, T, C0
+
+    # ------------------------------------------------------------------ features_pen + LayerNorm (a3, a4)
+    st.pen_acc = torch.zeros(1, device=dev, dtype=torch.float32)
+    feats, _, st.f_mean, st.f_rstd = ops.ln_fwd(y_last, W["layer_norm.weight"], W["layer_norm.bias"], sumsq=st.pen_acc)
+    st.y_last, st.feats = y_last, feats
+
+    # padding mask -> frame resolution (wav2vec2.py:560-565)
+    pad_frames = None
+    if padding_mask is not None:
+        pm = padding_mask.bool().cpu()
+        extra = pm.size(1) % T
+        if extra > 0:
+            pm = pm[:, :-extra]
+        pad_frames = pm.view(pm.size(0), T, -1).all(-1)
+        if not bool(pad_frames.any()):
+            pad_frames = pad_frames  # keep: the reference still passes it on
+    st.pad_frames = pad_frames
+
+    # ------------------------------------------------------------------ post_extract_proj (a5)
+    E = cfg.encoder_embed_dim
+    if "post_extract_proj.weight" in W:
+        xproj = ops.linear_fwd(feats.view(B * T, C0), W["post_extract_proj.weight"], W["post_extract_proj.bias"]).view(B, T, E)
+    else:
+        xproj = feats
+    st.xproj = xproj
+
+    # ------------------------------------------------------------------ mask (a6) host draw
+    mask_np = None
+    if mask and cfg.mask_prob > 0:
+        if draws.mask_indices is not None:
+            mask_np = np.asarray(draws.mask_indices, dtype=bool)
+        else:
+            mask_np = host_rng.compute_mask_indices((B, T), pad_frames, cfg.mask_prob, cfg.mask_length,
+                                                    cfg.mask_selection, cfg.mask_other, min_masks=2,
+                                                    no_overlap=cfg.no_mask_overlap, min_space=cfg.mask_min_space)
+    st.mask_np = mask_np
+    mask_dev = torch.from_numpy(mask_np.astype(np.uint8)).to(dev) if mask_np is not None else None
+    st.mask_dev = mask_dev
+
+    # ------------------------------------------------------------------ encoder prologue (a7-a10)
+    mult = cfg.required_seq_len_multiple
+    Tp = T + ((-T) % mult)
+    m_ctx, r_ctx = draws.context if draws.context is not None else host_rng.sample_context(
+        cfg.context_type, cfg.main_context, cfg.right_context)
+    lay = host_rng.block_layout(Tp, m_ctx, r_ctx)
+    N = lay.N
+    st.Tp, st.N, st.lay, st.m, st.r = Tp, N, lay, m_ctx, r_ctx
+    pad_np = None
+    if pad_frames is not None or Tp != T:
+        pad_np = np.zeros((B, Tp), dtype=bool)
+        if pad_frames is not None:
+            pad_np[:, :T] = pad_frames.numpy()
+        if Tp != T:
+            if pad_frames is None:
+                pad_np[:, T:] = True       # wav2vec_S.py:378-380
+            else:
+                pad_np[:, T:] = True       # wav2vec_S.py:382-384 (value=True)
+    kpad_np = lay.key_padding(pad_np, B)
+    st.kpad = torch.from_numpy(kpad_np).to(dev) if kpad_np is not None else None
+    st.pad_dev = torch.from_numpy(pad_frames.numpy().astype(np.uint8)).to(dev) if pad_frames is not None else None
+    pos = host_rng.positions_from_padding(pad_frames, B, T).to(dev)
+    st.pos = pos
+    table = _pos_table(E, dev)
+    st.src = torch.from_numpy(lay.src).to(dev)
+    st.copy_start = torch.from_numpy(lay.copy_start).to(dev)
+    st.copy_list = torch.from_numpy(lay.copy_list).to(dev)
+    post_ln = not cfg.layer_norm_first
+    x0, st.p_mean, st.p_rstd = ops.enc_prologue_fwd(
+        xproj, mask_dev, st.pad_dev, pos, W["mask_emb"], table, W["encoder.layer_norm.weight"],
+        W["encoder.layer_norm.bias"], st.src, Tp, apply_ln=post_ln, p_in=p_in, seed_in=seed(1), p_enc=p_enc,
+        seed_enc=seed(2))
+
+    # ------------------------------------------------------------------ encoder layers (a11, a12)
+    keep = draws.layer_keep if draws.layer_keep is not None else host_rng.layerdrop_keep(
+        cfg.encoder_layers, cfg.encoder_layerdrop, training)
+    st.kept = [i for i in range(cfg.encoder_layers) if keep[i]]
+    H = cfg.encoder_attention_heads
+    R = B * N
+    st.layers = []
+    x = x0.view(R, E)
+    st.x0 = x
+    if post_ln:
+        for li in st.kept:
+            pre = f"encoder.layers.{li}."
+            rec = dict(li=li, x_in=x)
+            wqkv, bqkv = _qkv_pack(W, pre)
+            qkv = ops.linear_fwd(x, wqkv, bqkv)
+            ctx, lse = ops.attn_fwd(qkv.view(B, N, 3 * E), H, Tp, m_ctx, r_ctx, kpad=st.kpad, p_drop=p_att,
+                                    seed=seed(100 + 4 * li))
+            a = ops.linear_fwd(ctx.view(R, E), W[pre + "self_attn.out_proj.weight"], W[pre + "self_attn.out_proj.bias"])
+            x1, s1, mean1, rstd1 = ops.ln_fwd(a, W[pre + "self_attn_layer_norm.weight"], W[pre + "self_attn_layer_norm.bias"],
+                                              res=x, want_sum=True, p_drop=p_enc, seed=seed(101 + 4 * li))
+            h, hpre = ops.linear_fwd(x1, W[pre + "fc1.weight"], W[pre + "fc1.bias"], gelu=True, save_pre=True)
+            f = ops.linear_fwd(h, W[pre + "fc2.weight"], W[pre + "fc2.bias"])
+            x2, s2, mean2, rstd2 = ops.ln_fwd(f, W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
+                                              res=x1, want_sum=True, p_drop=p_enc, seed=seed(102 + 4 * li))
+            rec.update(qkv=qkv, ctx=ctx, lse=lse, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, h=h, hpre=hpre, s2=s2,
+                       mean2=mean2, rstd2=rstd2)
+            st.layers.append(rec)
+            x = x2
+        enc = x
+    else:
+        # pre-LN: stream s; every "residual add + next LayerNorm" pair is one fused kernel
+        s = x
+        names = [f"encoder.layers.{li}." for li in st.kept]
+        if st.kept:
+            n1, _, mean1, rstd1 = ops.ln_fwd(s, W[names[0] + "self_attn_layer_norm.weight"],
+                                             W[names[0] + "self_attn_layer_norm.bias"])
+        for j, li in enumerate(st.kept):
+            pre = names[j]
+            rec = dict(li=li, s_in=s, n1=n1, mean1=mean1, rstd1=rstd1)
+            wqkv, bqkv = _qkv_pack(W, pre)
+            qkv = ops.linear_fwd(n1, wqkv, bqkv)
+            ctx, lse = ops.attn_fwd(qkv.view(B, N, 3 * E), H, Tp, m_ctx, r_ctx, kpad=st.kpad, p_drop=p_att,
+                                    seed=seed(100 + 4 * li))
+            a = ops.linear_fwd(ctx.view(R, E), W[pre + "self_attn.out_proj.weight"], W[pre + "self_attn.out_proj.bias"])
+            n2, s_mid, mean2, rstd2 = ops.ln_fwd(a, W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
+                                                 res=s, want_sum=True, p_drop=p_enc, seed=seed(101 + 4 * li))
+            h, hpre = ops.linear_fwd(n2, W[pre + "fc1.weight"], W[pre + "fc1.bias"], gelu=True, save_pre=True)
+            f = ops.linear_fwd(h, W[pre + "fc2.weight"], W[pre + "fc2.bias"])
+            if j + 1 < len(st.kept):
+                nxt_w, nxt_b = W[names[j + 1] + "self_attn_layer_norm.weight"], W[names[j + 1] + "self_attn_layer_norm.bias"]
+            else:
+                nxt_w, nxt_b = W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"]
+            n1, s_out, mean1, rstd1 = ops.ln_fwd(f, nxt_w, nxt_b, res=s_mid, want_sum=True, p_drop=p_enc,
+                                                 seed=seed(102 + 4 * li))
+            rec.update(qkv=qkv, ctx=ctx, lse=lse, s_mid=s_mid, n2=n2, mean2=mean2, rstd2=rstd2, h=h, hpre=hpre,
+                       s_out=s_out, mean_o=mean1, rstd_o=rstd1)
+            st.layers.append(rec)
+            s = s_out
+        if st.kept:
+            enc = n1                      # encoder.layer_norm(stream), wav2vec2.py:831-832
+        else:
+            enc, _, st.fin_mean, st.fin_rstd = ops.ln_fwd(s, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"])
+    st.enc = enc                           # [B*N, E]
+
+    if features_only:
+        idx = (torch.arange(B, device=dev).view(B, 1) * N + torch.arange(T, device=dev).view(1, T)).reshape(-1).int()
+        st.out_idx = idx
+        st.out_x = ops.gather_rows(enc, idx, B * T).view(B, T, E)
+        return st
+
+    # ------------------------------------------------------------------ loss head (a14-a18)
+    if mask_np is None:
+        raise W2vsError("the pre-training head needs mask=True and mask_prob > 0")
+    if not cfg.quantize_targets:
+        raise W2vsError("quantize_targets=False is not built (wav2vec-S pre-training quantizes targets)")
+    bidx, tidx = np.nonzero(mask_np)
+    M = len(tidx) // B
+    st.M = M
+    frame_idx = torch.from_numpy((bidx * T + tidx).astype(np.int32)).to(dev)     # rows of [B*T, .]
+    token_idx = torch.from_numpy((bidx * N + tidx).astype(np.int32)).to(dev)     # rows of [B*N, .]
+    st.frame_idx, st.token_idx = frame_idx, token_idx
+    RM = B * M
+    y_in = ops.gather_rows(feats.view(B * T, C0), frame_idx, RM)
+    if p_feat > 0:
+        y_in = ops.dropout(y_in, p_feat, seed(3))
+    st.y_in = y_in
+    G, V = cfg.latent_groups, cfg.latent_vars
+    st.q_logits = ops.linear_fwd(y_in, W["quantizer.weight_proj.weight"], W["quantizer.weight_proj.bias"])
+    vars2d = W["quantizer.vars"].view(G * V, -1)
+    noise = draws.gumbel_noise
+    if noise is not None:
+        noise = noise.to(dev).float().contiguous()
+    st.noise = noise
+    st.tau = tau
+    q, st.qst = ops.quant_fwd(st.q_logits, vars2d, G, V, tau, training, noise=noise, seed=seed(4))
+    st.q = q
+    yq = ops.linear_fwd(q, W["project_q.weight"], W["project_q.bias"])
+    xm = ops.gather_rows(enc, token_idx, RM)
+    xf = ops.linear_fwd(xm, W["final_proj.weight"], W["final_proj.bias"])
+    st.yq, st.xm, st.xf = yq, xm, xf
+    K = cfg.num_negatives
+    neg = draws.neg_idx if draws.neg_idx is not None else host_rng.sample_negative_indices(B, M, K)
+    st.neg = neg.to(dev)
+    st.K = K
+    st.logits = ops.nce_fwd(xf, yq, st.neg, B, M, K, cfg.logit_temp)            # [B*M, K+1] rows (b, m)
+    return st
+
+
+_POS_TABLES = {}
+
+
+def _pos_table(E, dev):
+    key = (E, str(dev))
+    if key not in _POS_TABLES:
+        _POS_TABLES[key] = host_rng.sinusoidal_table(8000 + 1 + 1, E, 1).to(dev).contiguous()  # wav2vec_S.py:341-347
+    return _POS_TABLES[key]
+
+
+def _qkv_pack(W, pre):
+    w = torch.cat([W[pre + "self_attn.q_proj.weight"], W[pre + "self_attn.k_proj.weight"], W[pre + "self_attn.v_proj.weight"]], 0)
+    b = torch.cat([W[pre + "self_attn.q_proj.bias"], W[pre + "self_attn.k_proj.bias"], W[pre + "self_attn.v_proj.bias"]], 0)
+    return w, b
+
+
+# ==================================================================================================
+def grad_shapes(cfg, W) -> Dict[str, tuple]:
+    """Arena layout: q/k/v weights (and biases) of a layer are adjacent so the fused QKV GEMM
+    writes one [3E, E] block; conv weights are kept tap-major [Cout, k, Cin]."""
+    shapes = {}
+    order = []
+    for i in range(cfg.encoder_layers):
+        pre = f"encoder.layers.{i}."
+        order += [pre + f"self_attn.{n}_proj.weight" for n in "qkv"]
+        order += [pre + f"self_attn.{n}_proj.bias" for n in "qkv"]
+    seen = set(order)
+    order += [n for n in W if n not in seen]
+    for n in order:
+        if n not in W:
+            continue
+        shp = tuple(W[n].shape)
+        if n.startswith("feature_extractor.conv_layers.") and n.endswith(".0.weight"):
+            shp = (shp[0], shp[2], shp[1])
+        shapes[n] = shp
+    return shapes
+
+
+def _linear_bwd(dy, x, w_name, b_name, W, A, *, need_dx=True, dgelu_aux=None, add_aux=None):
+    ops.linear_wgrad(dy, x, A.view(w_name))
+    ops.colsum(dy, A.view(b_name))
+    if not need_dx:
+        return None
+    wt = ops.transpose2d(W[w_name])
+    return ops.linear_dgrad(dy, wt, dgelu_aux=dgelu_aux, add_aux=add_aux)
+
+
+def backward(st: State, A: Arena, *, d_logits=None, d_pen: float = 0.0, d_prob_ppl: float = 0.0, d_out=None):
+    """Accumulates parameter gradients into the arena.  d_logits fp32 [B*M, K+1] (rows (b, m));
+    d_pen = dLoss/d features_pen, d_prob_ppl = dLoss/d prob_perplexity (host floats); d_out bf16
+    [B, T, E] for features_only."""
+    cfg, W = st.cfg, st.W
+    B, T, C0, N, Tp = st.B, st.T, st.C0, st.N, st.Tp
+    E = cfg.encoder_embed_dim
+    H = cfg.encoder_attention_heads
+    dev = st.feats.device
+    p_in, p_feat, p_enc, p_att = st.p
+    seed = st.seed
+    R = B * N
+    d_enc = torch.zeros(R, E, device=dev, dtype=BF16)
+    d_feats_unmasked = None
+
+    if st.features_only:
+        ops.gather_rows(d_out.reshape(B * T, E).contiguous(), st.out_idx, B * T, scatter=True, out=d_enc)
+    else:
+        M, K = st.M, st.K
+        RM = B * M
+        dxf32, dyq32 = ops.nce_bwd(d_logits, st.xf, st.yq, st.neg, B, M, K, cfg.logit_temp)
+        dxf, dyq = ops.f32_to_bf16(dxf32), ops.f32_to_bf16(dyq32)
+        # final_proj
+        dxm = _linear_bwd(dxf, st.xm, "final_proj.weight", "final_proj.bias", W, A)
+        ops.gather_rows(dxm, st.token_idx, RM, scatter=True, out=d_enc)
+        # project_q
+        dq = _linear_bwd(dyq, st.q, "project_q.weight", "project_q.bias", W, A)
+        # quantizer
+        G, V = cfg.latent_groups, cfg.latent_vars
+        vars2d = W["quantizer.vars"].view(G * V, -1)
+        dql = ops.quant_bwd(dq, st.q_logits, vars2d, st.qst, G, V, st.tau, st.training, d_prob_ppl,
+                            A.view("quantizer.vars").view(G * V, -1), noise=st.noise, seed=seed(4))
+        d_yin = _linear_bwd(dql, st.y_in, "quantizer.weight_proj.weight", "quantizer.weight_proj.bias", W, A)
+        if p_feat > 0:
+            d_yin = ops.dropout(d_yin, p_feat, seed(3))
+        d_feats_unmasked = torch.zeros(B * T, C0, device=dev, dtype=BF16)
+        ops.gather_rows(d_yin, st.frame_idx, RM, scatter=True, out=d_feats_unmasked)
+
+    # ------------------------------------------------------------------ encoder layers, reversed
+    post_ln = not cfg.layer_norm_first
+    if post_ln:
+        dx = d_enc
+        for rec in reversed(st.layers):
+            li = rec["li"]
+            pre = f"encoder.layers.{li}."
+            d_f, d_x1a = ops.ln_bwd(rec["s2"], W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
+                                    rec["mean2"], rec["rstd2"], A.view(pre + "final_layer_norm.weight"),
+                                    A.view(pre + "final_layer_norm.bias"), dy=dx, want_dres=True, p_drop=p_enc,
+                                    seed=seed(102 + 4 * li))
+            d_hpre = _linear_bwd(d_f, rec["h"], pre + "fc2.weight", pre + "fc2.bias", W, A, dgelu_aux=rec["hpre"])
+            d_x1 = _linear_bwd(d_hpre, rec["x1"], pre + "fc1.weight", pre + "fc1.bias", W, A, add_aux=d_x1a)
+            d_a, d_xin_a = ops.ln_bwd(rec["s1"], W[pre + "self_attn_layer_norm.weight"], W[pre + "self_attn_layer_norm.bias"],
+                                      rec["mean1"], rec["rstd1"], A.view(pre + "self_attn_layer_norm.weight"),
+                                      A.view(pre + "self_attn_layer_norm.bias"), dy=d_x1, want_dres=True, p_drop=p_enc,
+                                      seed=seed(101 + 4 * li))
+            dx = _attn_block_bwd(st, rec, pre, d_a, rec["x_in"], d_xin_a, A)
+        d_x0 = dx
+    else:
+        d_s = None
+        d_n = d_enc                        # grad wrt encoder.layer_norm output
+        if not st.layers:
+            d_x0, _ = ops.ln_bwd(st.x0, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], st.fin_mean,
+                                 st.fin_rstd, A.view("encoder.layer_norm.weight"), A.view("encoder.layer_norm.bias"), dy=d_n)
+        names = [f"encoder.layers.{r['li']}." for r in st.layers]
+        for j in range(len(st.layers) - 1, -1, -1):
+            rec = st.layers[j]
+            li = rec["li"]
+            pre = names[j]
+            if j + 1 < len(st.layers):
+                gw, gb = names[j + 1] + "self_attn_layer_norm.weight", names[j + 1] + "self_attn_layer_norm.bias"
+            else:
+                gw, gb = "encoder.layer_norm.weight", "encoder.layer_norm.bias"
+            d_f, d_smid = ops.ln_bwd(rec["s_out"], W[gw], W[gb], rec["mean_o"], rec["rstd_o"], A.view(gw), A.view(gb),
+                                     dy=d_n, dsum=d_s, want_dres=True, p_drop=p_enc, seed=seed(102 + 4 * li))
+            d_hpre = _linear_bwd(d_f, rec["h"], pre + "fc2.weight", pre + "fc2.bias", W, A, dgelu_aux=rec["hpre"])
+            d_n2 = _linear_bwd(d_hpre, rec["n2"], pre + "fc1.weight", pre + "fc1.bias", W, A)
+            d_a, d_sin = ops.ln_bwd(rec["s_mid"], W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
+                                    rec["mean2"], rec["rstd2"], A.view(pre + "final_layer_norm.weight"),
+                                    A.view(pre + "final_layer_norm.bias"), dy=d_n2, dsum=d_smid, want_dres=True,
+                                    p_drop=p_enc, seed=seed(101 + 4 * li))
+            d_n = _attn_block_bwd(st, rec, pre, d_a, rec["n1"], None, A)
+            d_s = d_sin
+        if st.layers:
+            pre = names[0]
+            d_x0, _ = ops.ln_bwd(st.x0, W[pre + "self_attn_layer_norm.weight"], W[pre + "self_attn_layer_norm.bias"],
+                                 st.layers[0]["mean1"], st.layers[0]["rstd1"], A.view(pre + "self_attn_layer_norm.weight"),
+                                 A.view(pre + "self_attn_layer_norm.bias"), dy=d_n, dsum=d_s)
+
+    # ------------------------------------------------------------------ prologue
+    table = _pos_table(E, dev)
+    d_xproj = ops.enc_prologue_bwd(
+        d_x0.view(B, N, E), st.xproj, st.mask_dev, st.pad_dev, st.pos, W["mask_emb"], table,
+        W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], st.p_mean, st.p_rstd, st.src, st.copy_start,
+        st.copy_list, Tp, A.view("mask_emb"), A.view("encoder.layer_norm.weight"), A.view("encoder.layer_norm.bias"),
+        apply_ln=post_ln, p_in=p_in, seed_in=seed(1), p_enc=p_enc, seed_enc=seed(2))
+    if cfg.feature_grad_mult <= 0:
+        # extractor ran under no_grad in the reference (wav2vec2.py:550-552); the projection and
+        # the feature LayerNorm still train
+        pass
+    if "post_extract_proj.weight" in W:
+        d_feats = _linear_bwd(d_xproj.view(B * T, E), st.feats.view(B * T, C0), "post_extract_proj.weight",
+                              "post_extract_proj.bias", W, A, add_aux=d_feats_unmasked)
+    else:
+        d_feats = d_xproj.view(B * T, C0)
+        if d_feats_unmasked is not None:
+            raise W2vsError("conv dim == encoder dim with the pre-training head is not built")
+    # ------------------------------------------------------------------ feature LN + penalty + GradMultiply
+    convs = cfg.conv_layers
+    last = st.conv[-1]
+    numel = float(B * T * C0)
+    gm = cfg.feature_grad_mult
+    if gm <= 0:
+        ops.ln_bwd(st.y_last, W["layer_norm.weight"], W["layer_norm.bias"], st.f_mean, st.f_rstd,
+                   A.view("layer_norm.weight"), A.view("layer_norm.bias"), dy=d_feats, want_dx=False)
+        return
+    aux = last.get("pre") if (len(st.conv) > 1 and not last["ln"]) else None
+    d_cur, _ = ops.ln_bwd(st.y_last, W["layer_norm.weight"], W["layer_norm.bias"], st.f_mean, st.f_rstd,
+                          A.view("layer_norm.weight"), A.view("layer_norm.bias"), dy=d_feats, aux=aux, out_scale=gm,
+                          pen_coef=d_pen / numel)
+    # d_cur: grad wrt conv_i pre-activation (plain layers) or wrt conv_i's post-GELU output (LN layers / layer 0)
+    for i in range(len(convs) - 1, 0, -1):
+        rec = st.conv[i]
+        dim, k, s = convs[i]
+        if rec["ln"]:
+            d_c, _ = ops.ln_bwd(rec["c"], W[_pname(i, "2.1.weight")], W[_pname(i, "2.1.bias")], rec["mean"], rec["rstd"],
+                                A.view(_pname(i, "2.1.weight")), A.view(_pname(i, "2.1.bias")), dy=d_cur, gelu=True)
+        else:
+            d_c = d_cur
+        x_in = rec["x_in"]
+        ops.conv_cl_wgrad(d_c, x_in, k, s, A.view(_pname(i, "0.weight")).view(dim, -1))
+        if _pname(i, "0.bias") in A:
+            ops.colsum(d_c.view(-1, dim), A.view(_pname(i, "0.bias")))
+        prev = st.conv[i - 1]
+        prev_aux = prev.get("pre") if (i - 1 >= 1 and not prev["ln"]) else None
+        d_cur = ops.conv_cl_dgrad(d_c, W[_pname(i, "0.weight")], k, s, x_in.shape[1], dgelu_aux=prev_aux)
+    dim0, k0, s0 = convs[0]
+    r0 = st.conv[0]
+    ops.conv0_bwd(st.source, W[_pname(0, "0.weight")], W[_pname(0, "2.1.weight")], W[_pname(0, "2.1.bias")], r0["mean"],
+                  r0["rstd"], d_cur, k0, s0, A.view(_pname(0, "0.weight")).view(dim0, k0), A.view(_pname(0, "2.1.weight")),
+                  A.view(_pname(0, "2.1.bias")), conv_bias=W.get(_pname(0, "0.bias")),
+                  dconv_bias=A.view(_pname(0, "0.bias")) if _pname(0, "0.bias") in A else None)
+
+
+def _attn_block_bwd(st, rec, pre, d_a, x_in, add_to_dx, A):
+    """out_proj -> attention -> fused QKV projection, backward.  Returns grad wrt the block input."""
+    cfg, W = st.cfg, st.W
+    B, N, Tp = st.B, st.N, st.Tp
+    E, H = cfg.encoder_embed_dim, cfg.encoder_attention_heads
+    R = B * N
+    li = rec["li"]
+    d_ctx = _linear_bwd(d_a, rec["ctx"].view(R, E), pre + "self_attn.out_proj.weight", pre + "self_attn.out_proj.bias", W, A)
+    dqkv = ops.attn_bwd(d_ctx.view(B, N, E), rec["qkv"].view(B, N, 3 * E), rec["ctx"], rec["lse"], H, Tp, st.m, st.r,
+                        kpad=st.kpad, p_drop=st.p[3], seed=st.seed(100 + 4 * li)).view(R, 3 * E)
+    # fused [3E, E] weight block: q, k, v views are adjacent in the arena
+    off_w = A.offsets[pre + "self_attn.q_proj.weight"][0]
+    off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
+    dW = A.flat[off_w:off_w + 3 * E * E].view(3 * E, E)
+    db = A.flat[off_b:off_b + 3 * E]
+    ops.linear_wgrad(dqkv, x_in, dW)
+    ops.colsum(dqkv, db)
+    wqkv, _ = _qkv_pack(W, pre)
+    wt = ops.transpose2d(wqkv)
+    return ops.linear_dgrad(dqkv, wt, add_aux=add_to_dx)

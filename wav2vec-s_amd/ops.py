@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_NONE, AttnDesc,
+from ._lib import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_NONE, AttnDesc,
                    EncPrologueDesc, GemmDesc, LnBwdDesc, LnFwdDesc, NceDesc, QuantDesc, W2vsError)
 
 BF16 = torch.bfloat16
@@ -73,14 +73,18 @@ def linear_fwd(x, w, bias=None, *, gelu=False, save_pre=False):
     return (y, pre) if save_pre else y
 
 
-def linear_dgrad(dy, w_t, *, dgelu_aux=None):
-    """dx = dy @ w  given w_t = w.T contiguous ([K, N]).  Optionally dx *= gelu'(aux)."""
-    _chk(dy, BF16, "dy"); _chk(w_t, BF16, "w_t")
+def linear_dgrad(dy, w_t, *, dgelu_aux=None, add_aux=None):
+    """dx = dy @ w  given w_t = w.T contiguous ([K, N]).  Optionally dx *= gelu'(aux) or dx += add_aux."""
+    _chk(dy, BF16, "dy"); _chk(w_t, BF16, "w_t"); _chk(dgelu_aux, BF16, "aux"); _chk(add_aux, BF16, "aux")
     R, N = dy.shape
     K = w_t.shape[0]
     dx = torch.empty(R, K, device=dy.device, dtype=BF16)
-    gemm_nt(dy, w_t, M=R, N=K, K=N, lda=N, ldb=N, ldc=K, out=dx, aux=dgelu_aux,
-            epi=EPI_DGELU if dgelu_aux is not None else EPI_NONE)
+    epi, aux = EPI_NONE, None
+    if dgelu_aux is not None:
+        epi, aux = EPI_DGELU, dgelu_aux
+    elif add_aux is not None:
+        epi, aux = EPI_ADD, add_aux
+    gemm_nt(dy, w_t, M=R, N=K, K=N, lda=N, ldb=N, ldc=K, out=dx, aux=aux, epi=epi)
     return dx
 
 
@@ -406,6 +410,13 @@ def ce_rows(logits, want_grad=True):
     dl = torch.empty_like(logits) if want_grad else None
     _lib.call("w2vs_ce_rows", _p(logits), R, W, _p(out3), _p(dl), _stream())
     return out3, dl
+
+
+def dropout(x, p, seed):
+    _chk(x, BF16, "x")
+    out = torch.empty_like(x)
+    _lib.call("w2vs_dropout", _p(x), _p(out), x.numel(), p, seed, _stream())
+    return out
 
 
 def gather_rows(src, idx, R, scatter=False, out=None):
