@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: wav2vec-S base pre-training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch: conv feature extractor ->
+block-causal encoder -> Gumbel quantizer -> InfoNCE + diversity + feature-penalty loss ->
+backward of all of it (+ gradient all-reduce over RCCL when N > 1) + fused Adam update.
+Workload = BASELINE.json configs[1]: base model (12 x 768), bf16, batch 8 x 175 000 samples
+(1.4 M samples = 87.5 audio-seconds) per GPU, yaml dropouts / LayerDrop / sampled contexts on.
+Weak scaling: every rank gets its own batch.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+B_PER_GPU, L_SAMPLES, SR = 8, 175000, 16000
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(threads):
+    """The oracle (a CPU port of the reference algorithm, fp32) timed on the host cores over a bounded
+    sample of the same workload: base model, 2 x 80 000 samples (10 audio-seconds), fwd+loss+bwd."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import w2vs_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.OracleCfg()
+    P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
+    Bc, Lc = 2, 80000
+    g = torch.Generator().manual_seed(1234)
+    src = torch.randn(Bc, Lc, generator=g)
+    T = O.conv_out_lengths(Lc, cfg.conv_layers)[-1]
+    np.random.seed(1234)
+    mask = torch.from_numpy(O.compute_mask_indices((Bc, T), None, 0.65, 10, "static", 0, min_masks=2))
+    M = int(mask[0].sum())
+    torch.manual_seed(1234)
+    neg = O.sample_negative_indices(Bc, M, 100)
+    noise = -torch.empty(Bc * M * 2, 320).exponential_().log()
+    times = []
+    for it in range(3):
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        out = O.forward_loss(P, src, cfg, mask_indices=mask, neg_idx=neg, main_context=16, right_context=8, tau=2.0,
+                             gumbel_noise=noise)
+        out["loss"].backward()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(Bc * Lc / SR / t, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": "oracle fp32, base model, 2 x 80000 samples, fwd+loss+bwd, median of 2 after 1 warm-up, %.2f s/step" % t}
+
+
+def gemm_flops_per_step(cfg, B, T, N, M):
+    """Algorithmic FLOPs of every gemm_nt/gemm_tn launch of one step (fwd + dgrad + wgrad), SURVEY.md 8d."""
+    E, F, C0 = cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, 512
+    R = B * N
+    lin = lambda rows, k, n: 2.0 * rows * k * n  # noqa: E731
+    per_layer = lin(R, E, 3 * E) + lin(R, E, E) + 2 * lin(R, E, F)
+    return per_layer
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--samples", type=int, default=L_SAMPLES)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import wav2vec_s_amd as w
+    from wav2vec_s_amd import ops, trainer
+    cfg = w.base_librispeech_config()
+    torch.manual_seed(1)                       # identical replicas on every rank
+    model = w.Wav2VecSModel(cfg).to(torch.bfloat16).to(dev).train()
+    crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0], log_keys=["prob_perplexity", "code_perplexity", "temp"])
+    step_fn = trainer.TrainStep(model, crit, world_size=world, use_optimizer=not args.no_optimizer,
+                                lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+    B, L = args.batch, args.samples
+    g = torch.Generator().manual_seed(1234 + rank)
+    source = torch.randn(B, L, generator=g).to(torch.bfloat16).to(dev)
+    np.random.seed(1234 + rank)
+    random.seed(1234)
+    torch.manual_seed(1234 + rank)
+    torch.cuda.manual_seed(1234 + rank)
+    sample = {"net_input": {"source": source}}
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.set_num_updates(i)
+        step_fn(sample)
+    barrier()
+    ops.GEMM_TIMER.enable()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.set_num_updates(args.warmup + i)
+        loss_t = step_fn(sample)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_TIMER.disable()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    audio_s = B * L / SR
+    value = world * audio_s * args.steps / elapsed
+    roof = ops.GEMM_TIMER.report(PEAK_BF16_TFLOPS)
+    st = model._last_state
+    out = {
+        "metric": "audio-seconds/s/GPU, wav2vec-S base pretrain step, 1/2/4/8 MI355X",
+        "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "wav2vec-S base (12L d768, 90.3M params) pretrain step: fwd + InfoNCE/diversity/penalty loss + "
+                               "bwd%s%s; %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, LayerDrop 0.05, sampled "
+                               "block contexts; random-init weights" % (
+                                   " + RCCL grad all-reduce" if world > 1 else "",
+                                   "" if args.no_optimizer else " + fused Adam", B, L, audio_s),
+                   "global_batch_samples": world * B * L, "per_gpu_audio_s_per_s": round(value / world, 2),
+                   "last_loss_per_sample": round(float(loss_t) / max(1, st.B * st.M), 4),
+                   "tokens_last_step": {"T": st.T, "N": st.N, "M": st.M, "m": st.m, "r": st.r}},
+        "roofline": roof,
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, 16)
+        out["cpu_baseline"] = cpu_baseline(threads)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,14 @@ int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* s
 /* out[i] = in[i] * keep(seed, i) / (1 - p) : nn.Dropout (dropout_features, wav2vec2.py:571);
  * the backward is the same call on the gradient with the same seed. */
 int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* stream);
+/* Fused Adam on flat arrays: fairseq Adam (fs/optim/adam.py:205-229: decoupled weight decay,
+ * bias-corrected step) + fp32 master / bf16 working copy (fs/optim/fp16_optimizer.py:205-218).
+ * g = fp32 gradient arena; effective gradient = g * scale_host * (scale_dev ? *scale_dev : 1).  */
+int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, const float* scale_dev, float scale_host,
+                   void* stream);
+/* out[0] += sum x^2 : gradient norm (fs/utils.py:341-386) */
+int w2vs_sumsq(const float* x, int64_t n, float* out, void* stream);
 /* out[n] += sum_m in[m, n] : bias gradients */
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* stream);
 

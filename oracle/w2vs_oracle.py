@@ -305,11 +305,15 @@ def blockwise_encoder(x, P, cfg: OracleCfg, main_context: int, right_context: in
     return x
 
 
-def gumbel_quantize(y, P, cfg: OracleCfg, tau: float, noise: Optional[torch.Tensor]):
+def gumbel_quantize(y, P, cfg: OracleCfg, tau: float, noise: Optional[torch.Tensor],
+                    force_idx: Optional[torch.Tensor] = None):
     """GumbelVectorQuantizer.forward, fs/modules/gumbel_vector_quantizer.py:141-202.
     y: B x M x 512.  ``noise`` None = eval (hard one-hot of the argmax); otherwise the
     Gumbel sample g (shape (B*M*G, V)) that F.gumbel_softmax would have drawn:
-    y_soft = softmax((logits+g)/tau); out = onehot(argmax y_soft) - y_soft.detach() + y_soft."""
+    y_soft = softmax((logits+g)/tau); out = onehot(argmax y_soft) - y_soft.detach() + y_soft.
+    ``force_idx`` (B*M, G) overrides the argmax SELECTION only (test aid: a bf16 implementation can
+    flip a near-tied argmax; with the selection pinned the remaining fp math is comparable); the
+    returned idx is still the natural fp32 argmax."""
     B, M, Fd = y.shape
     G, V = cfg.latent_groups, cfg.latent_vars
     logits = F.linear(y.reshape(-1, Fd), P["quantizer.weight_proj.weight"],
@@ -323,11 +327,13 @@ def gumbel_quantize(y, P, cfg: OracleCfg, tau: float, noise: Optional[torch.Tens
     if noise is not None:
         soft = torch.softmax((logits.float() + noise) / tau, dim=-1)
         idx = soft.argmax(-1)
-        onehot = torch.zeros_like(soft).scatter_(-1, idx.view(-1, 1), 1.0)
+        use = idx if force_idx is None else force_idx.reshape(-1).long()
+        onehot = torch.zeros_like(soft).scatter_(-1, use.view(-1, 1), 1.0)
         sel = onehot - soft.detach() + soft
     else:
         idx = k
-        sel = hard.view(B * M * G, V)
+        use = idx if force_idx is None else force_idx.reshape(-1).long()
+        sel = torch.zeros_like(logits).scatter_(-1, use.view(-1, 1), 1.0)
     vars_ = P["quantizer.vars"]  # 1 x (G*V) x D
     D = vars_.shape[-1]
     q = (sel.view(B * M, G * V, 1) * vars_).view(B * M, G, V, D).sum(-2).view(B, M, G * D)
@@ -373,7 +379,8 @@ def criterion(logits, prob_ppl, features_pen, num_vars: int, cfg: OracleCfg):
 def forward_loss(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCfg, *,
                  mask_indices: torch.Tensor, neg_idx: torch.Tensor, main_context: int,
                  right_context: int, tau: float = 2.0, gumbel_noise: Optional[torch.Tensor] = None,
-                 layer_keep: Optional[List[bool]] = None, collect: Optional[dict] = None):
+                 layer_keep: Optional[List[bool]] = None, collect: Optional[dict] = None,
+                 force_code_idx: Optional[torch.Tensor] = None):
     """Wav2Vec2Model.forward (fs/models/wav2vec/wav2vec2.py:544-658) + criterion, with
     every host-RNG draw INJECTED (mask_indices B x T bool, neg_idx, context sizes,
     gumbel noise, LayerDrop keeps) and all dropouts off, so that two implementations
@@ -398,7 +405,7 @@ def forward_loss(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCf
     if collect is not None:
         collect.update(features=feats, x_masked=x, y_in=y)
     x = blockwise_encoder(x, P, cfg, main_context, right_context, None, layer_keep, collect)
-    q, idx, prob_ppl, code_ppl = gumbel_quantize(y, P, cfg, tau, gumbel_noise)
+    q, idx, prob_ppl, code_ppl = gumbel_quantize(y, P, cfg, tau, gumbel_noise, force_code_idx)
     yq = F.linear(q, P["project_q.weight"], P["project_q.bias"])
     xm = x[mask_indices].view(B, -1, C)
     xf = F.linear(xm, P["final_proj.weight"], P["final_proj.bias"])

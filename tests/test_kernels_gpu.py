@@ -99,14 +99,14 @@ def test_conv_channel_last(ops, k, s, Lin):
     Lout = ref_pre.shape[-1]
     dy = rnd(B, Lout, Cout, seed=3)
     ref_pre.backward(dy.float().transpose(1, 2))
-    dx = ops.conv_cl_dgrad(dev(dy), dev(w), k, s, Lin)
+    dx = ops.conv_cl_dgrad(dev(dy), w2, k, s, Lin)
     assert rel(dx, xr.grad.transpose(1, 2)) < 5e-3
     dw2 = torch.zeros(Cout, k * Cin, device="cuda")
     ops.conv_cl_wgrad(dev(dy), dev(x), k, s, dw2)
     assert rel(dw2, wr.grad.permute(0, 2, 1).reshape(Cout, k * Cin)) < 3e-3
     # dgrad chained through the previous layer's GELU
     aux = rnd(B, Lin, Cin, seed=4)
-    dx2 = ops.conv_cl_dgrad(dev(dy), dev(w), k, s, Lin, dgelu_aux=dev(aux))
+    dx2 = ops.conv_cl_dgrad(dev(dy), w2, k, s, Lin, dgelu_aux=dev(aux))
     a = aux.float().requires_grad_(True)
     F.gelu(a).backward(dx.float().cpu())
     assert rel(dx2, a.grad) < 6e-3
@@ -450,3 +450,30 @@ def test_rejects_bad_arguments(ops):
     with pytest.raises(W2vsError):
         ops.ln_fwd(torch.zeros(4, 2048, dtype=BF, device="cuda"), torch.zeros(2048, dtype=BF, device="cuda"),
                    torch.zeros(2048, dtype=BF, device="cuda"))
+
+
+def test_fused_adam_matches_fairseq_formula(ops):
+    """fs/optim/adam.py:205-229 on an fp32 master with a bf16 working copy."""
+    n = 4096 * 3
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g) * 3
+    lr, b1, b2, eps, wd, scale = 5e-4, 0.9, 0.98, 1e-6, 0.01, 0.25
+    p32, m, v = p.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    p16 = torch.zeros(n, dtype=BF).cuda()
+    pr, mr, vr = p.clone(), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        ops.adam_step(p32, p16, m, v, grad.cuda(), lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=step,
+                      scale_host=scale)
+        gs = grad * scale
+        mr.mul_(b1).add_(gs, alpha=1 - b1)
+        vr.mul_(b2).addcmul_(gs, gs, value=1 - b2)
+        denom = vr.sqrt().add_(eps)
+        step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        pr.add_(pr, alpha=-wd * lr)
+        pr.addcdiv_(mr, denom, value=-step_size)
+    assert float((p32.cpu() - pr).abs().max()) < 1e-6
+    assert torch.equal(p16.cpu(), pr.to(BF)) or rel(p16, pr) < 4e-3
+    out = torch.zeros(1, device="cuda")
+    ops.sumsq(grad.cuda(), out)
+    assert abs(float(out) - float((grad ** 2).sum())) / float((grad ** 2).sum()) < 1e-5

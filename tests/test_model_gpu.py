@@ -62,16 +62,20 @@ BASE = dict(quantize_targets=True, extractor_mode="layer_norm", final_dim=256, e
 def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
     w, model, P, ocfg, source, draws, mask, neg, noise = _setup(cfg_kw, B, L, seed, m_ctx, r_ctx)
     ocfg.loss_weights = tuple(loss_weights)
-    col = {}
-    ref = O.forward_loss(P, source.float(), ocfg, mask_indices=torch.from_numpy(mask), neg_idx=neg, main_context=m_ctx,
-                         right_context=r_ctx, tau=2.0, gumbel_noise=noise, collect=col)
-    ref["loss"].backward()
     model = model.cuda().train()
     model.inject_draws(draws)
     crit = w.Wav2vecCriterion(infonce=True, loss_weights=list(loss_weights), log_keys=["prob_perplexity", "code_perplexity", "temp"])
     loss, sample_size, log = crit(model, {"net_input": {"source": source.cuda()}})
     loss.backward()
     st = model._last_state
+    # The code SELECTION is an argmax over bf16 logits on the HIP side: a near-tie can flip it.  The
+    # oracle reports its own (fp32) argmax in q_idx, and is run with the HIP selection pinned so that
+    # everything downstream of the discrete choice is comparable.
+    col = {}
+    ref = O.forward_loss(P, source.float(), ocfg, mask_indices=torch.from_numpy(mask), neg_idx=neg, main_context=m_ctx,
+                         right_context=r_ctx, tau=2.0, gumbel_noise=noise, collect=col,
+                         force_code_idx=st.qst.idx.cpu())
+    ref["loss"].backward()
     rep = {"tag": tag, "loss_hip": float(loss), "loss_ref": float(ref["loss"]), "sample_size": sample_size}
     rep["loss_rel"] = abs(rep["loss_hip"] - rep["loss_ref"]) / abs(rep["loss_ref"])
     B_, T, N = st.B, st.T, st.N
@@ -196,3 +200,31 @@ def test_features_only_and_padding_mask():
     assert torch.equal(pad.cpu(), pmf)
     valid = ~pmf
     assert rel(x.cpu()[valid], ref[valid]) < 2e-2
+
+
+def test_train_step_flat_storage_learns_and_keeps_checkpoint_layout():
+    """trainer.TrainStep: flat parameter storage + fused Adam; loss must fall on a fixed batch and
+    state_dict must keep the reference's conv weight layout."""
+    import wav2vec_s_amd as w
+    from wav2vec_s_amd import trainer
+    kw = dict(BASE, encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,
+              final_dim=128, latent_vars=40, num_negatives=20,
+              conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
+    cfg = w.Wav2VecSConfig(**kw)
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    model = w.Wav2VecSModel(cfg).to(BF).cuda().train()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0])
+    step = trainer.TrainStep(model, crit, lr=2e-3)
+    sd = model.state_dict()
+    for k in before:
+        assert sd[k].shape == before[k].shape and torch.equal(sd[k].cpu(), before[k].cpu()), k
+    src = torch.randn(2, 16000).to(BF).cuda()
+    losses = []
+    for i in range(12):
+        np.random.seed(1); torch.manual_seed(1)      # same mask / negatives every step
+        losses.append(float(step({"net_input": {"source": src}})))
+    assert losses[-1] < losses[0] * 0.97, losses
+    assert all(np.isfinite(losses))
+    changed = sum(int(not torch.equal(model.state_dict()[k].cpu(), before[k].cpu())) for k in before if "pos_conv" not in k)
+    assert changed >= len(before) - 8

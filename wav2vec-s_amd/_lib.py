@@ -86,6 +86,8 @@ _SIGS = {
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],
     "w2vs_colsum": [vp, vp, i64, i32, i64, vp],
     "w2vs_dropout": [vp, vp, i64, f32, u64, vp],
+    "w2vs_adam_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp],
+    "w2vs_sumsq": [vp, i64, vp, vp],
 }
 EXPORTS = ["w2vs_abi_version", "w2vs_last_error", "w2vs_sizeof"] + list(_SIGS)
 

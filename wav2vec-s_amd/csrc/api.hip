@@ -60,5 +60,10 @@ int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, 
 int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* s) { return transpose2d(in, out, R, C, batch, ST(s)); }
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* s) { return f32_to_bf16(in, out, n, scale, ST(s)); }
 int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* s) { return dropout(in, out, n, p, seed, ST(s)); }
+int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
+                   float wd, int32_t step, const float* scale_dev, float scale_host, void* s) {
+  return adam_step(p32, p16, m, v, g, n, lr, b1, b2, eps, wd, step, scale_dev, scale_host, ST(s));
+}
+int w2vs_sumsq(const float* x, int64_t n, float* out, void* s) { return sumsq(x, n, out, ST(s)); }
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* s) { return colsum(in, out, M, N, ld, ST(s)); }
 }

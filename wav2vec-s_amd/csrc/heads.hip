@@ -482,6 +482,53 @@ int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream
   return hip_check(hipGetLastError(), "dropout");
 }
 
+// Fused Adam over flat arrays (fs/optim/adam.py:205-229: decoupled weight decay, bias-corrected
+// step size) with the fp32 master / bf16 working copy split of fs/optim/fp16_optimizer.py:205-218.
+// g is the fp32 gradient arena; grad_scale folds the 1/sample_size (and clip) factor in.
+__global__ void adam_kernel(float* p32, bf16* p16, float* m, float* v, const float* g, long n, float lr_wd, float step_size,
+                            float b1, float b2, float eps, const float* scale_dev, float scale_host) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float gs = scale_dev ? scale_host * scale_dev[0] : scale_host;
+  f32x4 pv = *(f32x4*)(p32 + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i), gv = *(const f32x4*)(g + i);
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float gr = gv[e] * gs;
+    mv[e] = b1 * mv[e] + (1.f - b1) * gr;
+    vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+    float pe = pv[e] - lr_wd * pv[e];
+    pe -= step_size * mv[e] / (sqrtf(vv[e]) + eps);
+    pv[e] = pe;
+    o[e] = f2bf(pe);
+  }
+  *(f32x4*)(p32 + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+  *(bf16x4*)(p16 + i) = o;
+}
+int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n, float lr, float b1, float b2, float eps,
+              float wd, int step, const float* scale_dev, float scale_host, hipStream_t st) {
+  if (!p32 || !p16 || !m || !v || !g || n <= 0 || (n % 4)) return set_error("adam_step: bad arguments (n must be a multiple of 4)");
+  if (step < 1) return set_error("adam_step: step counts from 1");
+  double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  float step_size = (float)(lr * sqrt(bc2) / bc1);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, p32, (bf16*)p16, m, v, g, n,
+                     wd * lr, step_size, b1, b2, eps, scale_dev, scale_host);
+  return hip_check(hipGetLastError(), "adam_step");
+}
+
+// out[0] += sum x^2 (fp32): gradient norm for clip_grad_norm_ (fs/utils.py:341-386)
+__global__ void sumsq_kernel(const float* x, long n, float* out) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+int sumsq(const float* x, long n, float* out, hipStream_t st) {
+  if (!x || !out || n <= 0) return set_error("sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, st, x, n, out);
+  return hip_check(hipGetLastError(), "sumsq");
+}
+
 // out[n] += sum_m in[m][n]  (bf16 in, fp32 atomics out): bias gradients
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* in, float* out, long M, int N, long ld, int rows_per_block) {
   __shared__ float red[8][33][8];

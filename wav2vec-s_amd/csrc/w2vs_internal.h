@@ -40,6 +40,9 @@ int gather_rows(const void* src, const int* idx, void* dst, long R, int C, int s
 int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t st);
 int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st);
 int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream_t st);
+int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n, float lr, float b1, float b2, float eps,
+              float wd, int step, const float* scale_dev, float scale_host, hipStream_t st);
+int sumsq(const float* x, long n, float* out, hipStream_t st);
 int colsum(const void* in, float* out, long M, int N, long ld, hipStream_t st);
 
 }  // namespace w2vs

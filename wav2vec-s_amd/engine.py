@@ -43,14 +43,15 @@ class Draws:
 class Arena:
     """Flat fp32 gradient arena with named views."""
 
-    def __init__(self, shapes: Dict[str, tuple], device):
+    def __init__(self, shapes: Dict[str, tuple], device, flat: Optional[torch.Tensor] = None):
         self.offsets = {}
         off = 0
         for n, shp in shapes.items():
             numel = int(np.prod(shp))
             self.offsets[n] = (off, numel, shp)
             off += (numel + 3) // 4 * 4  # keep 16-B alignment of every view
-        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.numel = off
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32) if flat is None else flat
 
     def view(self, n):
         off, numel, shp = self.offsets[n]
@@ -70,9 +71,12 @@ def _pname(i, tail):
 
 def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: bool, mask: bool,
             features_only: bool, padding_mask: Optional[torch.Tensor], draws: Draws, rng_base: int,
-            tau: float) -> State:
-    """W: name -> bf16 contiguous device tensor (reference state_dict names).  source [B, L] bf16."""
+            tau: float, packed: Optional[Dict[str, torch.Tensor]] = None) -> State:
+    """W: name -> bf16 contiguous device tensor (reference state_dict names).  source [B, L] bf16.
+    packed: conv weights already tap-major [Cout, k*Cin] (flat parameter storage), else packed here."""
     st = State()
+    packed = packed or {}
+    st.packed = {}
     st.cfg, st.W, st.training, st.features_only = cfg, W, training, features_only
     dev = source.device
     B, L = source.shape
@@ -98,15 +102,21 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     ln_num = cfg.layer_norm_num
     st.conv = []
     dim0, k0, s0 = convs[0]
-    y, mean, rstd = ops.conv0_fwd(source, W[_pname(0, "0.weight")], W[_pname(0, "2.1.weight")],
+    w0 = packed.get(_pname(0, "0.weight"))
+    if w0 is None:
+        w0 = W[_pname(0, "0.weight")]
+    st.packed[0] = w0                      # Cin == 1: [C, 1, k] and [C, k*1] are the same bytes
+    y, mean, rstd = ops.conv0_fwd(source, w0, W[_pname(0, "2.1.weight")],
                                   W[_pname(0, "2.1.bias")], k0, s0, conv_bias=W.get(_pname(0, "0.bias")))
     st.source = source
     st.conv.append(dict(y=y, mean=mean, rstd=rstd))
     x = y
     for i in range(1, len(convs)):
         dim, k, s = convs[i]
-        w = W[_pname(i, "0.weight")]
-        w2 = ops.conv_pack_weight(w)
+        w2 = packed.get(_pname(i, "0.weight"))
+        if w2 is None:
+            w2 = ops.conv_pack_weight(W[_pname(i, "0.weight")])
+        st.packed[i] = w2
         bias = W.get(_pname(i, "0.bias"))
         rec = dict(x_in=x, k=k, s=s, ln=(i < ln_num))
         if rec["ln"]:
@@ -482,10 +492,10 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen: float = 0.0, d_prob_p
             ops.colsum(d_c.view(-1, dim), A.view(_pname(i, "0.bias")))
         prev = st.conv[i - 1]
         prev_aux = prev.get("pre") if (i - 1 >= 1 and not prev["ln"]) else None
-        d_cur = ops.conv_cl_dgrad(d_c, W[_pname(i, "0.weight")], k, s, x_in.shape[1], dgelu_aux=prev_aux)
+        d_cur = ops.conv_cl_dgrad(d_c, st.packed[i], k, s, x_in.shape[1], dgelu_aux=prev_aux)
     dim0, k0, s0 = convs[0]
     r0 = st.conv[0]
-    ops.conv0_bwd(st.source, W[_pname(0, "0.weight")], W[_pname(0, "2.1.weight")], W[_pname(0, "2.1.bias")], r0["mean"],
+    ops.conv0_bwd(st.source, st.packed[0], W[_pname(0, "2.1.weight")], W[_pname(0, "2.1.bias")], r0["mean"],
                   r0["rstd"], d_cur, k0, s0, A.view(_pname(0, "0.weight")).view(dim0, k0), A.view(_pname(0, "2.1.weight")),
                   A.view(_pname(0, "2.1.bias")), conv_bias=W.get(_pname(0, "0.bias")),
                   dconv_bias=A.view(_pname(0, "0.bias")) if _pname(0, "0.bias") in A else None)

@@ -186,11 +186,15 @@ class _HotPath(torch.autograd.Function):
         cfg = model.cfg
         names = model._param_names
         W = {}
+        packed = model._flat.packed if model._flat is not None else None
         for n, p in zip(names, params):
             t = p.detach()
             if t.dtype != BF16:
                 t = t.to(BF16)
-            W[n] = t.contiguous()
+            if packed is not None and n in packed:
+                W[n] = t                    # tap-major storage; the engine reads packed[n]
+            else:
+                W[n] = t.contiguous()
         src = source.detach()
         if src.dtype != BF16:
             src = src.to(BF16)
@@ -199,7 +203,8 @@ class _HotPath(torch.autograd.Function):
         base = (torch.cuda.initial_seed() * 0x9E3779B97F4A7C15 + model._rng_counter * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
         st = engine.forward(cfg, W, src, training=model.training, mask=mask, features_only=features_only,
                             padding_mask=padding_mask, draws=draws, rng_base=base,
-                            tau=float(model.quantizer.curr_temp) if model.quantizer is not None else 1.0)
+                            tau=float(model.quantizer.curr_temp) if model.quantizer is not None else 1.0,
+                            packed=packed)
         ctx.st = st
         ctx.model = model
         ctx.param_dtypes = [p.dtype for p in params]
@@ -217,7 +222,11 @@ class _HotPath(torch.autograd.Function):
     def backward(ctx, *grads):
         st, model = ctx.st, ctx.model
         names = model._param_names
-        A = engine.Arena(engine.grad_shapes(st.cfg, st.W), st.feats.device)
+        flat_mode = model._flat is not None
+        if flat_mode:
+            A = model._flat.arena            # persistent fp32 arena the optimizer / all-reduce work on
+        else:
+            A = engine.Arena(engine.grad_shapes(st.cfg, st.W), st.feats.device)
         if st.features_only:
             engine.backward(st, A, d_out=grads[0].to(BF16).contiguous())
         else:
@@ -225,6 +234,9 @@ class _HotPath(torch.autograd.Function):
             d_logits = torch.zeros_like(st.logits) if d_logits is None else d_logits.float().contiguous()
             engine.backward(st, A, d_logits=d_logits, d_pen=0.0 if d_pen is None else float(d_pen),
                             d_prob_ppl=0.0 if d_ppl is None else float(d_ppl))
+        if flat_mode:
+            ctx.st = None
+            return (None,) * (6 + len(names))   # gradients stay in the arena (see trainer.FlatParams)
         flat16 = ops.f32_to_bf16(A.flat)
         dropped = set(range(st.cfg.encoder_layers)) - set(st.kept)
         out = []
@@ -286,6 +298,7 @@ class Wav2Vec2Model(nn.Module):
         self.layer_norm = nn.LayerNorm(self.embed)
         self.final_proj = nn.Linear(cfg.encoder_embed_dim, final_dim)
         self._rng_counter = 0
+        self._flat = None                    # trainer.FlatParams when flat storage is active
         self._last_state = None
         self._draws = None
         self.load_pretrained_model(cfg)

@@ -37,6 +37,59 @@ def _chk(t, dtype=None, name="tensor"):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+class _GemmTimer:
+    """HIP-event timing of gemm_nt launches on the stream they are launched on (bench.py roofline).
+    Every ``stride``-th launch is bracketed by a pair of events; durations are read after the timed
+    region, grouped per epilogue instantiation."""
+
+    def __init__(self, stride=4):
+        self.stride, self.on, self.count, self.samples = stride, False, 0, []
+
+    def enable(self):
+        self.on, self.count, self.samples = True, 0, []
+
+    def disable(self):
+        self.on = False
+
+    def begin(self):
+        self.count += 1
+        if not self.on or self.count % self.stride:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, e0, epi, flops):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.samples.append((e0, e1, epi, flops))
+
+    def report(self, peak_tflops):
+        torch.cuda.synchronize()
+        groups = {}
+        for e0, e1, epi, flops in self.samples:
+            g = groups.setdefault(epi, [0.0, 0.0, 0])
+            g[0] += e0.elapsed_time(e1) * 1e-3
+            g[1] += flops
+            g[2] += 1
+        if not groups:
+            return None
+        names = {0: "none", 1: "bias", 2: "bias_gelu", 3: "bias_gelu_save", 4: "dgelu", 5: "f32", 6: "add"}
+        epi, (t, fl, n) = max(groups.items(), key=lambda kv: kv[1][0])
+        ach = fl / t / 1e12
+        tot_t = sum(g[0] for g in groups.values())
+        tot_f = sum(g[1] for g in groups.values())
+        return {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % names.get(epi, epi), "achieved": round(ach, 1),
+                "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4), "traffic": None,
+                "launches_timed": n, "avg_launch_us": round(t / n * 1e6, 2),
+                "all_gemm_nt_tflops": round(tot_f / tot_t / 1e12, 1)}
+
+
+GEMM_TIMER = _GemmTimer()
+
+
 def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, bias=None, aux=None,
             epi=EPI_NONE, a_off=0, batch=1, sA=0, sB=0, sC=0, a_bytes=0, b_bytes=0, c_elems=0, alpha=1.0):
     d = GemmDesc()
@@ -46,7 +99,9 @@ def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, 
     d.sA, d.sB, d.sC = sA, sB, sC
     d.a_bytes, d.b_bytes, d.c_elems = a_bytes, b_bytes, c_elems
     d.epi, d.alpha = epi, alpha
+    ev = GEMM_TIMER.begin()
     _lib.call("w2vs_gemm_nt", C.byref(d), _stream())
+    GEMM_TIMER.end(ev, epi, 2.0 * M * N * K * batch)
 
 
 def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB=0, a_bytes=0, b_bytes=0,
@@ -143,24 +198,29 @@ def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True):
     return (y, pre) if save_pre else y
 
 
-def conv_cl_dgrad(dy, w, k, s, Lin, *, dgelu_aux=None):
-    """Gradient wrt the channel-last input of conv_cl_fwd.  dy [B, Lout, Cout]; w [Cout, Cin, k] bf16.
+def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None):
+    """Gradient wrt the channel-last input of conv_cl_fwd.  dy [B, Lout, Cout]; w2 [Cout, k*Cin] packed.
     (k, s) = (2, 2): non-overlapping windows -> plain GEMM into [B, Lout, 2*Cin].
     (k, s) = (3, 2): input rows pair up, pair p = [dy[p-1] | dy[p]] @ [[W2, 0], [W0, W1]]."""
-    _chk(dy, BF16, "dy"); _chk(w, BF16, "w")
+    _chk(dy, BF16, "dy"); _chk(w2, BF16, "w2")
     B, Lout, Cout = dy.shape
-    Cin = w.shape[1]
+    Cin = w2.shape[1] // k
     dx = torch.empty(B, Lin, Cin, device=dy.device, dtype=BF16)
     epi = EPI_DGELU if dgelu_aux is not None else EPI_NONE
+    wt = transpose2d(w2)  # [k*Cin, Cout]: row (j*Cin + ci) = w[:, ci, j]
     if (k, s) == (2, 2):
-        # B operand [N = 2*Cin, K = Cout]: row (j*Cin + ci) = w[:, ci, j]
-        bt = dgrad_pack_k2(w)
         if Lin > 2 * Lout:
             dx[:, 2 * Lout:].zero_()
-        gemm_nt(dy, bt, M=Lout, N=2 * Cin, K=Cout, lda=Cout, ldb=Cout, ldc=2 * Cin, out=dx, aux=dgelu_aux, epi=epi,
+        gemm_nt(dy, wt, M=Lout, N=2 * Cin, K=Cout, lda=Cout, ldb=Cout, ldc=2 * Cin, out=dx, aux=dgelu_aux, epi=epi,
                 batch=B, sA=Lout * Cout, sC=Lin * Cin, a_bytes=Lout * Cout * 2, c_elems=Lin * Cin)
     elif (k, s) == (3, 2):
-        bt = dgrad_pack_k3(w)
+        # B operand [N = 2*Cin, K = 2*Cout]: row-half 0 = [W2^T | W0^T], row-half 1 = [0 | W1^T]
+        # (K index 0..Cout-1 multiplies dy[p-1], Cout..2Cout-1 multiplies dy[p])
+        wt3 = wt.view(3, Cin, Cout)
+        bt = torch.zeros(2, Cin, 2, Cout, device=dy.device, dtype=BF16)
+        bt[0, :, 0] = wt3[2]
+        bt[0, :, 1] = wt3[0]
+        bt[1, :, 1] = wt3[1]
         P = (Lin + 1) // 2
         gemm_nt(dy, bt, M=P, N=2 * Cin, K=2 * Cout, lda=Cout, ldb=2 * Cout, ldc=2 * Cin, out=dx, aux=dgelu_aux,
                 epi=epi, a_off=-Cout, batch=B, sA=Lout * Cout, sC=Lin * Cin, a_bytes=Lout * Cout * 2,
@@ -168,24 +228,6 @@ def conv_cl_dgrad(dy, w, k, s, Lin, *, dgelu_aux=None):
     else:
         raise W2vsError("conv dgrad is built for (k,s) in {(2,2),(3,2)}; got (%d,%d)" % (k, s))
     return dx
-
-
-def dgrad_pack_k2(w):
-    Cout, Cin, k = w.shape
-    # [Cout, Cin, 2] -> [2, Cin, Cout] -> [2*Cin, Cout]
-    return transpose2d(w.view(Cout, Cin * k), batch=1).view(Cin, k, Cout).transpose(0, 1).contiguous().view(k * Cin, Cout)
-
-
-def dgrad_pack_k3(w):
-    """B operand [N = 2*Cin, K = 2*Cout] with blocks  row-half 0: [W2^T | W0^T], row-half 1: [0 | W1^T]
-    (K index 0..Cout-1 multiplies dy[p-1], Cout..2Cout-1 multiplies dy[p])."""
-    Cout, Cin, k = w.shape
-    wt = transpose2d(w.view(Cout, Cin * k), batch=1).view(Cin, k, Cout)  # [Cin, k, Cout]
-    bt = torch.zeros(2, Cin, 2, Cout, device=w.device, dtype=BF16)
-    bt[0, :, 0] = wt[:, 2]
-    bt[0, :, 1] = wt[:, 0]
-    bt[1, :, 1] = wt[:, 1]
-    return bt.view(2 * Cin, 2 * Cout)
 
 
 def conv_cl_wgrad(dy, x, k, s, dw2_f32, alpha=1.0):
@@ -417,6 +459,17 @@ def dropout(x, p, seed):
     out = torch.empty_like(x)
     _lib.call("w2vs_dropout", _p(x), _p(out), x.numel(), p, seed, _stream())
     return out
+
+
+def adam_step(p32, p16, m, v, g, *, lr, beta1, beta2, eps, weight_decay, step, scale_host=1.0, scale_dev=None):
+    _chk(p32, torch.float32, "p32"); _chk(p16, BF16, "p16"); _chk(g, torch.float32, "g")
+    _lib.call("w2vs_adam_step", _p(p32), _p(p16), _p(m), _p(v), _p(g), p32.numel(), lr, beta1, beta2, eps, weight_decay,
+              step, _p(scale_dev), scale_host, _stream())
+
+
+def sumsq(x, out):
+    _chk(x, torch.float32, "x"); _chk(out, torch.float32, "out")
+    _lib.call("w2vs_sumsq", _p(x), x.numel(), _p(out), _stream())
 
 
 def gather_rows(src, idx, R, scatter=False, out=None):
