@@ -151,10 +151,12 @@ int w2vs_quant_bwd(const w2vs_quant_desc* d, void* stream);
  * sample_negatives' gather (wav2vec2.py:521-526) + compute_preds (:529-542) fused: the
  * 100 x B x M x C negatives tensor is never materialised.  x, y [B*M, C] bf16, neg_idx [B, K*M]
  * int64 (the reference's index tensor, rows of y.view(-1, C)), logits [B*M, K+1] fp32 with
- * column 0 the positive; neg==pos entries are -inf.  bwd: dx, dy fp32 [B*M, C] (dy zeroed here). */
+ * column 0 the positive; neg==pos entries are -inf.  bwd reads the saved logits and norms; dy is
+ * accumulated per utterance in LDS (negatives never cross utterances) - no global atomics.    */
 typedef struct w2vs_nce_desc {
   const void* x; const void* y; const int64_t* neg_idx; float* logits;
-  const float* dlogits; float* dx; float* dy;
+  float* xn; float* yn;              /* [B*M] fp32 row norms, written by fwd, read by bwd */
+  const float* dlogits; void* dx; void* dy;   /* bwd: dx, dy bf16 [B*M, C] */
   int32_t B, M, K, C; float temp;
 } w2vs_nce_desc;
 int w2vs_nce_fwd(const w2vs_nce_desc* d, void* stream);

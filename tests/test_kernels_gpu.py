@@ -397,7 +397,7 @@ def test_infonce_logits(ops, B, M, K, Cc):
     torch.manual_seed(0)
     neg = O.sample_negative_indices(B, M, K)
     neg[0, 3 * K] = 5
-    logits = ops.nce_fwd(dev(x.view(-1, Cc)), dev(y.view(-1, Cc)), dev(neg), B, M, K, cfg.logit_temp)
+    logits, norms = ops.nce_fwd(dev(x.view(-1, Cc)), dev(y.view(-1, Cc)), dev(neg), B, M, K, cfg.logit_temp)
     xr, yr = x.float().requires_grad_(True), y.float().requires_grad_(True)
     preds, ref = O.compute_logits(xr, yr, neg, cfg)
     ref_bm = preds.permute(1, 2, 0).reshape(B * M, K + 1)  # rows (b, m)
@@ -407,9 +407,9 @@ def test_infonce_logits(ops, B, M, K, Cc):
     dl = torch.randn(B * M, K + 1)
     dl[inf_mask] = 0
     (ref_bm.masked_fill(inf_mask, 0) * dl).sum().backward()
-    dx, dy = ops.nce_bwd(dev(dl), dev(x.view(-1, Cc)), dev(y.view(-1, Cc)), dev(neg), B, M, K, cfg.logit_temp)
-    assert rel(dx, xr.grad.view(-1, Cc)) < 2e-3
-    assert rel(dy, yr.grad.view(-1, Cc)) < 2e-3
+    dx, dy = ops.nce_bwd(dev(dl), logits, norms, dev(x.view(-1, Cc)), dev(y.view(-1, Cc)), dev(neg), B, M, K, cfg.logit_temp)
+    assert rel(dx, xr.grad.view(-1, Cc)) < 5e-3
+    assert rel(dy, yr.grad.view(-1, Cc)) < 5e-3
 
 
 def test_cross_entropy_rows(ops):

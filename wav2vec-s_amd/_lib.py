@@ -56,7 +56,8 @@ class QuantDesc(C.Structure):
 
 
 class NceDesc(C.Structure):
-    _fields_ = [("x", vp), ("y", vp), ("neg_idx", vp), ("logits", vp), ("dlogits", vp), ("dx", vp), ("dy", vp),
+    _fields_ = [("x", vp), ("y", vp), ("neg_idx", vp), ("logits", vp), ("xn", vp), ("yn", vp), ("dlogits", vp),
+                ("dx", vp), ("dy", vp),
                 ("B", i32), ("M", i32), ("K", i32), ("C", i32), ("temp", f32)]
 
 

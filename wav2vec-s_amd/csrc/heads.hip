@@ -220,8 +220,9 @@ int quant_bwd(const QuantDesc& d, hipStream_t st) {
 struct NceP {
   const bf16* x; const bf16* y; const long long* neg;  // neg: [B, K*M] int64 (the reference's tensor)
   float* logits;                                       // [R, K+1]
-  const float* dlogits; float* dx; float* dy;          // bwd: fp32 accumulators [R, C]
-  int B, M, K, C; float inv_temp;
+  float* xn; float* yn;                                // [R] row norms (clamped at eps), saved by fwd
+  const float* dlogits; bf16* dx; bf16* dy;            // bwd outputs bf16 [R, C]
+  int B, M, K, C; float inv_temp; int cw;
 };
 
 __device__ __forceinline__ float sum16(float v) {
@@ -252,11 +253,6 @@ __global__ __launch_bounds__(256) void nce_kernel(NceP p) {
     }
     xx = sum16(xx);
     const float xn = fmaxf(sqrtf(xx), EPS);
-    float gx[PER];
-    if (BWD) {
-#pragma unroll
-      for (int e = 0; e < per; ++e) gx[e] = 0.f;
-    }
     for (int k0 = 0; k0 <= K; k0 += 4) {
       const int k = k0 + grp;
       const bool valid = k <= K;
@@ -286,37 +282,76 @@ __global__ __launch_bounds__(256) void nce_kernel(NceP p) {
       const float cosv = dot / (xn * tn);
       const bool neg_is_pos = (k > 0) && all_same;
       if (!BWD) {
-        if (valid && gl == 0) p.logits[row * (K + 1) + k] = neg_is_pos ? -INFINITY : cosv * p.inv_temp;
-      } else if (valid && !neg_is_pos) {
-        const float gl_ = p.dlogits[row * (K + 1) + k] * p.inv_temp;  // d/dcos
-        if (gl_ != 0.f) {
-          // d cos/dx = t/(|x||t|) - cos * x/|x|^2 ; d cos/dt = x/(|x||t|) - cos * t/|t|^2
-          const float a = gl_ / (xn * tn), bx = gl_ * cosv / (xn * xn), bt = gl_ * cosv / (tn * tn);
-          float* dyr = p.dy + trow * C + gl * per;
-#pragma unroll
-          for (int e = 0; e < per; ++e) {
-            gx[e] += a * ts[e] - bx * xs[e];
-            atomicAdd(&dyr[e], a * xs[e] - bt * ts[e]);
-          }
+        if (valid && gl == 0) {
+          p.logits[row * (K + 1) + k] = neg_is_pos ? -INFINITY : cosv * p.inv_temp;
+          if (k == 0) { p.xn[row] = xn; p.yn[row] = tn; }
         }
-      }
-    }
-    if (BWD) {
-      // combine the four groups' partial dx and store (row is owned by this wave: plain store)
-#pragma unroll
-      for (int e = 0; e < per; ++e) {
-        float v = gx[e];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (grp == 0) p.dx[row * C + gl * per + e] = v;
       }
     }
   }
 }
 
+// Backward.  The forward saved cos (= logits * temp) and the row norms, so the gradient needs no
+// dot products:  d cos/dx = t/(|x||t|) - cos x/|x|^2,  d cos/dt = x/(|x||t|) - cos t/|t|^2.
+// One 1024-thread block per (channel slice, utterance): negatives never leave their utterance
+// (wav2vec2.py:512-514), so dy of the utterance's M rows x cw channels is accumulated in LDS with
+// LDS atomics and written once - no global atomics, bf16 results directly.
+template <int EPL>  // elements per lane: cw = 64 * EPL
+__global__ __launch_bounds__(1024) void nce_bwd_kernel(NceP p) {
+  extern __shared__ float dyl[];  // [M][cw]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.x * p.cw;
+  const int M = p.M, K = p.K, C = p.C, cw = p.cw;
+  const float temp = 1.f / p.inv_temp;
+  for (int i = threadIdx.x; i < M * cw; i += 1024) dyl[i] = 0.f;
+  __syncthreads();
+  bool act[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) act[e] = (c0 + lane + 64 * e) < C;
+  for (int i = wid; i < M; i += 16) {
+    const long row = (long)b * M + i;
+    float xs[EPL], gx[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { xs[e] = act[e] ? bf2f(p.x[row * C + c0 + lane + 64 * e]) : 0.f; gx[e] = 0.f; }
+    const float xn = p.xn[row];
+    float sbx = 0.f;
+    const float* lg = p.logits + row * (K + 1);
+    const float* dl = p.dlogits + row * (K + 1);
+    const long long* ng = p.neg + (long)b * K * M + (long)i * K;
+    for (int k = 0; k <= K; ++k) {
+      const float lv = lg[k];
+      const float g = (lv == -INFINITY) ? 0.f : dl[k] * p.inv_temp;  // d/dcos ; neg==pos entries carry no gradient
+      if (g == 0.f) continue;                                       // wave-uniform
+      const int t = (k == 0) ? i : (int)(ng[k - 1] - (long long)b * M);
+      const long trow = (long)b * M + t;
+      const float cosv = lv * temp, tn = p.yn[trow];
+      const float a = g / (xn * tn), bt = g * cosv / (tn * tn);
+      sbx += g * cosv / (xn * xn);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        if (act[e]) {
+          float tv = bf2f(p.y[trow * C + c0 + lane + 64 * e]);
+          gx[e] += a * tv;
+          atomicAdd(&dyl[t * cw + lane + 64 * e], a * xs[e] - bt * tv);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+      if (act[e]) p.dx[row * C + c0 + lane + 64 * e] = f2bf(gx[e] - sbx * xs[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < M * cw; i += 1024) {
+    int t = i / cw, c = i % cw;
+    if (c0 + c < C) p.dy[((long)b * M + t) * C + c0 + c] = f2bf(dyl[i]);
+  }
+}
+
 static int nce_fill(const NceDesc& d, NceP& p) {
   p.x = (const bf16*)d.x; p.y = (const bf16*)d.y; p.neg = (const long long*)d.neg_idx; p.logits = d.logits;
-  p.dlogits = d.dlogits; p.dx = d.dx; p.dy = d.dy; p.B = d.B; p.M = d.M; p.K = d.K; p.C = d.C;
+  p.xn = d.xn; p.yn = d.yn;
+  p.dlogits = d.dlogits; p.dx = (bf16*)d.dx; p.dy = (bf16*)d.dy; p.B = d.B; p.M = d.M; p.K = d.K; p.C = d.C;
+  if (!p.xn || !p.yn) return set_error("infonce: norm buffers xn/yn required");
   if (!p.x || !p.y || !p.neg) return set_error("infonce: null pointer");
   if (p.C != 128 && p.C != 256 && p.C != 512 && p.C != 768) return set_error("infonce: final_dim must be one of 128, 256, 512, 768");
   if (p.B <= 0 || p.M <= 1 || p.K < 0) return set_error("infonce: need B>0, M>1, K>=0");
@@ -343,16 +378,29 @@ int nce_fwd(const NceDesc& d, hipStream_t st) {
 int nce_bwd(const NceDesc& d, hipStream_t st) {
   NceP p{};
   if (int e = nce_fill(d, p)) return e;
-  if (!p.dlogits || !p.dx || !p.dy) return set_error("infonce_bwd: null pointer");
-  long R = (long)p.B * p.M;
-  if (int e = hip_check(hipMemsetAsync(p.dy, 0, sizeof(float) * R * p.C, st), "memset")) return e;
-  int grid = (int)std::min<long>((R + 3) / 4, 4096);
-  switch (p.C) {
-    case 128: hipLaunchKernelGGL((nce_kernel<true, 8>), dim3(grid), dim3(256), 0, st, p); break;
-    case 256: hipLaunchKernelGGL((nce_kernel<true, 16>), dim3(grid), dim3(256), 0, st, p); break;
-    case 512: hipLaunchKernelGGL((nce_kernel<true, 32>), dim3(grid), dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((nce_kernel<true, 48>), dim3(grid), dim3(256), 0, st, p); break;
+  if (!p.dlogits || !p.dx || !p.dy || !p.logits) return set_error("infonce_bwd: null pointer");
+  // widest channel slice whose [M][cw] fp32 accumulator fits in LDS (keep 16 KiB headroom)
+  int cw = 0;
+  for (int c = 256; c >= 64; c -= 64)
+    if ((long)p.M * c * 4 <= 144 * 1024) { cw = c; break; }
+  if (!cw) return set_error("infonce_bwd: too many masked frames per utterance for the LDS accumulator (M > 576)");
+  if (cw > p.C) cw = ((p.C + 63) / 64) * 64;
+  p.cw = cw;
+  dim3 grid((p.C + cw - 1) / cw, p.B);
+  size_t lds = (size_t)p.M * cw * 4;
+#define NCE_LAUNCH(E)                                                                                          \
+  do {                                                                                                         \
+    if (int e = hip_check(hipFuncSetAttribute((const void*)nce_bwd_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              (int)lds), "hipFuncSetAttribute")) return e;                     \
+    hipLaunchKernelGGL(nce_bwd_kernel<E>, grid, dim3(1024), lds, st, p);                                        \
+  } while (0)
+  switch (cw / 64) {
+    case 1: NCE_LAUNCH(1); break;
+    case 2: NCE_LAUNCH(2); break;
+    case 3: NCE_LAUNCH(3); break;
+    default: NCE_LAUNCH(4); break;
   }
+#undef NCE_LAUNCH
   return hip_check(hipGetLastError(), "infonce_bwd");
 }
 

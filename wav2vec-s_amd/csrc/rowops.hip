@@ -167,17 +167,30 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0P p) {
       }
     }
   }
-  if (BWD && act) {
+  if (BWD) {
+    // block-level reduction in LDS first: one global atomic per value per BLOCK, not per wave
+    __shared__ float red[512 * 13];
+    for (int i = threadIdx.x; i < C * 13; i += 256) red[i] = 0.f;
+    __syncthreads();
+    if (act) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = lane * 8 + e;
-      atomicAdd(&p.dlnw[c], dg[e]);
-      atomicAdd(&p.dlnb[c], db[e]);
-      if (p.dcbias) atomicAdd(&p.dcbias[c], dcb[e]);
+      for (int e = 0; e < 8; ++e) {
+        int c = lane * 8 + e;
+        atomicAdd(&red[c], dg[e]);
+        atomicAdd(&red[C + c], db[e]);
+        atomicAdd(&red[2 * C + c], dcb[e]);
 #pragma unroll
-      for (int j = 0; j < 10; ++j)
-        if (j < K) atomicAdd(&p.dw[c * K + j], dw[e][j]);
+        for (int j = 0; j < 10; ++j)
+          if (j < K) atomicAdd(&red[3 * C + c * K + j], dw[e][j]);
+      }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+      atomicAdd(&p.dlnw[i], red[i]);
+      atomicAdd(&p.dlnb[i], red[C + i]);
+      if (p.dcbias) atomicAdd(&p.dcbias[i], red[2 * C + i]);
+    }
+    for (int i = threadIdx.x; i < C * K; i += 256) atomicAdd(&p.dw[i], red[3 * C + i]);
   }
 }
 
@@ -205,7 +218,7 @@ int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* ln
   p.dw = dw; p.dcbias = dcbias; p.dlnw = dlnw; p.dlnb = dlnb;
   p.B = B; p.L = L; p.L0 = (L - k) / s + 1; p.C = C; p.k = k; p.s = s;
   long rows = (long)B * p.L0;
-  int grid = (int)std::min<long>((rows + 3) / 4, 256 * 2);  // fewer, longer waves: fewer final atomics
+  int grid = (int)std::min<long>((rows + 3) / 4, 256);  // one block per CU: long waves, few final atomics
   hipLaunchKernelGGL(conv0_kernel<true>, dim3(grid), dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "conv0_bwd");
 }
@@ -378,16 +391,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
       store_row(p.dx + row * C, C, lane, dx);
     }
   }
+  __shared__ float red[2 * 1024];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     int ch = lane + 64 * h;
     if (ch < nchunks(C)) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        atomicAdd(&p.dg[ch * 8 + e], dg.v[h][e]);
-        atomicAdd(&p.db[ch * 8 + e], db.v[h][e]);
+        atomicAdd(&red[ch * 8 + e], dg.v[h][e]);
+        atomicAdd(&red[C + ch * 8 + e], db.v[h][e]);
       }
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(&p.dg[i], red[i]);
+    atomicAdd(&p.db[i], red[C + i]);
   }
 }
 
@@ -419,7 +440,7 @@ int ln_bwd(const LnBwdDesc& d, hipStream_t st) {
   p.out_scale = d.out_scale; p.pen_coef = d.pen_coef; p.gelu = d.gelu; p.rows = d.rows; p.C = d.C;
   if (!p.x || !p.g || !p.b || !p.mean || !p.rstd || !p.dg || !p.db) return set_error("ln_bwd: null pointer");
   if (int e = ln_check(p, "ln_bwd")) return e;
-  int grid = (int)std::min<long>((p.rows + 3) / 4, 256 * 2);
+  int grid = (int)std::min<long>((p.rows + 3) / 4, p.rows > 65536 ? 1024 : 256);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "ln_bwd");
 }
@@ -596,19 +617,28 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
     }
     store_row(p.dx + fr * C, C, lane, dx);
   }
+  __shared__ float red[3 * 1024];
+  for (int i = threadIdx.x; i < 3 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     int ch = lane + 64 * h;
     if (ch < nchunks(C)) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if (p.apply_ln) {
-          atomicAdd(&p.dg[ch * 8 + e], dgm.v[h][e]);
-          atomicAdd(&p.db[ch * 8 + e], dbt.v[h][e]);
-        }
-        atomicAdd(&p.dmask_emb[ch * 8 + e], dme.v[h][e]);
+        atomicAdd(&red[ch * 8 + e], dgm.v[h][e]);
+        atomicAdd(&red[C + ch * 8 + e], dbt.v[h][e]);
+        atomicAdd(&red[2 * C + ch * 8 + e], dme.v[h][e]);
       }
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    if (p.apply_ln) {
+      atomicAdd(&p.dg[i], red[i]);
+      atomicAdd(&p.db[i], red[C + i]);
+    }
+    atomicAdd(&p.dmask_emb[i], red[2 * C + i]);
   }
 }
 
@@ -642,7 +672,7 @@ int enc_prologue_bwd(const EncPrologueDesc& d, hipStream_t st) {
   if (!p.dout || !p.dx || !p.dmask_emb || !p.dg || !p.db || !p.copy_start || !p.copy_list)
     return set_error("enc_prologue_bwd: null pointer");
   long rows = (long)p.B * p.T;
-  int grid = (int)std::min<long>((rows + 3) / 4, 256 * 2);
+  int grid = (int)std::min<long>((rows + 3) / 4, 256);
   hipLaunchKernelGGL(enc_prologue_bwd_kernel, dim3(grid), dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "enc_prologue_bwd");
 }

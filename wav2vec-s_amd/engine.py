@@ -307,7 +307,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     neg = draws.neg_idx if draws.neg_idx is not None else host_rng.sample_negative_indices(B, M, K)
     st.neg = neg.to(dev)
     st.K = K
-    st.logits = ops.nce_fwd(xf, yq, st.neg, B, M, K, cfg.logit_temp)            # [B*M, K+1] rows (b, m)
+    st.logits, st.nce_norms = ops.nce_fwd(xf, yq, st.neg, B, M, K, cfg.logit_temp)   # [B*M, K+1] rows (b, m)
     return st
 
 
@@ -378,8 +378,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen: float = 0.0, d_prob_p
     else:
         M, K = st.M, st.K
         RM = B * M
-        dxf32, dyq32 = ops.nce_bwd(d_logits, st.xf, st.yq, st.neg, B, M, K, cfg.logit_temp)
-        dxf, dyq = ops.f32_to_bf16(dxf32), ops.f32_to_bf16(dyq32)
+        dxf, dyq = ops.nce_bwd(d_logits, st.logits, st.nce_norms, st.xf, st.yq, st.neg, B, M, K, cfg.logit_temp)
         # final_proj
         dxm = _linear_bwd(dxf, st.xm, "final_proj.weight", "final_proj.bias", W, A)
         ops.gather_rows(dxm, st.token_idx, RM, scatter=True, out=d_enc)

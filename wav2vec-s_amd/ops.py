@@ -421,24 +421,28 @@ def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, 
 
 # ---------------------------------------------------------------------------------------- InfoNCE
 def nce_fwd(x, y, neg_idx, B, M, K, temp):
-    """x, y [B*M, C] bf16; neg_idx [B, K*M] int64 -> logits [B*M, K+1] fp32."""
+    """x, y [B*M, C] bf16; neg_idx [B, K*M] int64 -> logits [B*M, K+1] fp32 and the saved row norms."""
     _chk(x, BF16, "x"); _chk(y, BF16, "y"); _chk(neg_idx, torch.int64, "neg_idx")
     Cc = x.shape[1]
     logits = torch.empty(B * M, K + 1, device=x.device, dtype=torch.float32)
+    norms = torch.empty(2, B * M, device=x.device, dtype=torch.float32)
     d = NceDesc()
     d.x, d.y, d.neg_idx, d.logits = _p(x), _p(y), _p(neg_idx), _p(logits)
+    d.xn, d.yn = _p(norms[0]), _p(norms[1])
     d.B, d.M, d.K, d.C, d.temp = B, M, K, Cc, temp
     _lib.call("w2vs_nce_fwd", C.byref(d), _stream())
-    return logits
+    return logits, norms
 
 
-def nce_bwd(dlogits, x, y, neg_idx, B, M, K, temp):
-    _chk(dlogits, torch.float32, "dlogits")
+def nce_bwd(dlogits, logits, norms, x, y, neg_idx, B, M, K, temp):
+    """Returns dx, dy bf16 [B*M, C]."""
+    _chk(dlogits, torch.float32, "dlogits"); _chk(logits, torch.float32, "logits")
     Cc = x.shape[1]
-    dx = torch.empty(B * M, Cc, device=x.device, dtype=torch.float32)
-    dy = torch.empty(B * M, Cc, device=x.device, dtype=torch.float32)
+    dx = torch.empty(B * M, Cc, device=x.device, dtype=BF16)
+    dy = torch.empty(B * M, Cc, device=x.device, dtype=BF16)
     d = NceDesc()
-    d.x, d.y, d.neg_idx, d.dlogits, d.dx, d.dy = _p(x), _p(y), _p(neg_idx), _p(dlogits), _p(dx), _p(dy)
+    d.x, d.y, d.neg_idx, d.logits, d.dlogits, d.dx, d.dy = _p(x), _p(y), _p(neg_idx), _p(logits), _p(dlogits), _p(dx), _p(dy)
+    d.xn, d.yn = _p(norms[0]), _p(norms[1])
     d.B, d.M, d.K, d.C, d.temp = B, M, K, Cc, temp
     _lib.call("w2vs_nce_bwd", C.byref(d), _stream())
     return dx, dy
