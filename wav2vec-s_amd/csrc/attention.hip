@@ -81,8 +81,26 @@ __device__ __forceinline__ void tile_ranges(int q0, int q1, int Tp, int m, int r
   clo = r > 0 ? Tp + bmin * r : N;
   chi = r > 0 ? min(Tp + (bmax + 1) * r, N) : N;
 }
-__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
-  return hash32(seed, idx) >= thr ? inv_keep : 0.f;
+// attention-dropout keep decision: 32-bit element index ((b*H+h)*N + q)*N + key, two-round
+// multiply-xorshift mix keyed by the 64-bit seed.  Cheaper than common.h's hash32 because it runs
+// once per score inside three kernels (fwd, dQ pass, dK/dV pass) that must agree bit for bit.
+__device__ __forceinline__ float keep_scale(uint32_t s0, uint32_t s1, uint32_t idx, uint32_t thr, float inv_keep) {
+  uint32_t x = idx * 0x9E3779B1u ^ s0;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= s1;
+  x ^= x >> 16;
+  return x >= thr ? inv_keep : 0.f;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
 }
 
 // cooperative load of a [64][64] tile (rows row0.., zero beyond nrows) into a swizzled LDS image
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk0 = blockIdx.x * QB;
+  const int qblk0 = (gridDim.x - 1 - blockIdx.x) * QB;  // longest query tiles first: shorter tail
   const int q = qblk0 + wid * 32 + r32;
   const int N = p.N;
   const bf16* Q = p.q + (long)b * p.sb + h * HD;
@@ -128,10 +146,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   int mlim, bclo, bchi;
   tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
 
+  // per-wave key ranges: sub-tiles no query of this wave can see are skipped, sub-tiles every
+  // query sees completely (and that hold no padded key) skip the mask arithmetic
+  const int wmlim = wave_max_i(L.lim), wfull = wave_min_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
+
   const float c = p.scale * LOG2E;
   const uint32_t thr = drop_threshold(p.p_drop);
   const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
-  const uint64_t drow = ((uint64_t)(b * p.H + h) * N + (uint64_t)min(q, N - 1)) * N;
+  const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)min(q, N - 1)) * (uint32_t)N;
 
   f32x16 O0, O1;
 #pragma unroll
@@ -150,8 +173,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       kbias[tid] = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
     }
     __syncthreads();
+    const bool tile_clean = !__any(kbias[lane] != 0.f);  // no padded / out-of-range key in this tile
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      const int k0 = kt0 + sub * 32;
+      if (!((k0 < wmlim) || (k0 < wchi && k0 + 32 > wclo))) continue;  // wave-uniform
+      const bool full = tile_clean && (k0 + 32 <= wfull);
       f32x16 S;
 #pragma unroll
       for (int i = 0; i < 16; ++i) S[i] = 0.f;
@@ -161,13 +188,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], S, 0, 0, 0);
       }
       float mloc = -INFINITY;
+      if (full) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
-        bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
-        float sv = ok ? S[i] * c + kbias[kl] : -INFINITY;
-        S[i] = sv;
-        mloc = fmaxf(mloc, sv);
+        for (int i = 0; i < 16; ++i) { S[i] *= c; mloc = fmaxf(mloc, S[i]); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
+          bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
+          float sv = ok ? S[i] * c + kbias[kl] : -INFINITY;
+          S[i] = sv;
+          mloc = fmaxf(mloc, sv);
+        }
       }
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float mnew = fmaxf(mrun, mloc);
@@ -179,12 +211,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       for (int i = 0; i < 16; ++i) {
         float e = exp2f(S[i] - muse);
         ls += e;
-        if (p.p_drop > 0.f) e *= keep_scale(p.seed, drow + (uint64_t)(kt0 + sub * 32 + acc_row(i, hh)), thr, inv_keep);
+        if (p.p_drop > 0.f) e *= keep_scale(s0, s1, drow + (uint32_t)(k0 + acc_row(i, hh)), thr, inv_keep);
         S[i] = e;
       }
       lrun = lrun * alpha + ls;
+      if (!__all(alpha == 1.f)) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pb = pack8(S, s2);
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk0 = blockIdx.x * QB;
+  const int qblk0 = (gridDim.x - 1 - blockIdx.x) * QB;
   const int q = qblk0 + wid * 32 + r32;
   const int N = p.N;
   const int qc = min(q, N - 1);
@@ -274,10 +308,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
   int mlim, bclo, bchi;
   tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+  const int wmlim = wave_max_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
   const float c = p.scale * LOG2E;
   const uint32_t thr = drop_threshold(p.p_drop);
   const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
-  const uint64_t drow = ((uint64_t)(b * p.H + h) * N + (uint64_t)qc) * N;
+  const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)qc) * (uint32_t)N;
   f32x16 D0, D1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { D0[i] = 0.f; D1[i] = 0.f; }
@@ -296,6 +332,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     __syncthreads();
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      const int k0 = kt0 + sub * 32;
+      if (!((k0 < wmlim) || (k0 < wchi && k0 + 32 > wclo))) continue;  // wave-uniform
       f32x16 S, dP;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
@@ -313,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
         float sv = ok ? S[i] * c + kbias[kl] : -INFINITY;
         float pe = exp2f(sv - lse2);
         float dp = dP[i];
-        if (p.p_drop > 0.f) dp *= keep_scale(p.seed, drow + (uint64_t)key, thr, inv_keep);
+        if (p.p_drop > 0.f) dp *= keep_scale(s0, s1, drow + (uint32_t)key, thr, inv_keep);
         S[i] = pe * (dp - delta) * p.scale;
       }
 #pragma unroll
@@ -381,8 +419,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
   const float c = p.scale * LOG2E;
   const uint32_t thr = drop_threshold(p.p_drop);
   const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
-  const uint64_t dbase = (uint64_t)(b * p.H + h) * N;
+  const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
+  const uint32_t dbase = (uint32_t)(b * p.H + h) * (uint32_t)N;
   const int klo = kblk0, khi = min(kblk0 + QB, N);  // this block's keys [klo, khi)
+  const int wk0 = kblk0 + wid * 32, wk1 = min(wk0 + 32, N);  // this wave's keys [wk0, wk1)
   f32x16 dV0, dV1, dK0, dK1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
@@ -409,6 +449,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
     __syncthreads();
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      {  // can any query of this 32-row sub-tile see any key of this wave?  (wave-uniform)
+        const int qs0 = q0 + sub * 32;
+        if (qs0 >= N || wk0 >= N) continue;
+        int smlim, sclo, schi;
+        tile_ranges(qs0, min(qs0 + 32, N) - 1, p.Tp, p.m, p.r, N, smlim, sclo, schi);
+        if (!((wk0 < smlim) || (wk0 < schi && wk1 > sclo))) continue;
+      }
       f32x16 S, dP;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
@@ -427,7 +474,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
         float sv = ok ? S[i] * c : -INFINITY;
         float pe = exp2f(sv - lse_s[ql]);
         float ks = 1.f;
-        if (p.p_drop > 0.f) ks = keep_scale(p.seed, (dbase + (uint64_t)min(qq, N - 1)) * N + (uint64_t)min(key, N - 1), thr, inv_keep);
+        if (p.p_drop > 0.f) ks = keep_scale(s0, s1, (dbase + (uint32_t)min(qq, N - 1)) * (uint32_t)N + (uint32_t)min(key, N - 1), thr, inv_keep);
         Pd[i] = pe * ks;
         S[i] = pe * (dP[i] * ks - del_s[ql]) * p.scale;
       }
@@ -479,7 +526,7 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
   if (p.N != p.Tp + (p.Tp / p.m) * p.r) return set_error("attention: N must equal Tp + (Tp/m)*r");
   if ((p.ld % 8) || (p.ldo % 8) || (p.sb % 8) || (p.sbo % 8)) return set_error("attention: strides must be multiples of 8 elements");
   if (p.p_drop < 0.f || p.p_drop >= 1.f) return set_error("attention: dropout must be in [0,1)");
-  if ((long)p.B * p.H * p.N * (long)p.N >= (1L << 62)) return set_error("attention: too large");
+  if ((long)p.B * p.H * p.N * (long)p.N >= (1L << 32)) return set_error("attention: B*H*N*N must be < 2^32 (dropout index)");
   return 0;
 }
 

@@ -314,25 +314,45 @@ __global__ __launch_bounds__(1024) void nce_bwd_kernel(NceP p) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { xs[e] = act[e] ? bf2f(p.x[row * C + c0 + lane + 64 * e]) : 0.f; gx[e] = 0.f; }
     const float xn = p.xn[row];
-    float sbx = 0.f;
     const float* lg = p.logits + row * (K + 1);
     const float* dl = p.dlogits + row * (K + 1);
     const long long* ng = p.neg + (long)b * K * M + (long)i * K;
-    for (int k = 0; k <= K; ++k) {
-      const float lv = lg[k];
-      const float g = (lv == -INFINITY) ? 0.f : dl[k] * p.inv_temp;  // d/dcos ; neg==pos entries carry no gradient
-      if (g == 0.f) continue;                                       // wave-uniform
-      const int t = (k == 0) ? i : (int)(ng[k - 1] - (long long)b * M);
-      const long trow = (long)b * M + t;
-      const float cosv = lv * temp, tn = p.yn[trow];
-      const float a = g / (xn * tn), bt = g * cosv / (tn * tn);
-      sbx += g * cosv / (xn * xn);
+    // phase 1: the (K+1) per-target scalars, lanes in parallel (k = lane, lane+64); entries without
+    // gradient (g == 0, neg==pos, k > K) become a no-op on the own row
+    int tq[2]; float aq[2], bq[2];
+    float sbx = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = lane + 64 * h;
+      tq[h] = i; aq[h] = 0.f; bq[h] = 0.f;
+      if (k <= K) {
+        const float lv = lg[k];
+        const float g = (lv == -INFINITY) ? 0.f : dl[k] * p.inv_temp;
+        if (g != 0.f) {
+          const int t = (k == 0) ? i : (int)(ng[k - 1] - (long long)b * M);
+          const float cosv = lv * temp, tn = p.yn[(long)b * M + t];
+          tq[h] = t; aq[h] = g / (xn * tn); bq[h] = g * cosv / (tn * tn);
+          sbx += g * cosv / (xn * xn);
+        }
+      }
+    }
+    sbx = wave_sum(sbx);
+    // phase 2: straight-line over targets; scalars broadcast from lane registers, rows of y stream in
+    const int KK = K + 1;
+#pragma unroll 4
+    for (int k = 0; k < KK; ++k) {
+      const int h = k >> 6, src = k & 63;
+      const int t = __builtin_amdgcn_readlane(h ? tq[1] : tq[0], src);
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h ? aq[1] : aq[0]), src));
+      const float bt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h ? bq[1] : bq[0]), src));
+      const bf16* yr = p.y + ((long)b * M + t) * C + c0 + lane;
+      float* dr = dyl + t * cw + lane;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
         if (act[e]) {
-          float tv = bf2f(p.y[trow * C + c0 + lane + 64 * e]);
+          float tv = bf2f(yr[64 * e]);
           gx[e] += a * tv;
-          atomicAdd(&dyl[t * cw + lane + 64 * e], a * xs[e] - bt * tv);
+          atomicAdd(&dr[64 * e], a * xs[e] - bt * tv);
         }
       }
     }
@@ -381,7 +401,7 @@ int nce_bwd(const NceDesc& d, hipStream_t st) {
   if (!p.dlogits || !p.dx || !p.dy || !p.logits) return set_error("infonce_bwd: null pointer");
   // widest channel slice whose [M][cw] fp32 accumulator fits in LDS (keep 16 KiB headroom)
   int cw = 0;
-  for (int c = 256; c >= 64; c -= 64)
+  for (int c = 64; c >= 64; c -= 64)   // 64-wide slices: C/64 x B blocks keep more CUs busy than wider ones
     if ((long)p.M * c * 4 <= 144 * 1024) { cw = c; break; }
   if (!cw) return set_error("infonce_bwd: too many masked frames per utterance for the LDS accumulator (M > 576)");
   if (cw > p.C) cw = ((p.C + 63) / 64) * 64;
