@@ -31,7 +31,7 @@ extern "C" {
 int w2vs_abi_version(void);
 const char* w2vs_last_error(void);
 /* sizeof() of the descriptor structs as compiled, so a binding can verify its mirror:
- * which = 0 gemm, 1 ln_fwd, 2 ln_bwd, 3 enc_prologue, 4 attn, 5 quant, 6 nce */
+ * which = 0 gemm, 1 ln_fwd, 2 ln_bwd, 3 enc_prologue, 4 attn, 5 quant, 6 nce, 7 layer */
 int w2vs_sizeof(int which);
 
 /* ---- GEMM family ----------------------------------------------------------------------------
@@ -128,6 +128,31 @@ typedef struct w2vs_attn_desc {
 } w2vs_attn_desc;
 int w2vs_attn_fwd(const w2vs_attn_desc* d, void* stream);
 int w2vs_attn_bwd(const w2vs_attn_desc* d, void* stream);
+
+/* ---- composite: one post-LN Transformer encoder layer -------------------------------------------
+ * TransformerSentenceEncoderLayer.forward (fs/models/wav2vec/wav2vec2.py:955-976) with the fused QKV
+ * projection, block attention, out_proj, dropout+residual+LayerNorm, fc1+GELU, fc2,
+ * dropout+residual+LayerNorm enqueued by ONE call (and the whole backward by one more), so the host
+ * issues 2 calls per layer.  R = B*N rows.  Saved activations are written by fwd and read by bwd.
+ * wqkv [3E,E] / bqkv [3E] = q,k,v projections stacked.  Scratch (bwd): ws_e0..2 [R,E], ws_f [R,F],
+ * ws_qkv [R,3E], delta [B,H,N] fp32, wt_scratch >= max(3E*E, E*F) bf16.  Gradients accumulate.      */
+typedef struct w2vs_layer_desc {
+  int32_t B, N, E, F, H, Tp, m, r, post_ln, num_cu;
+  float p_drop, p_attn; uint64_t seed_attn, seed_drop1, seed_drop2;
+  const uint8_t* kpad;
+  const void *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+  const void* x_in;
+  void *qkv, *ctx; float* lse;
+  void* s1; float *mean1, *rstd1; void* x1;
+  void *hpre, *h;
+  void* s2; float *mean2, *rstd2; void* x_out;
+  void* tmp;
+  const void* d_out; void* d_in;
+  float *g_wqkv, *g_bqkv, *g_wo, *g_bo, *g_ln1_g, *g_ln1_b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2_g, *g_ln2_b;
+  void *ws_e0, *ws_e1, *ws_e2, *ws_f, *ws_qkv, *wt_scratch; float* delta;
+} w2vs_layer_desc;
+int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
+int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);
 
 /* ---- Gumbel vector quantizer ---------------------------------------------------------------------
  * fs/modules/gumbel_vector_quantizer.py:141-202 after the weight_proj GEMM: hard argmax +

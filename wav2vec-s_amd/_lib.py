@@ -61,7 +61,18 @@ class NceDesc(C.Structure):
                 ("B", i32), ("M", i32), ("K", i32), ("C", i32), ("temp", f32)]
 
 
-_DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc]
+class LayerDesc(C.Structure):
+    _fields_ = ([(n, i32) for n in ("B", "N", "E", "F", "H", "Tp", "m", "r", "post_ln", "num_cu")]
+                + [("p_drop", f32), ("p_attn", f32), ("seed_attn", u64), ("seed_drop1", u64), ("seed_drop2", u64)]
+                + [(n, vp) for n in (
+                    "kpad", "wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b",
+                    "x_in", "qkv", "ctx", "lse", "s1", "mean1", "rstd1", "x1", "hpre", "h", "s2", "mean2", "rstd2",
+                    "x_out", "tmp", "d_out", "d_in",
+                    "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_ln1_g", "g_ln1_b", "g_w1", "g_b1", "g_w2", "g_b2",
+                    "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta")])
+
+
+_DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc]
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_ADD = range(7)
 
@@ -77,6 +88,8 @@ _SIGS = {
     "w2vs_enc_prologue_bwd": [C.POINTER(EncPrologueDesc), vp],
     "w2vs_attn_fwd": [C.POINTER(AttnDesc), vp],
     "w2vs_attn_bwd": [C.POINTER(AttnDesc), vp],
+    "w2vs_layer_fwd": [C.POINTER(LayerDesc), vp],
+    "w2vs_layer_bwd": [C.POINTER(LayerDesc), vp],
     "w2vs_quant_fwd": [C.POINTER(QuantDesc), vp],
     "w2vs_quant_bwd": [C.POINTER(QuantDesc), vp],
     "w2vs_nce_fwd": [C.POINTER(NceDesc), vp],

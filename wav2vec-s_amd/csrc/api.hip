@@ -29,6 +29,7 @@ int w2vs_sizeof(int which) {
     case 4: return (int)sizeof(w2vs_attn_desc);
     case 5: return (int)sizeof(w2vs_quant_desc);
     case 6: return (int)sizeof(w2vs_nce_desc);
+    case 7: return (int)sizeof(w2vs_layer_desc);
   }
   return -1;
 }
@@ -49,6 +50,8 @@ int w2vs_enc_prologue_fwd(const w2vs_enc_prologue_desc* d, void* s) { NONNULL(d)
 int w2vs_enc_prologue_bwd(const w2vs_enc_prologue_desc* d, void* s) { NONNULL(d); return enc_prologue_bwd(*d, ST(s)); }
 int w2vs_attn_fwd(const w2vs_attn_desc* d, void* s) { NONNULL(d); return attn_fwd(*d, ST(s)); }
 int w2vs_attn_bwd(const w2vs_attn_desc* d, void* s) { NONNULL(d); return attn_bwd(*d, ST(s)); }
+int w2vs_layer_fwd(const w2vs_layer_desc* d, void* s) { NONNULL(d); return layer_fwd(*d, ST(s)); }
+int w2vs_layer_bwd(const w2vs_layer_desc* d, void* s) { NONNULL(d); return layer_bwd(*d, ST(s)); }
 int w2vs_quant_fwd(const w2vs_quant_desc* d, void* s) { NONNULL(d); return quant_fwd(*d, ST(s)); }
 int w2vs_quant_bwd(const w2vs_quant_desc* d, void* s) { NONNULL(d); return quant_bwd(*d, ST(s)); }
 int w2vs_nce_fwd(const w2vs_nce_desc* d, void* s) { NONNULL(d); return nce_fwd(*d, ST(s)); }

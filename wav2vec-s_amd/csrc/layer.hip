@@ -1,0 +1,128 @@
+// Host-side composite entry points: one C call enqueues every kernel of a Transformer encoder
+// layer (forward or backward) on the caller's stream.  The Python driver then issues ~2 calls per
+// layer instead of ~45, which removes the host launch path from the critical path (the GPU work of
+// a layer is ~1 ms; 45 ctypes round trips were costing more than that).
+//
+// Post-LN layer (wav2vec-S base), fs/models/wav2vec/wav2vec2.py:955-976:
+//     a  = out_proj(attn(qkv(x)))            s1 = x + drop(a)      x1 = LN1(s1)
+//     f  = fc2(gelu(fc1(x1)))                s2 = x1 + drop(f)     y  = LN2(s2)
+#include "w2vs_internal.h"
+
+namespace w2vs {
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6 };
+
+static int lin_fwd(const void* x, const void* w, const void* b, void* y, void* pre, int R, int N, int K, int epi, hipStream_t s) {
+  GemmDesc d{};
+  d.A = x; d.B = w; d.C = y; d.C2 = pre; d.bias = b;
+  d.M = R; d.N = N; d.K = K; d.batch = 1; d.lda = K; d.ldb = K; d.ldc = N; d.epi = epi; d.alpha = 1.f;
+  return gemm_nt(d, s);
+}
+// dx[R,K] = dy[R,N] @ W[N,K], W given transposed (wt = [K,N]); aux for DGELU / ADD epilogues
+static int lin_dgrad(const void* dy, const void* wt, void* dx, const void* aux, int R, int N, int K, int epi, hipStream_t s) {
+  GemmDesc d{};
+  d.A = dy; d.B = wt; d.C = dx; d.aux = aux;
+  d.M = R; d.N = K; d.K = N; d.batch = 1; d.lda = N; d.ldb = N; d.ldc = K; d.epi = epi; d.alpha = 1.f;
+  return gemm_nt(d, s);
+}
+// dw[N,K] += dy[R,N]^T x[R,K] ; db[N] += colsum(dy)
+static int lin_wgrad(const void* dy, const void* x, float* dw, float* db, int R, int N, int K, int num_cu, hipStream_t s) {
+  GemmDesc d{};
+  d.A = dy; d.B = x; d.Cf = dw;
+  d.M = N; d.N = K; d.K = R; d.batch = 1; d.lda = N; d.ldb = K; d.ldc = K; d.alpha = 1.f;
+  if (int e = gemm_tn(d, num_cu, s)) return e;
+  return colsum(dy, db, R, N, N, s);
+}
+
+#define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
+
+static int layer_check(const w2vs_layer_desc& L) {
+  if (L.B <= 0 || L.N <= 0 || L.E <= 0 || L.F <= 0 || L.H <= 0) return set_error("layer: bad dims");
+  if (L.E % 8 || L.F % 8 || L.E / L.H != 64) return set_error("layer: need E%8==0, F%8==0, head_dim 64");
+  if (!L.post_ln) return set_error("layer: the composite entry covers the post-LN layer; pre-LN runs per kernel");
+  if (!L.x_in || !L.wqkv || !L.bqkv || !L.wo || !L.bo || !L.w1 || !L.b1 || !L.w2 || !L.b2 || !L.ln1_g || !L.ln1_b ||
+      !L.ln2_g || !L.ln2_b)
+    return set_error("layer: null weight/input pointer");
+  if (!L.qkv || !L.ctx || !L.lse || !L.s1 || !L.mean1 || !L.rstd1 || !L.x1 || !L.hpre || !L.h || !L.s2 || !L.mean2 ||
+      !L.rstd2 || !L.x_out || !L.tmp)
+    return set_error("layer: null activation pointer");
+  return 0;
+}
+
+static void fill_attn(const w2vs_layer_desc& L, AttnDesc& a) {
+  const long E = L.E;
+  a.q = L.qkv; a.k = (const char*)L.qkv + 2 * E; a.v = (const char*)L.qkv + 4 * E;
+  a.o = L.ctx; a.lse = L.lse; a.kpad = L.kpad;
+  a.ld = 3 * E; a.ldo = E; a.sb = (long)L.N * 3 * E; a.sbo = (long)L.N * E;
+  a.B = L.B; a.H = L.H; a.N = L.N; a.Tp = L.Tp; a.m = L.m; a.r = L.r; a.head_dim = 64;
+  a.scale = 0.125f; a.p_drop = L.p_attn; a.seed = L.seed_attn;
+}
+
+int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
+  TRY(layer_check(L));
+  const int R = L.B * L.N, E = L.E, F = L.F;
+  TRY(lin_fwd(L.x_in, L.wqkv, L.bqkv, L.qkv, nullptr, R, 3 * E, E, EPI_BIAS, s));
+  AttnDesc a{};
+  fill_attn(L, a);
+  TRY(attn_fwd(a, s));
+  TRY(lin_fwd(L.ctx, L.wo, L.bo, L.tmp, nullptr, R, E, E, EPI_BIAS, s));
+  LnFwdDesc n1{};
+  n1.x = L.tmp; n1.res = L.x_in; n1.gamma = L.ln1_g; n1.beta = L.ln1_b; n1.y = L.x1; n1.sum_out = L.s1;
+  n1.mean = L.mean1; n1.rstd = L.rstd1; n1.rows = R; n1.C = E; n1.p_drop = L.p_drop; n1.seed = L.seed_drop1;
+  TRY(ln_fwd(n1, s));
+  TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, R, F, E, EPI_BIAS_GELU_SAVE, s));
+  TRY(lin_fwd(L.h, L.w2, L.b2, L.tmp, nullptr, R, E, F, EPI_BIAS, s));
+  LnFwdDesc n2{};
+  n2.x = L.tmp; n2.res = L.x1; n2.gamma = L.ln2_g; n2.beta = L.ln2_b; n2.y = L.x_out; n2.sum_out = L.s2;
+  n2.mean = L.mean2; n2.rstd = L.rstd2; n2.rows = R; n2.C = E; n2.p_drop = L.p_drop; n2.seed = L.seed_drop2;
+  TRY(ln_fwd(n2, s));
+  return 0;
+}
+
+int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
+  TRY(layer_check(L));
+  if (!L.d_out || !L.d_in || !L.wt_scratch || !L.ws_e0 || !L.ws_e1 || !L.ws_e2 || !L.ws_f || !L.ws_qkv || !L.delta)
+    return set_error("layer_bwd: null scratch pointer");
+  if (!L.g_wqkv || !L.g_bqkv || !L.g_wo || !L.g_bo || !L.g_w1 || !L.g_b1 || !L.g_w2 || !L.g_b2 || !L.g_ln1_g ||
+      !L.g_ln1_b || !L.g_ln2_g || !L.g_ln2_b)
+    return set_error("layer_bwd: null gradient pointer");
+  const int R = L.B * L.N, E = L.E, F = L.F, cu = L.num_cu > 0 ? L.num_cu : 256;
+  // LN2 backward: d_f = ds2 o dropmask (ws_e0), d_x1a = ds2 (ws_e1)
+  LnBwdDesc b2{};
+  b2.x = L.s2; b2.gamma = L.ln2_g; b2.beta = L.ln2_b; b2.mean = L.mean2; b2.rstd = L.rstd2; b2.dy = L.d_out;
+  b2.dx = L.ws_e0; b2.dres = L.ws_e1; b2.dgamma = L.g_ln2_g; b2.dbeta = L.g_ln2_b; b2.rows = R; b2.C = E;
+  b2.p_drop = L.p_drop; b2.seed = L.seed_drop2; b2.out_scale = 1.f;
+  TRY(ln_bwd(b2, s));
+  // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
+  TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, cu, s));
+  TRY(transpose2d(L.w2, L.wt_scratch, E, F, 1, s));                       // [E,F] -> [F,E]
+  TRY(lin_dgrad(L.ws_e0, L.wt_scratch, L.ws_f, L.hpre, R, E, F, EPI_DGELU, s));
+  // fc1: wgrad, bias, dgrad + residual branch -> d_x1 (ws_e2)
+  TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, cu, s));
+  TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));                       // [F,E] -> [E,F]
+  TRY(lin_dgrad(L.ws_f, L.wt_scratch, L.ws_e2, L.ws_e1, R, F, E, EPI_ADD, s));
+  // LN1 backward: d_a = ds1 o dropmask (ws_e0), d_xin_a = ds1 (ws_e1)
+  LnBwdDesc b1{};
+  b1.x = L.s1; b1.gamma = L.ln1_g; b1.beta = L.ln1_b; b1.mean = L.mean1; b1.rstd = L.rstd1; b1.dy = L.ws_e2;
+  b1.dx = L.ws_e0; b1.dres = L.ws_e1; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = R; b1.C = E;
+  b1.p_drop = L.p_drop; b1.seed = L.seed_drop1; b1.out_scale = 1.f;
+  TRY(ln_bwd(b1, s));
+  // out_proj
+  TRY(lin_wgrad(L.ws_e0, L.ctx, L.g_wo, L.g_bo, R, E, E, cu, s));
+  TRY(transpose2d(L.wo, L.wt_scratch, E, E, 1, s));
+  TRY(lin_dgrad(L.ws_e0, L.wt_scratch, L.ws_e2, nullptr, R, E, E, EPI_NONE, s));   // d_ctx
+  // attention
+  AttnDesc a{};
+  fill_attn(L, a);
+  const long E2 = 2L * E;
+  a.dout = L.ws_e2; a.delta = L.delta;
+  a.dq = L.ws_qkv; a.dk = (char*)L.ws_qkv + E2; a.dv = (char*)L.ws_qkv + 2 * E2;
+  TRY(attn_bwd(a, s));
+  // fused QKV projection
+  TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s));
+  TRY(transpose2d(L.wqkv, L.wt_scratch, 3 * E, E, 1, s));                 // [3E,E] -> [E,3E]
+  TRY(lin_dgrad(L.ws_qkv, L.wt_scratch, L.d_in, L.ws_e1, R, 3 * E, E, EPI_ADD, s));
+  return 0;
+}
+
+}  // namespace w2vs

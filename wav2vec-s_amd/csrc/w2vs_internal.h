@@ -31,6 +31,8 @@ int enc_prologue_fwd(const EncPrologueDesc& d, hipStream_t st);
 int enc_prologue_bwd(const EncPrologueDesc& d, hipStream_t st);
 int attn_fwd(const AttnDesc& d, hipStream_t st);
 int attn_bwd(const AttnDesc& d, hipStream_t st);
+int layer_fwd(const w2vs_layer_desc& L, hipStream_t st);
+int layer_bwd(const w2vs_layer_desc& L, hipStream_t st);
 int quant_fwd(const QuantDesc& d, hipStream_t st);
 int quant_bwd(const QuantDesc& d, hipStream_t st);
 int nce_fwd(const NceDesc& d, hipStream_t st);

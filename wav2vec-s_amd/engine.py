@@ -13,8 +13,10 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import host_rng, ops
-from ._lib import W2vsError
+import ctypes as C
+
+from . import _lib, host_rng, ops
+from ._lib import LayerDesc, W2vsError
 
 BF16 = torch.bfloat16
 _GOLD = 0x9E3779B97F4A7C15
@@ -213,24 +215,47 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     x = x0.view(R, E)
     st.x0 = x
     if post_ln:
-        for li in st.kept:
+        F = cfg.encoder_ffn_embed_dim
+        nk = len(st.kept)
+        # one bf16 slab and one fp32 slab hold every saved activation of every kept layer
+        per16 = R * (8 * E + 2 * F)
+        slab16 = torch.empty(max(nk, 1) * per16 + R * E, device=dev, dtype=BF16)
+        per32 = B * H * N + 4 * R
+        slab32 = torch.empty(max(nk, 1) * per32, device=dev, dtype=torch.float32)
+        st.tmp = slab16[max(nk, 1) * per16:]
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        kpad_ptr = st.kpad.data_ptr() if st.kpad is not None else None
+        for j, li in enumerate(st.kept):
             pre = f"encoder.layers.{li}."
-            rec = dict(li=li, x_in=x)
+            d = LayerDesc()
+            d.B, d.N, d.E, d.F, d.H, d.Tp, d.m, d.r, d.post_ln, d.num_cu = B, N, E, F, H, Tp, m_ctx, r_ctx, 1, 256
+            d.p_drop, d.p_attn = p_enc, p_att
+            d.seed_attn, d.seed_drop1, d.seed_drop2 = seed(100 + 4 * li), seed(101 + 4 * li), seed(102 + 4 * li)
+            d.kpad = kpad_ptr
             wqkv, bqkv = _qkv_pack(W, pre)
-            qkv = ops.linear_fwd(x, wqkv, bqkv)
-            ctx, lse = ops.attn_fwd(qkv.view(B, N, 3 * E), H, Tp, m_ctx, r_ctx, kpad=st.kpad, p_drop=p_att,
-                                    seed=seed(100 + 4 * li))
-            a = ops.linear_fwd(ctx.view(R, E), W[pre + "self_attn.out_proj.weight"], W[pre + "self_attn.out_proj.bias"])
-            x1, s1, mean1, rstd1 = ops.ln_fwd(a, W[pre + "self_attn_layer_norm.weight"], W[pre + "self_attn_layer_norm.bias"],
-                                              res=x, want_sum=True, p_drop=p_enc, seed=seed(101 + 4 * li))
-            h, hpre = ops.linear_fwd(x1, W[pre + "fc1.weight"], W[pre + "fc1.bias"], gelu=True, save_pre=True)
-            f = ops.linear_fwd(h, W[pre + "fc2.weight"], W[pre + "fc2.bias"])
-            x2, s2, mean2, rstd2 = ops.ln_fwd(f, W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
-                                              res=x1, want_sum=True, p_drop=p_enc, seed=seed(102 + 4 * li))
-            rec.update(qkv=qkv, ctx=ctx, lse=lse, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, h=h, hpre=hpre, s2=s2,
-                       mean2=mean2, rstd2=rstd2)
+            rec = dict(li=li, wqkv=wqkv, bqkv=bqkv)
+            d.wqkv, d.bqkv = wqkv.data_ptr(), bqkv.data_ptr()
+            for f_, n_ in (("wo", "self_attn.out_proj.weight"), ("bo", "self_attn.out_proj.bias"),
+                           ("ln1_g", "self_attn_layer_norm.weight"), ("ln1_b", "self_attn_layer_norm.bias"),
+                           ("w1", "fc1.weight"), ("b1", "fc1.bias"), ("w2", "fc2.weight"), ("b2", "fc2.bias"),
+                           ("ln2_g", "final_layer_norm.weight"), ("ln2_b", "final_layer_norm.bias")):
+                setattr(d, f_, W[pre + n_].data_ptr())
+            base16 = slab16.data_ptr() + 2 * j * per16
+            o = 0
+            for f_, cols in (("qkv", 3 * E), ("ctx", E), ("s1", E), ("x1", E), ("hpre", F), ("h", F), ("s2", E), ("x_out", E)):
+                setattr(d, f_, base16 + 2 * o)
+                o += R * cols
+            base32 = slab32.data_ptr() + 4 * j * per32
+            d.lse = base32
+            d.mean1, d.rstd1 = base32 + 4 * (B * H * N), base32 + 4 * (B * H * N + R)
+            d.mean2, d.rstd2 = base32 + 4 * (B * H * N + 2 * R), base32 + 4 * (B * H * N + 3 * R)
+            d.x_in = x.data_ptr()
+            d.tmp = st.tmp.data_ptr()
+            _lib.call("w2vs_layer_fwd", C.byref(d), stream)
+            rec["desc"] = d
             st.layers.append(rec)
-            x = x2
+            x = slab16[j * per16 + R * (7 * E + 2 * F): j * per16 + R * (8 * E + 2 * F)].view(R, E)
+        st.slabs = (slab16, slab32)
         enc = x
     else:
         # pre-LN: stream s; every "residual add + next LayerNorm" pair is one fused kernel
@@ -322,6 +347,17 @@ def _pos_table(E, dev):
 
 
 def _qkv_pack(W, pre):
+    q, k, v = W[pre + "self_attn.q_proj.weight"], W[pre + "self_attn.k_proj.weight"], W[pre + "self_attn.v_proj.weight"]
+    qb, kb, vb = W[pre + "self_attn.q_proj.bias"], W[pre + "self_attn.k_proj.bias"], W[pre + "self_attn.v_proj.bias"]
+    esz = q.element_size()
+    if (k.data_ptr() == q.data_ptr() + q.numel() * esz and v.data_ptr() == k.data_ptr() + k.numel() * esz
+            and kb.data_ptr() == qb.data_ptr() + qb.numel() * esz and vb.data_ptr() == kb.data_ptr() + kb.numel() * esz
+            and q.storage_offset() + 3 * q.numel() <= q.untyped_storage().nbytes() // esz):
+        # flat parameter storage keeps q, k, v adjacent: the fused [3E, E] weight is just a view
+        E_ = q.shape[0]
+        wv = torch.as_strided(q, (3 * E_, q.shape[1]), (q.shape[1], 1))
+        bv = torch.as_strided(qb, (3 * E_,), (1,))
+        return wv, bv
     w = torch.cat([W[pre + "self_attn.q_proj.weight"], W[pre + "self_attn.k_proj.weight"], W[pre + "self_attn.v_proj.weight"]], 0)
     b = torch.cat([W[pre + "self_attn.q_proj.bias"], W[pre + "self_attn.k_proj.bias"], W[pre + "self_attn.v_proj.bias"]], 0)
     return w, b
@@ -398,21 +434,49 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen: float = 0.0, d_prob_p
     # ------------------------------------------------------------------ encoder layers, reversed
     post_ln = not cfg.layer_norm_first
     if post_ln:
+        F = cfg.encoder_ffn_embed_dim
         dx = d_enc
-        for rec in reversed(st.layers):
-            li = rec["li"]
-            pre = f"encoder.layers.{li}."
-            d_f, d_x1a = ops.ln_bwd(rec["s2"], W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
-                                    rec["mean2"], rec["rstd2"], A.view(pre + "final_layer_norm.weight"),
-                                    A.view(pre + "final_layer_norm.bias"), dy=dx, want_dres=True, p_drop=p_enc,
-                                    seed=seed(102 + 4 * li))
-            d_hpre = _linear_bwd(d_f, rec["h"], pre + "fc2.weight", pre + "fc2.bias", W, A, dgelu_aux=rec["hpre"])
-            d_x1 = _linear_bwd(d_hpre, rec["x1"], pre + "fc1.weight", pre + "fc1.bias", W, A, add_aux=d_x1a)
-            d_a, d_xin_a = ops.ln_bwd(rec["s1"], W[pre + "self_attn_layer_norm.weight"], W[pre + "self_attn_layer_norm.bias"],
-                                      rec["mean1"], rec["rstd1"], A.view(pre + "self_attn_layer_norm.weight"),
-                                      A.view(pre + "self_attn_layer_norm.bias"), dy=d_x1, want_dres=True, p_drop=p_enc,
-                                      seed=seed(101 + 4 * li))
-            dx = _attn_block_bwd(st, rec, pre, d_a, rec["x_in"], d_xin_a, A)
+        if st.layers:
+            ws = torch.empty(R * (3 * E + F + 3 * E + E) + max(3 * E * E, E * F), device=dev, dtype=BF16)
+            delta = torch.empty(B * H * N, device=dev, dtype=torch.float32)
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            wp = ws.data_ptr()
+            offs = {}
+            o = 0
+            for f_, n_ in (("ws_e0", R * E), ("ws_e1", R * E), ("ws_e2", R * E), ("ws_f", R * F), ("ws_qkv", R * 3 * E),
+                           ("d_in_a", R * E), ("wt_scratch", max(3 * E * E, E * F))):
+                offs[f_] = wp + 2 * o
+                o += n_
+            d_in_bufs = [offs["d_in_a"], None]
+            alt = torch.empty(R, E, device=dev, dtype=BF16)
+            d_in_bufs[1] = alt.data_ptr()
+            cur = dx
+            for jj, rec in enumerate(reversed(st.layers)):
+                li = rec["li"]
+                pre = f"encoder.layers.{li}."
+                d = rec["desc"]
+                d.d_out = cur.data_ptr()
+                tgt = d_in_bufs[jj & 1]
+                d.d_in = tgt
+                for f_ in ("ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch"):
+                    setattr(d, f_, offs[f_])
+                d.delta = delta.data_ptr()
+                off_w = A.offsets[pre + "self_attn.q_proj.weight"][0]
+                off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
+                fp = A.flat.data_ptr()
+                d.g_wqkv, d.g_bqkv = fp + 4 * off_w, fp + 4 * off_b
+                for f_, n_ in (("g_wo", "self_attn.out_proj.weight"), ("g_bo", "self_attn.out_proj.bias"),
+                               ("g_ln1_g", "self_attn_layer_norm.weight"), ("g_ln1_b", "self_attn_layer_norm.bias"),
+                               ("g_w1", "fc1.weight"), ("g_b1", "fc1.bias"), ("g_w2", "fc2.weight"), ("g_b2", "fc2.bias"),
+                               ("g_ln2_g", "final_layer_norm.weight"), ("g_ln2_b", "final_layer_norm.bias")):
+                    setattr(d, f_, fp + 4 * A.offsets[pre + n_][0])
+                _lib.call("w2vs_layer_bwd", C.byref(d), stream)
+                if jj & 1:
+                    cur = alt
+                else:
+                    cur = ws[(3 * R * E + R * F + 3 * R * E):(3 * R * E + R * F + 3 * R * E) + R * E].view(R, E)
+            dx = cur
+            st._bwd_ws = (ws, alt, delta)
         d_x0 = dx
     else:
         d_s = None
