@@ -91,6 +91,7 @@ typedef struct w2vs_ln_bwd_desc {
   const void* dy; const void* dsum; const void* aux;
   void* dx; void* dres; float* dgamma; float* dbeta;
   int64_t rows; int32_t C; int32_t gelu; float p_drop; uint64_t seed; float out_scale; float pen_coef;
+  const float* pen_coef_dev;   /* optional device scalar multiplied into pen_coef (no host sync) */
 } w2vs_ln_bwd_desc;
 int w2vs_ln_fwd(const w2vs_ln_fwd_desc* d, void* stream);
 int w2vs_ln_bwd(const w2vs_ln_bwd_desc* d, void* stream);
@@ -168,6 +169,7 @@ typedef struct w2vs_quant_desc {
   void* q; int32_t* idx; float* hard_cnt; float* prob_sum; float* ppl_out; float* cvec_out;
   const void* dq; const void* dsoft; const float* cvec; void* dlogits; float* dvars;
   float ppl_grad; float tau; int32_t R, G, V, D, training; uint64_t seed;
+  const float* ppl_grad_dev;   /* optional device scalar multiplied into ppl_grad (no host sync) */
 } w2vs_quant_desc;
 int w2vs_quant_fwd(const w2vs_quant_desc* d, void* stream);
 int w2vs_quant_bwd(const w2vs_quant_desc* d, void* stream);

@@ -28,7 +28,8 @@ class LnFwdDesc(C.Structure):
 class LnBwdDesc(C.Structure):
     _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp), ("dy", vp), ("dsum", vp),
                 ("aux", vp), ("dx", vp), ("dres", vp), ("dgamma", vp), ("dbeta", vp), ("rows", i64),
-                ("C", i32), ("gelu", i32), ("p_drop", f32), ("seed", u64), ("out_scale", f32), ("pen_coef", f32)]
+                ("C", i32), ("gelu", i32), ("p_drop", f32), ("seed", u64), ("out_scale", f32), ("pen_coef", f32),
+                ("pen_coef_dev", vp)]
 
 
 class EncPrologueDesc(C.Structure):
@@ -52,7 +53,7 @@ class QuantDesc(C.Structure):
     _fields_ = [("logits", vp), ("noise", vp), ("vars", vp), ("q", vp), ("idx", vp), ("hard_cnt", vp),
                 ("prob_sum", vp), ("ppl_out", vp), ("cvec_out", vp), ("dq", vp), ("dsoft", vp), ("cvec", vp),
                 ("dlogits", vp), ("dvars", vp), ("ppl_grad", f32), ("tau", f32),
-                ("R", i32), ("G", i32), ("V", i32), ("D", i32), ("training", i32), ("seed", u64)]
+                ("R", i32), ("G", i32), ("V", i32), ("D", i32), ("training", i32), ("seed", u64), ("ppl_grad_dev", vp)]
 
 
 class NceDesc(C.Structure):

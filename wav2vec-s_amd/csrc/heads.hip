@@ -35,6 +35,7 @@ struct QuantP {
   bf16* dlogits;        // [R, G*V]
   float* dvars;         // [G*V, D] fp32 accumulators
   float ppl_grad;       // dLoss/d(prob_ppl)
+  const float* ppl_dev;  // optional device multiplier
   int R, G, V, D;
   float tau; int training; uint64_t seed;
 };
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void quant_kernel(QuantP p) {
       dot1 = wave_sum(dot1);
       dot2 = wave_sum(dot2);
       bf16* dl = p.dlogits + row * (long)(G * V) + (long)g * V;
-      const float sc = p.ppl_grad / (float)p.R;
+      const float sc = (p.ppl_dev ? p.ppl_grad * p.ppl_dev[0] : p.ppl_grad) / (float)p.R;
 #pragma unroll
       for (int j = 0; j < QV_MAX; ++j) {
         int v = lane + 64 * j;
@@ -178,7 +179,7 @@ __global__ void quant_finalize_kernel(const float* hard_cnt, const float* prob_s
 static int quant_fill(const QuantDesc& d, QuantP& p) {
   p.logits = (const bf16*)d.logits; p.noise = d.noise; p.vars = (const bf16*)d.vars; p.q = (bf16*)d.q; p.idx = d.idx;
   p.hard_cnt = d.hard_cnt; p.prob_sum = d.prob_sum; p.dq = (const bf16*)d.dq; p.dsoft = (const bf16*)d.dsoft; p.cvec = d.cvec;
-  p.dlogits = (bf16*)d.dlogits; p.dvars = d.dvars; p.ppl_grad = d.ppl_grad; p.R = d.R; p.G = d.G; p.V = d.V; p.D = d.D;
+  p.dlogits = (bf16*)d.dlogits; p.dvars = d.dvars; p.ppl_grad = d.ppl_grad; p.ppl_dev = d.ppl_grad_dev; p.R = d.R; p.G = d.G; p.V = d.V; p.D = d.D;
   p.tau = d.tau; p.training = d.training; p.seed = d.seed;
   if (!p.logits || !p.vars) return set_error("quantizer: null pointer");
   if (p.V > 64 * QV_MAX || p.V < 1) return set_error("quantizer: num_vars per group must be in [1, 320]");

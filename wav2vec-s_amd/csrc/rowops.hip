@@ -242,6 +242,7 @@ struct LnP {
   bf16* dx; bf16* dres; float* dg; float* db;
   float out_scale;    // multiplies dx (GradMultiply)
   float pen_coef;     // d(loss)/d(sum x^2) : adds 2*x*pen_coef to dx
+  const float* pen_dev;  // optional device multiplier of pen_coef
   int gelu;           // fwd: apply GELU after LN; bwd: dy is grad wrt GELU output
   long rows; int C;
 };
@@ -363,14 +364,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
     }
     if (p.dres) store_row(p.dres + row * C, C, lane, dx);
     if (p.dx) {
-      if (p.pen_coef != 0.f || p.out_scale != 1.f) {
+      const float pen = p.pen_dev ? p.pen_coef * p.pen_dev[0] : p.pen_coef;
+      if (pen != 0.f || p.out_scale != 1.f) {
         // x.v currently holds xhat: rebuild the raw input for the penalty term
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float raw = x.v[h][e] / rstd + mean;
-            dx.v[h][e] = (dx.v[h][e] + 2.f * raw * p.pen_coef) * p.out_scale;
+            dx.v[h][e] = (dx.v[h][e] + 2.f * raw * pen) * p.out_scale;
           }
       }
       if (p.p_drop > 0.f) {
@@ -437,7 +439,7 @@ int ln_bwd(const LnBwdDesc& d, hipStream_t st) {
   p.x = (const bf16*)d.x; p.g = (const bf16*)d.gamma; p.b = (const bf16*)d.beta; p.mean = const_cast<float*>(d.mean);
   p.rstd = const_cast<float*>(d.rstd); p.dy = (const bf16*)d.dy; p.dsum = (const bf16*)d.dsum; p.aux = (const bf16*)d.aux;
   p.dx = (bf16*)d.dx; p.dres = (bf16*)d.dres; p.dg = d.dgamma; p.db = d.dbeta; p.p_drop = d.p_drop; p.seed = d.seed;
-  p.out_scale = d.out_scale; p.pen_coef = d.pen_coef; p.gelu = d.gelu; p.rows = d.rows; p.C = d.C;
+  p.out_scale = d.out_scale; p.pen_coef = d.pen_coef; p.pen_dev = d.pen_coef_dev; p.gelu = d.gelu; p.rows = d.rows; p.C = d.C;
   if (!p.x || !p.g || !p.b || !p.mean || !p.rstd || !p.dg || !p.db) return set_error("ln_bwd: null pointer");
   if (int e = ln_check(p, "ln_bwd")) return e;
   int grid = (int)std::min<long>((p.rows + 3) / 4, p.rows > 65536 ? 1024 : 256);

@@ -67,6 +67,28 @@ class State:
     pass
 
 
+def _upload(arrays: Dict[str, np.ndarray], dev) -> Dict[str, torch.Tensor]:
+    """Every host-made index array of a step travels in ONE pinned buffer with ONE async copy, issued
+    before the first kernel launch, so nothing in the step blocks the host on the GPU."""
+    metas, off = [], 0
+    for n, a in arrays.items():
+        a = np.ascontiguousarray(a)
+        metas.append((n, a, off))
+        off += (a.nbytes + 15) // 16 * 16
+    host = torch.empty(max(off, 16), dtype=torch.uint8, pin_memory=True)
+    hv = host.numpy()
+    for n, a, o in metas:
+        hv[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+    devbuf = host.to(dev, non_blocking=True)
+    out = {"_host": host, "_dev": devbuf}
+    tmap = {np.dtype("uint8"): torch.uint8, np.dtype("int32"): torch.int32, np.dtype("int64"): torch.int64,
+            np.dtype("bool"): torch.uint8}
+    for n, a, o in metas:
+        t = devbuf[o:o + a.nbytes].view(tmap[a.dtype]).view(a.shape)
+        out[n] = t
+    return out
+
+
 def _pname(i, tail):
     return f"feature_extractor.conv_layers.{i}.{tail}"
 
@@ -100,6 +122,85 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     st.seed = seed
     st.p = (p_in, p_feat, p_enc, p_att)
 
+    # ------------------------------------------------------------------ host phase (a6, a9, a10, a16, a21)
+    # T follows from L alone, so every host draw (mask -> context -> LayerDrop -> negatives, each from
+    # its own generator in the reference's order) and every index array is made BEFORE the first launch.
+    convs_ = cfg.conv_layers
+    T = L
+    for (_, k_, s_) in convs_:
+        T = (T - k_) // s_ + 1
+    C0 = convs_[-1][0]
+    E = cfg.encoder_embed_dim
+    pad_frames = None
+    if padding_mask is not None:   # padding mask -> frame resolution (wav2vec2.py:560-565)
+        pm = padding_mask.bool().cpu()
+        extra = pm.size(1) % T
+        if extra > 0:
+            pm = pm[:, :-extra]
+        pad_frames = pm.view(pm.size(0), T, -1).all(-1)
+    st.pad_frames = pad_frames
+    mask_np = None
+    if mask and cfg.mask_prob > 0:
+        if draws.mask_indices is not None:
+            mask_np = np.asarray(draws.mask_indices, dtype=bool)
+        else:
+            mask_np = host_rng.compute_mask_indices((B, T), pad_frames, cfg.mask_prob, cfg.mask_length,
+                                                    cfg.mask_selection, cfg.mask_other, min_masks=2,
+                                                    no_overlap=cfg.no_mask_overlap, min_space=cfg.mask_min_space)
+    st.mask_np = mask_np
+    mult = cfg.required_seq_len_multiple
+    Tp = T + ((-T) % mult)
+    m_ctx, r_ctx = draws.context if draws.context is not None else host_rng.sample_context(
+        cfg.context_type, cfg.main_context, cfg.right_context)
+    lay = host_rng.block_layout(Tp, m_ctx, r_ctx)
+    N = lay.N
+    st.Tp, st.N, st.lay, st.m, st.r = Tp, N, lay, m_ctx, r_ctx
+    keep = draws.layer_keep if draws.layer_keep is not None else host_rng.layerdrop_keep(
+        cfg.encoder_layers, cfg.encoder_layerdrop, training)
+    st.kept = [i for i in range(cfg.encoder_layers) if keep[i]]
+    pad_np = None
+    if pad_frames is not None or Tp != T:
+        pad_np = np.zeros((B, Tp), dtype=bool)
+        if pad_frames is not None:
+            pad_np[:, :T] = pad_frames.numpy()
+        pad_np[:, T:] = True               # wav2vec_S.py:378-384
+    kpad_np = lay.key_padding(pad_np, B)
+    up = {"pos": host_rng.positions_from_padding(pad_frames, B, T).numpy(), "src": lay.src,
+          "copy_start": lay.copy_start, "copy_list": lay.copy_list}
+    if mask_np is not None:
+        up["mask"] = mask_np.astype(np.uint8)
+    if kpad_np is not None:
+        up["kpad"] = kpad_np
+    if pad_frames is not None:
+        up["pad"] = pad_frames.numpy().astype(np.uint8)
+    if features_only:
+        up["out_idx"] = (np.arange(B)[:, None] * N + np.arange(T)[None, :]).reshape(-1).astype(np.int32)
+    else:
+        if mask_np is None:
+            raise W2vsError("the pre-training head needs mask=True and mask_prob > 0")
+        if not cfg.quantize_targets:
+            raise W2vsError("quantize_targets=False is not built (wav2vec-S pre-training quantizes targets)")
+        bidx, tidx = np.nonzero(mask_np)
+        M = len(tidx) // B
+        st.M, st.K = M, cfg.num_negatives
+        up["frame_idx"] = (bidx * T + tidx).astype(np.int32)      # rows of [B*T, .]
+        up["token_idx"] = (bidx * N + tidx).astype(np.int32)      # rows of [B*N, .]
+        neg = draws.neg_idx if draws.neg_idx is not None else host_rng.sample_negative_indices(B, M, st.K)
+        up["neg"] = neg.numpy() if torch.is_tensor(neg) and not neg.is_cuda else None
+        if up["neg"] is None:
+            del up["neg"]
+            st.neg = neg
+    st.up = _upload(up, dev)
+    if "neg" in st.up:
+        st.neg = st.up["neg"]
+    mask_dev = st.up.get("mask")
+    st.mask_dev = mask_dev
+    st.kpad = st.up.get("kpad")
+    st.pad_dev = st.up.get("pad")
+    pos = st.up["pos"]
+    st.pos = pos
+    st.src, st.copy_start, st.copy_list = st.up["src"], st.up["copy_start"], st.up["copy_list"]
+
     # ------------------------------------------------------------------ feature extractor (a1)
     ln_num = cfg.layer_norm_num
     st.conv = []
@@ -131,7 +232,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         st.conv.append(rec)
         x = y
     y_last = x                                   # [B, T, C0] post-GELU features
-    _, T, C0 = y_last.shape
+    assert y_last.shape[1] == T and y_last.shape[2] == C0
     st.B, st.T, st.C0 = B, T, C0
 
     # ------------------------------------------------------------------ features_pen + LayerNorm (a3, a4)
@@ -139,66 +240,15 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     feats, _, st.f_mean, st.f_rstd = ops.ln_fwd(y_last, W["layer_norm.weight"], W["layer_norm.bias"], sumsq=st.pen_acc)
     st.y_last, st.feats = y_last, feats
 
-    # padding mask -> frame resolution (wav2vec2.py:560-565)
-    pad_frames = None
-    if padding_mask is not None:
-        pm = padding_mask.bool().cpu()
-        extra = pm.size(1) % T
-        if extra > 0:
-            pm = pm[:, :-extra]
-        pad_frames = pm.view(pm.size(0), T, -1).all(-1)
-        if not bool(pad_frames.any()):
-            pad_frames = pad_frames  # keep: the reference still passes it on
-    st.pad_frames = pad_frames
-
     # ------------------------------------------------------------------ post_extract_proj (a5)
-    E = cfg.encoder_embed_dim
     if "post_extract_proj.weight" in W:
         xproj = ops.linear_fwd(feats.view(B * T, C0), W["post_extract_proj.weight"], W["post_extract_proj.bias"]).view(B, T, E)
     else:
         xproj = feats
     st.xproj = xproj
 
-    # ------------------------------------------------------------------ mask (a6) host draw
-    mask_np = None
-    if mask and cfg.mask_prob > 0:
-        if draws.mask_indices is not None:
-            mask_np = np.asarray(draws.mask_indices, dtype=bool)
-        else:
-            mask_np = host_rng.compute_mask_indices((B, T), pad_frames, cfg.mask_prob, cfg.mask_length,
-                                                    cfg.mask_selection, cfg.mask_other, min_masks=2,
-                                                    no_overlap=cfg.no_mask_overlap, min_space=cfg.mask_min_space)
-    st.mask_np = mask_np
-    mask_dev = torch.from_numpy(mask_np.astype(np.uint8)).to(dev) if mask_np is not None else None
-    st.mask_dev = mask_dev
-
     # ------------------------------------------------------------------ encoder prologue (a7-a10)
-    mult = cfg.required_seq_len_multiple
-    Tp = T + ((-T) % mult)
-    m_ctx, r_ctx = draws.context if draws.context is not None else host_rng.sample_context(
-        cfg.context_type, cfg.main_context, cfg.right_context)
-    lay = host_rng.block_layout(Tp, m_ctx, r_ctx)
-    N = lay.N
-    st.Tp, st.N, st.lay, st.m, st.r = Tp, N, lay, m_ctx, r_ctx
-    pad_np = None
-    if pad_frames is not None or Tp != T:
-        pad_np = np.zeros((B, Tp), dtype=bool)
-        if pad_frames is not None:
-            pad_np[:, :T] = pad_frames.numpy()
-        if Tp != T:
-            if pad_frames is None:
-                pad_np[:, T:] = True       # wav2vec_S.py:378-380
-            else:
-                pad_np[:, T:] = True       # wav2vec_S.py:382-384 (value=True)
-    kpad_np = lay.key_padding(pad_np, B)
-    st.kpad = torch.from_numpy(kpad_np).to(dev) if kpad_np is not None else None
-    st.pad_dev = torch.from_numpy(pad_frames.numpy().astype(np.uint8)).to(dev) if pad_frames is not None else None
-    pos = host_rng.positions_from_padding(pad_frames, B, T).to(dev)
-    st.pos = pos
     table = _pos_table(E, dev)
-    st.src = torch.from_numpy(lay.src).to(dev)
-    st.copy_start = torch.from_numpy(lay.copy_start).to(dev)
-    st.copy_list = torch.from_numpy(lay.copy_list).to(dev)
     post_ln = not cfg.layer_norm_first
     x0, st.p_mean, st.p_rstd = ops.enc_prologue_fwd(
         xproj, mask_dev, st.pad_dev, pos, W["mask_emb"], table, W["encoder.layer_norm.weight"],
@@ -206,9 +256,6 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         seed_enc=seed(2))
 
     # ------------------------------------------------------------------ encoder layers (a11, a12)
-    keep = draws.layer_keep if draws.layer_keep is not None else host_rng.layerdrop_keep(
-        cfg.encoder_layers, cfg.encoder_layerdrop, training)
-    st.kept = [i for i in range(cfg.encoder_layers) if keep[i]]
     H = cfg.encoder_attention_heads
     R = B * N
     st.layers = []
@@ -293,21 +340,13 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     st.enc = enc                           # [B*N, E]
 
     if features_only:
-        idx = (torch.arange(B, device=dev).view(B, 1) * N + torch.arange(T, device=dev).view(1, T)).reshape(-1).int()
-        st.out_idx = idx
-        st.out_x = ops.gather_rows(enc, idx, B * T).view(B, T, E)
+        st.out_idx = st.up["out_idx"]
+        st.out_x = ops.gather_rows(enc, st.out_idx, B * T).view(B, T, E)
         return st
 
     # ------------------------------------------------------------------ loss head (a14-a18)
-    if mask_np is None:
-        raise W2vsError("the pre-training head needs mask=True and mask_prob > 0")
-    if not cfg.quantize_targets:
-        raise W2vsError("quantize_targets=False is not built (wav2vec-S pre-training quantizes targets)")
-    bidx, tidx = np.nonzero(mask_np)
-    M = len(tidx) // B
-    st.M = M
-    frame_idx = torch.from_numpy((bidx * T + tidx).astype(np.int32)).to(dev)     # rows of [B*T, .]
-    token_idx = torch.from_numpy((bidx * N + tidx).astype(np.int32)).to(dev)     # rows of [B*N, .]
+    M, K = st.M, st.K
+    frame_idx, token_idx = st.up["frame_idx"], st.up["token_idx"]
     st.frame_idx, st.token_idx = frame_idx, token_idx
     RM = B * M
     y_in = ops.gather_rows(feats.view(B * T, C0), frame_idx, RM)
@@ -328,10 +367,8 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     xm = ops.gather_rows(enc, token_idx, RM)
     xf = ops.linear_fwd(xm, W["final_proj.weight"], W["final_proj.bias"])
     st.yq, st.xm, st.xf = yq, xm, xf
-    K = cfg.num_negatives
-    neg = draws.neg_idx if draws.neg_idx is not None else host_rng.sample_negative_indices(B, M, K)
-    st.neg = neg.to(dev)
-    st.K = K
+    if not st.neg.is_cuda:
+        st.neg = st.neg.to(dev)
     st.logits, st.nce_norms = ops.nce_fwd(xf, yq, st.neg, B, M, K, cfg.logit_temp)   # [B*M, K+1] rows (b, m)
     return st
 
@@ -394,10 +431,10 @@ def _linear_bwd(dy, x, w_name, b_name, W, A, *, need_dx=True, dgelu_aux=None, ad
     return ops.linear_dgrad(dy, wt, dgelu_aux=dgelu_aux, add_aux=add_aux)
 
 
-def backward(st: State, A: Arena, *, d_logits=None, d_pen: float = 0.0, d_prob_ppl: float = 0.0, d_out=None):
+def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None, d_out=None):
     """Accumulates parameter gradients into the arena.  d_logits fp32 [B*M, K+1] (rows (b, m));
-    d_pen = dLoss/d features_pen, d_prob_ppl = dLoss/d prob_perplexity (host floats); d_out bf16
-    [B, T, E] for features_only."""
+    d_pen = dLoss/d features_pen, d_prob_ppl = dLoss/d prob_perplexity as fp32 DEVICE scalars (read by
+    the kernels, never by the host: no sync); d_out bf16 [B, T, E] for features_only."""
     cfg, W = st.cfg, st.W
     B, T, C0, N, Tp = st.B, st.T, st.C0, st.N, st.Tp
     E = cfg.encoder_embed_dim
@@ -423,8 +460,10 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen: float = 0.0, d_prob_p
         # quantizer
         G, V = cfg.latent_groups, cfg.latent_vars
         vars2d = W["quantizer.vars"].view(G * V, -1)
-        dql = ops.quant_bwd(dq, st.q_logits, vars2d, st.qst, G, V, st.tau, st.training, d_prob_ppl,
-                            A.view("quantizer.vars").view(G * V, -1), noise=st.noise, seed=seed(4))
+        dql = ops.quant_bwd(dq, st.q_logits, vars2d, st.qst, G, V, st.tau, st.training,
+                            1.0 if d_prob_ppl is not None else 0.0,
+                            A.view("quantizer.vars").view(G * V, -1), noise=st.noise, seed=seed(4),
+                            ppl_grad_dev=d_prob_ppl)
         d_yin = _linear_bwd(dql, st.y_in, "quantizer.weight_proj.weight", "quantizer.weight_proj.bias", W, A)
         if p_feat > 0:
             d_yin = ops.dropout(d_yin, p_feat, seed(3))
@@ -539,7 +578,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen: float = 0.0, d_prob_p
     aux = last.get("pre") if (len(st.conv) > 1 and not last["ln"]) else None
     d_cur, _ = ops.ln_bwd(st.y_last, W["layer_norm.weight"], W["layer_norm.bias"], st.f_mean, st.f_rstd,
                           A.view("layer_norm.weight"), A.view("layer_norm.bias"), dy=d_feats, aux=aux, out_scale=gm,
-                          pen_coef=d_pen / numel)
+                          pen_coef=(1.0 / numel) if d_pen is not None else 0.0, pen_coef_dev=d_pen)
     # d_cur: grad wrt conv_i pre-activation (plain layers) or wrt conv_i's post-GELU output (LN layers / layer 0)
     for i in range(len(convs) - 1, 0, -1):
         rec = st.conv[i]

@@ -232,8 +232,8 @@ class _HotPath(torch.autograd.Function):
         else:
             d_logits, d_pen, d_ppl = grads[0], grads[1], grads[2]
             d_logits = torch.zeros_like(st.logits) if d_logits is None else d_logits.float().contiguous()
-            engine.backward(st, A, d_logits=d_logits, d_pen=0.0 if d_pen is None else float(d_pen),
-                            d_prob_ppl=0.0 if d_ppl is None else float(d_ppl))
+            fix = lambda t: None if t is None else t.detach().float().reshape(1).contiguous()  # noqa: E731
+            engine.backward(st, A, d_logits=d_logits, d_pen=fix(d_pen), d_prob_ppl=fix(d_ppl))
         if flat_mode:
             ctx.st = None
             return (None,) * (6 + len(names))   # gradients stay in the arena (see trainer.FlatParams)

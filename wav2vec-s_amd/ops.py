@@ -279,7 +279,7 @@ def ln_fwd(x, gamma, beta, *, res=None, want_y=True, want_sum=False, sumsq=None,
 
 
 def ln_bwd(x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy=None, dsum=None, aux=None, want_dx=True,
-           want_dres=False, gelu=False, p_drop=0.0, seed=0, out_scale=1.0, pen_coef=0.0):
+           want_dres=False, gelu=False, p_drop=0.0, seed=0, out_scale=1.0, pen_coef=0.0, pen_coef_dev=None):
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(dsum, BF16, "dsum"); _chk(aux, BF16, "aux")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
@@ -289,6 +289,7 @@ def ln_bwd(x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy=None, dsum=None, aux
     d.x, d.gamma, d.beta, d.mean, d.rstd = _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd)
     d.dy, d.dsum, d.aux, d.dx, d.dres, d.dgamma, d.dbeta = _p(dy), _p(dsum), _p(aux), _p(dx), _p(dres), _p(dgamma), _p(dbeta)
     d.rows, d.C, d.gelu, d.p_drop, d.seed, d.out_scale, d.pen_coef = rows, Cc, int(gelu), p_drop, seed, out_scale, pen_coef
+    d.pen_coef_dev = _p(pen_coef_dev)
     _lib.call("w2vs_ln_bwd", C.byref(d), _stream())
     return dx, dres
 
@@ -399,7 +400,7 @@ def quant_fwd(logits, vars2d, G, V, tau, training, noise=None, seed=0):
     return q, st
 
 
-def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, noise=None, seed=0):
+def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, noise=None, seed=0, ppl_grad_dev=None):
     """Returns dlogits [R, G*V] bf16; accumulates dvars (fp32 [G*V, D])."""
     _chk(dq, BF16, "dq")
     R = logits.shape[0]
@@ -415,6 +416,7 @@ def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, 
     d.logits, d.noise, d.vars = _p(logits), _p(noise), _p(vars2d)
     d.prob_sum, d.dq, d.dsoft, d.cvec, d.dlogits, d.dvars = _p(st.prob_sum), _p(dq), _p(dsoft), _p(st.cvec), _p(dlogits), _p(dvars_f32)
     d.ppl_grad, d.tau, d.R, d.G, d.V, d.D, d.training, d.seed = ppl_grad, tau, R, G, V, D, int(training), seed
+    d.ppl_grad_dev = _p(ppl_grad_dev)
     _lib.call("w2vs_quant_bwd", C.byref(d), _stream())
     return dlogits
 
