@@ -236,7 +236,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     st.B, st.T, st.C0 = B, T, C0
 
     # ------------------------------------------------------------------ features_pen + LayerNorm (a3, a4)
-    st.pen_acc = torch.zeros(1, device=dev, dtype=torch.float32)
+    st.pen_acc = ops.zeros((4,), torch.float32, dev)[:1]
     feats, _, st.f_mean, st.f_rstd = ops.ln_fwd(y_last, W["layer_norm.weight"], W["layer_norm.bias"], sumsq=st.pen_acc)
     st.y_last, st.feats = y_last, feats
 
@@ -266,9 +266,9 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         nk = len(st.kept)
         # one bf16 slab and one fp32 slab hold every saved activation of every kept layer
         per16 = R * (8 * E + 2 * F)
-        slab16 = torch.empty(max(nk, 1) * per16 + R * E, device=dev, dtype=BF16)
+        slab16 = ops.empty((max(nk, 1) * per16 + R * E,), BF16, dev)
         per32 = B * H * N + 4 * R
-        slab32 = torch.empty(max(nk, 1) * per32, device=dev, dtype=torch.float32)
+        slab32 = ops.empty((max(nk, 1) * per32,), torch.float32, dev)
         st.tmp = slab16[max(nk, 1) * per16:]
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         kpad_ptr = st.kpad.data_ptr() if st.kpad is not None else None
@@ -443,7 +443,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
     p_in, p_feat, p_enc, p_att = st.p
     seed = st.seed
     R = B * N
-    d_enc = torch.zeros(R, E, device=dev, dtype=BF16)
+    d_enc = ops.zeros((R, E), BF16, dev)
     d_feats_unmasked = None
 
     if st.features_only:
@@ -467,7 +467,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         d_yin = _linear_bwd(dql, st.y_in, "quantizer.weight_proj.weight", "quantizer.weight_proj.bias", W, A)
         if p_feat > 0:
             d_yin = ops.dropout(d_yin, p_feat, seed(3))
-        d_feats_unmasked = torch.zeros(B * T, C0, device=dev, dtype=BF16)
+        d_feats_unmasked = ops.zeros((B * T, C0), BF16, dev)
         ops.gather_rows(d_yin, st.frame_idx, RM, scatter=True, out=d_feats_unmasked)
 
     # ------------------------------------------------------------------ encoder layers, reversed
@@ -476,8 +476,8 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         F = cfg.encoder_ffn_embed_dim
         dx = d_enc
         if st.layers:
-            ws = torch.empty(R * (3 * E + F + 3 * E + E) + max(3 * E * E, E * F), device=dev, dtype=BF16)
-            delta = torch.empty(B * H * N, device=dev, dtype=torch.float32)
+            ws = ops.empty((R * (3 * E + F + 3 * E + E) + max(3 * E * E, E * F),), BF16, dev)
+            delta = ops.empty((B * H * N,), torch.float32, dev)
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             wp = ws.data_ptr()
             offs = {}
@@ -487,7 +487,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 offs[f_] = wp + 2 * o
                 o += n_
             d_in_bufs = [offs["d_in_a"], None]
-            alt = torch.empty(R, E, device=dev, dtype=BF16)
+            alt = ops.empty((R, E), BF16, dev)
             d_in_bufs[1] = alt.data_ptr()
             cur = dx
             for jj, rec in enumerate(reversed(st.layers)):

@@ -15,6 +15,59 @@ from ._lib import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGE
 BF16 = torch.bfloat16
 
 
+class _StepArena:
+    """Bump allocator for the activations / scratch of one training step.
+
+    Sampled block contexts change the token count N every step; through torch's caching allocator
+    that means fresh multi-GB hipMalloc/hipFree pairs (device-synchronising) per step.  When active,
+    every buffer the kernels write comes from ONE preallocated slab that is rewound at step start -
+    288 GB of HBM3E makes reserving the worst case trivial.  Inactive (default): plain torch.empty."""
+
+    def __init__(self):
+        self.buf, self.off, self.cap = None, 0, 0
+
+    def activate(self, nbytes, device):
+        if self.buf is None or self.cap < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.cap = nbytes
+        self.off = 0
+
+    def deactivate(self):
+        self.buf, self.off, self.cap = None, 0, 0
+
+    def reset(self):
+        self.off = 0
+
+    def empty(self, shape, dtype, device):
+        if isinstance(shape, int):
+            shape = (shape,)
+        if self.buf is None:
+            return torch.empty(shape, device=device, dtype=dtype)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * _ITEMSIZE[dtype]
+        start = (self.off + 255) & ~255
+        if start + nbytes > self.cap:
+            return torch.empty(shape, device=device, dtype=dtype)   # overflow: fall back to the allocator
+        self.off = start + nbytes
+        return self.buf[start:start + nbytes].view(dtype).view(shape)
+
+
+_ITEMSIZE = {torch.bfloat16: 2, torch.float32: 4, torch.int32: 4, torch.int64: 8, torch.uint8: 1, torch.float16: 2}
+ARENA = _StepArena()
+
+
+def empty(shape, dtype, device):
+    return ARENA.empty(shape, dtype, device)
+
+
+def zeros(shape, dtype, device):
+    t = ARENA.empty(shape, dtype, device)
+    t.zero_()
+    return t
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -121,8 +174,8 @@ def linear_fwd(x, w, bias=None, *, gelu=False, save_pre=False):
     _chk(x, BF16, "x"); _chk(w, BF16, "w"); _chk(bias, BF16, "bias")
     R, K = x.shape
     N = w.shape[0]
-    y = torch.empty(R, N, device=x.device, dtype=BF16)
-    pre = torch.empty_like(y) if save_pre else None
+    y = empty((R, N), BF16, x.device)
+    pre = empty(y.shape, y.dtype, y.device) if save_pre else None
     epi = EPI_BIAS if not gelu else (EPI_BIAS_GELU_SAVE if save_pre else EPI_BIAS_GELU)
     gemm_nt(x, w, M=R, N=N, K=K, lda=K, ldb=K, ldc=N, out=y, out2=pre, bias=bias, epi=epi)
     return (y, pre) if save_pre else y
@@ -133,7 +186,7 @@ def linear_dgrad(dy, w_t, *, dgelu_aux=None, add_aux=None):
     _chk(dy, BF16, "dy"); _chk(w_t, BF16, "w_t"); _chk(dgelu_aux, BF16, "aux"); _chk(add_aux, BF16, "aux")
     R, N = dy.shape
     K = w_t.shape[0]
-    dx = torch.empty(R, K, device=dy.device, dtype=BF16)
+    dx = empty((R, K), BF16, dy.device)
     epi, aux = EPI_NONE, None
     if dgelu_aux is not None:
         epi, aux = EPI_DGELU, dgelu_aux
@@ -161,14 +214,14 @@ def transpose2d(x, batch=1):
     """[batch, R, C] -> [batch, C, R] (bf16)."""
     _chk(x, BF16, "x")
     R, Cc = x.shape[-2], x.shape[-1]
-    out = torch.empty(*x.shape[:-2], Cc, R, device=x.device, dtype=BF16)
+    out = empty((*x.shape[:-2], Cc, R), BF16, x.device)
     _lib.call("w2vs_transpose2d", _p(x), _p(out), R, Cc, batch, _stream())
     return out
 
 
 def f32_to_bf16(x, scale=1.0):
     _chk(x, torch.float32, "x")
-    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    out = empty((x.shape), BF16, x.device)
     _lib.call("w2vs_f32_to_bf16", _p(x), _p(out), x.numel(), scale, _stream())
     return out
 
@@ -187,8 +240,8 @@ def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True):
     B, Lin, Cin = x.shape
     Cout = w2.shape[0]
     Lout = (Lin - k) // s + 1
-    y = torch.empty(B, Lout, Cout, device=x.device, dtype=BF16)
-    pre = torch.empty_like(y) if save_pre else None
+    y = empty((B, Lout, Cout), BF16, x.device)
+    pre = empty(y.shape, y.dtype, y.device) if save_pre else None
     if gelu:
         epi = EPI_BIAS_GELU_SAVE if save_pre else EPI_BIAS_GELU
     else:
@@ -205,7 +258,7 @@ def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None):
     _chk(dy, BF16, "dy"); _chk(w2, BF16, "w2")
     B, Lout, Cout = dy.shape
     Cin = w2.shape[1] // k
-    dx = torch.empty(B, Lin, Cin, device=dy.device, dtype=BF16)
+    dx = empty((B, Lin, Cin), BF16, dy.device)
     epi = EPI_DGELU if dgelu_aux is not None else EPI_NONE
     wt = transpose2d(w2)  # [k*Cin, Cout]: row (j*Cin + ci) = w[:, ci, j]
     if (k, s) == (2, 2):
@@ -217,7 +270,7 @@ def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None):
         # B operand [N = 2*Cin, K = 2*Cout]: row-half 0 = [W2^T | W0^T], row-half 1 = [0 | W1^T]
         # (K index 0..Cout-1 multiplies dy[p-1], Cout..2Cout-1 multiplies dy[p])
         wt3 = wt.view(3, Cin, Cout)
-        bt = torch.zeros(2, Cin, 2, Cout, device=dy.device, dtype=BF16)
+        bt = zeros((2, Cin, 2, Cout), BF16, dy.device)
         bt[0, :, 0] = wt3[2]
         bt[0, :, 1] = wt3[0]
         bt[1, :, 1] = wt3[1]
@@ -245,9 +298,9 @@ def conv0_fwd(wave, w, ln_w, ln_b, k, s, conv_bias=None):
     B, L = wave.shape
     Cc = w.shape[0]
     L0 = (L - k) // s + 1
-    y = torch.empty(B, L0, Cc, device=wave.device, dtype=BF16)
-    mean = torch.empty(B * L0, device=wave.device, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
+    y = empty((B, L0, Cc), BF16, wave.device)
+    mean = empty((B * L0), torch.float32, wave.device)
+    rstd = empty(mean.shape, mean.dtype, mean.device)
     _lib.call("w2vs_conv0_fwd", _p(wave), _p(w), _p(conv_bias), _p(ln_w), _p(ln_b), _p(y), _p(mean), _p(rstd),
               B, L, Cc, k, s, _stream())
     return y, mean, rstd
@@ -266,10 +319,10 @@ def ln_fwd(x, gamma, beta, *, res=None, want_y=True, want_sum=False, sumsq=None,
     _chk(x, BF16, "x"); _chk(res, BF16, "res"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
-    y = torch.empty_like(x) if want_y else None
-    s_out = torch.empty_like(x) if want_sum else None
-    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if want_y else None
-    rstd = torch.empty_like(mean) if want_y else None
+    y = empty(x.shape, x.dtype, x.device) if want_y else None
+    s_out = empty(x.shape, x.dtype, x.device) if want_sum else None
+    mean = empty((rows), torch.float32, x.device) if want_y else None
+    rstd = empty(mean.shape, mean.dtype, mean.device) if want_y else None
     d = LnFwdDesc()
     d.x, d.res, d.gamma, d.beta, d.y, d.sum_out = _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(s_out)
     d.mean, d.rstd, d.sumsq = _p(mean), _p(rstd), _p(sumsq)
@@ -283,8 +336,8 @@ def ln_bwd(x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy=None, dsum=None, aux
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(dsum, BF16, "dsum"); _chk(aux, BF16, "aux")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
-    dx = torch.empty_like(x) if want_dx else None
-    dres = torch.empty_like(x) if want_dres else None
+    dx = empty(x.shape, x.dtype, x.device) if want_dx else None
+    dres = empty(x.shape, x.dtype, x.device) if want_dres else None
     d = LnBwdDesc()
     d.x, d.gamma, d.beta, d.mean, d.rstd = _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd)
     d.dy, d.dsum, d.aux, d.dx, d.dres, d.dgamma, d.dbeta = _p(dy), _p(dsum), _p(aux), _p(dx), _p(dres), _p(dgamma), _p(dbeta)
@@ -311,9 +364,9 @@ def enc_prologue_fwd(x, mask, pad, pos, mask_emb, pos_table, gamma, beta, src, T
     _chk(pos_table, torch.float32, "pos_table"); _chk(src, torch.int32, "src")
     B, T, Cc = x.shape
     N = src.numel()
-    out = torch.empty(B, N, Cc, device=x.device, dtype=BF16)
-    mean = torch.empty(B * T, device=x.device, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
+    out = empty((B, N, Cc), BF16, x.device)
+    mean = empty((B * T), torch.float32, x.device)
+    rstd = empty(mean.shape, mean.dtype, mean.device)
     d = _encpro_desc(x, mask, pad, pos, mask_emb, pos_table, gamma, beta, mean, rstd, src, p_in, seed_in, p_enc,
                      seed_enc, apply_ln, B, T, Tp, N, Cc)
     d.out = _p(out)
@@ -326,7 +379,7 @@ def enc_prologue_bwd(dout, x, mask, pad, pos, mask_emb, pos_table, gamma, beta, 
     _chk(dout, BF16, "dout")
     B, T, Cc = x.shape
     N = src.numel()
-    dx = torch.empty_like(x)
+    dx = empty(x.shape, x.dtype, x.device)
     d = _encpro_desc(x, mask, pad, pos, mask_emb, pos_table, gamma, beta, mean, rstd, src, p_in, seed_in, p_enc,
                      seed_enc, apply_ln, B, T, Tp, N, Cc)
     d.dout, d.dx, d.dmask_emb, d.dgamma, d.dbeta = _p(dout), _p(dx), _p(dmask_emb), _p(dgamma), _p(dbeta)
@@ -353,8 +406,8 @@ def attn_fwd(qkv, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
     """qkv [B, N, 3C] bf16 (q | k | v).  Returns ctx [B, N, C] and lse [B, H, N]."""
     _chk(qkv, BF16, "qkv"); _chk(kpad, torch.uint8, "kpad")
     B, N, C3 = qkv.shape
-    o = torch.empty(B, N, C3 // 3, device=qkv.device, dtype=BF16)
-    lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    o = empty((B, N, C3 // 3), BF16, qkv.device)
+    lse = empty((B, H, N), torch.float32, qkv.device)
     d = _attn_desc(qkv, o, lse, kpad, H, Tp, m, r, p_drop, seed)
     _lib.call("w2vs_attn_fwd", C.byref(d), _stream())
     return o, lse
@@ -364,8 +417,8 @@ def attn_bwd(dout, qkv, o, lse, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
     _chk(dout, BF16, "dout"); _chk(qkv, BF16, "qkv"); _chk(o, BF16, "o")
     B, N, C3 = qkv.shape
     Cc = C3 // 3
-    dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    dqkv = empty(qkv.shape, qkv.dtype, qkv.device)
+    delta = empty((B, H, N), torch.float32, qkv.device)
     d = _attn_desc(qkv, o, lse, kpad, H, Tp, m, r, p_drop, seed)
     base = dqkv.data_ptr()
     d.dout, d.delta = _p(dout), _p(delta)
@@ -385,13 +438,13 @@ def quant_fwd(logits, vars2d, G, V, tau, training, noise=None, seed=0):
     R = logits.shape[0]
     D = vars2d.shape[1]
     dev = logits.device
-    q = torch.empty(R, G * D, device=dev, dtype=BF16)
+    q = empty((R, G * D), BF16, dev)
     st = QuantState()
-    st.idx = torch.empty(R, G, device=dev, dtype=torch.int32)
-    st.hard_cnt = torch.empty(G * V, device=dev, dtype=torch.float32)
-    st.prob_sum = torch.empty(G * V, device=dev, dtype=torch.float32)
-    st.ppl = torch.empty(2, device=dev, dtype=torch.float32)
-    st.cvec = torch.empty(G * V, device=dev, dtype=torch.float32)
+    st.idx = empty((R, G), torch.int32, dev)
+    st.hard_cnt = empty((G * V), torch.float32, dev)
+    st.prob_sum = empty((G * V), torch.float32, dev)
+    st.ppl = empty((2), torch.float32, dev)
+    st.cvec = empty((G * V), torch.float32, dev)
     d = QuantDesc()
     d.logits, d.noise, d.vars, d.q, d.idx = _p(logits), _p(noise), _p(vars2d), _p(q), _p(st.idx)
     d.hard_cnt, d.prob_sum, d.ppl_out, d.cvec_out = _p(st.hard_cnt), _p(st.prob_sum), _p(st.ppl), _p(st.cvec)
@@ -407,11 +460,11 @@ def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, 
     D = vars2d.shape[1]
     dsoft = None
     if training:
-        dsoft = torch.empty(R, G * V, device=dq.device, dtype=BF16)
+        dsoft = empty((R, G * V), BF16, dq.device)
         # dsoft[:, g] = dq[:, g] @ vars_g^T : batched over groups through column-offset strides
         gemm_nt(dq, vars2d, M=R, N=V, K=D, lda=G * D, ldb=D, ldc=G * V, out=dsoft, batch=G, sA=D, sB=V * D, sC=V,
                 a_bytes=(R * G * D) * 2, b_bytes=V * D * 2, c_elems=R * G * V)
-    dlogits = torch.empty(R, G * V, device=dq.device, dtype=BF16)
+    dlogits = empty((R, G * V), BF16, dq.device)
     d = QuantDesc()
     d.logits, d.noise, d.vars = _p(logits), _p(noise), _p(vars2d)
     d.prob_sum, d.dq, d.dsoft, d.cvec, d.dlogits, d.dvars = _p(st.prob_sum), _p(dq), _p(dsoft), _p(st.cvec), _p(dlogits), _p(dvars_f32)
@@ -426,8 +479,8 @@ def nce_fwd(x, y, neg_idx, B, M, K, temp):
     """x, y [B*M, C] bf16; neg_idx [B, K*M] int64 -> logits [B*M, K+1] fp32 and the saved row norms."""
     _chk(x, BF16, "x"); _chk(y, BF16, "y"); _chk(neg_idx, torch.int64, "neg_idx")
     Cc = x.shape[1]
-    logits = torch.empty(B * M, K + 1, device=x.device, dtype=torch.float32)
-    norms = torch.empty(2, B * M, device=x.device, dtype=torch.float32)
+    logits = empty((B * M, K + 1), torch.float32, x.device)
+    norms = empty((2, B * M), torch.float32, x.device)
     d = NceDesc()
     d.x, d.y, d.neg_idx, d.logits = _p(x), _p(y), _p(neg_idx), _p(logits)
     d.xn, d.yn = _p(norms[0]), _p(norms[1])
@@ -440,8 +493,8 @@ def nce_bwd(dlogits, logits, norms, x, y, neg_idx, B, M, K, temp):
     """Returns dx, dy bf16 [B*M, C]."""
     _chk(dlogits, torch.float32, "dlogits"); _chk(logits, torch.float32, "logits")
     Cc = x.shape[1]
-    dx = torch.empty(B * M, Cc, device=x.device, dtype=BF16)
-    dy = torch.empty(B * M, Cc, device=x.device, dtype=BF16)
+    dx = empty((B * M, Cc), BF16, x.device)
+    dy = empty((B * M, Cc), BF16, x.device)
     d = NceDesc()
     d.x, d.y, d.neg_idx, d.logits, d.dlogits, d.dx, d.dy = _p(x), _p(y), _p(neg_idx), _p(logits), _p(dlogits), _p(dx), _p(dy)
     d.xn, d.yn = _p(norms[0]), _p(norms[1])
@@ -454,15 +507,15 @@ def ce_rows(logits, want_grad=True):
     """Cross entropy (target 0, sum) of fp32 logits [R, W].  Returns out3 = [loss, n_max0, n_both0], dlogits."""
     _chk(logits, torch.float32, "logits")
     R, W = logits.shape
-    out3 = torch.empty(3, device=logits.device, dtype=torch.float32)
-    dl = torch.empty_like(logits) if want_grad else None
+    out3 = empty((3), torch.float32, logits.device)
+    dl = empty(logits.shape, logits.dtype, logits.device) if want_grad else None
     _lib.call("w2vs_ce_rows", _p(logits), R, W, _p(out3), _p(dl), _stream())
     return out3, dl
 
 
 def dropout(x, p, seed):
     _chk(x, BF16, "x")
-    out = torch.empty_like(x)
+    out = empty(x.shape, x.dtype, x.device)
     _lib.call("w2vs_dropout", _p(x), _p(out), x.numel(), p, seed, _stream())
     return out
 
@@ -485,6 +538,6 @@ def gather_rows(src, idx, R, scatter=False, out=None):
     if out is None:
         if scatter:
             raise W2vsError("scatter needs a pre-zeroed destination")
-        out = torch.empty(R, Cc, device=src.device, dtype=BF16)
+        out = empty((R, Cc), BF16, src.device)
     _lib.call("w2vs_gather_rows", _p(src), _p(idx), _p(out), R, Cc, int(scatter), _stream())
     return out

@@ -57,7 +57,7 @@ class TrainStep:
     with update_freq = 1 (the bench's step)."""
 
     def __init__(self, model, criterion, world_size=1, use_optimizer=True, lr=5e-4, betas=(0.9, 0.98), eps=1e-6,
-                 weight_decay=0.01, clip_norm=0.0):
+                 weight_decay=0.01, clip_norm=0.0, arena_gib=12.0):
         self.model, self.criterion, self.world = model, criterion, world_size
         self.flat = FlatParams(model)
         self.use_optimizer = use_optimizer
@@ -67,9 +67,12 @@ class TrainStep:
             import torch.distributed as dist
             self.dist = dist
         self.norm_buf = torch.zeros(1, device=self.flat.p16.device, dtype=torch.float32)
+        # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB
+        ops.ARENA.activate(int(arena_gib * (1 << 30)), self.flat.p16.device)
 
     def __call__(self, sample):
         f = self.flat
+        ops.ARENA.reset()
         f.zero_grad()
         loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
         loss.backward()
