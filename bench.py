@@ -21,6 +21,14 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The host thread only issues launches; idle OpenMP workers spinning after torch's small CPU ops
+# (mask / negative sampling) would burn the container's CPU quota and get the launch thread
+# throttled for tens of ms.  Keep the pools small and passive; the cpu_baseline leg raises the
+# thread count explicitly for its own run.
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+os.environ.setdefault("MKL_NUM_THREADS", "4")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

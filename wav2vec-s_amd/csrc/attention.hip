@@ -92,6 +92,17 @@ __device__ __forceinline__ float keep_scale(uint32_t s0, uint32_t s1, uint32_t i
   x ^= x >> 16;
   return x >= thr ? inv_keep : 0.f;
 }
+// Two keep decisions per hash word: element (q, key) uses word ((b*H+h)*N + q)*ceil(N/2) + key/2 and
+// its low (key even) or high (key odd) 16 bits, compared against a 16-bit threshold
+// (p_eff = round(p*65536)/65536, e.g. 0.100006 for p = 0.1; inv_keep uses p_eff).
+__device__ __forceinline__ uint32_t pair_hash(uint32_t s0, uint32_t s1, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u ^ s0;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x ^= s1; x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -120,9 +131,11 @@ __device__ __forceinline__ void load_tile(bf16* dst, const bf16* src, long ld, i
 // forward
 // =================================================================================================
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
-  __shared__ __attribute__((aligned(16))) bf16 Ks[KT * HD];
-  __shared__ __attribute__((aligned(16))) bf16 Vs[KT * HD];
-  __shared__ __attribute__((aligned(16))) float kbias[KT];
+  // double-buffered K / V tiles: the next needed tile is prefetched into registers while the current
+  // one is consumed from LDS, then written to the other buffer (one barrier per tile)
+  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * HD];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[2][KT * HD];
+  __shared__ __attribute__((aligned(16))) float kbias[2][KT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -145,16 +158,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   const QLimits L = q_limits(min(q, N - 1), p.Tp, p.m, p.r, N);
   int mlim, bclo, bchi;
   tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
-
   // per-wave key ranges: sub-tiles no query of this wave can see are skipped, sub-tiles every
   // query sees completely (and that hold no padded key) skip the mask arithmetic
   const int wmlim = wave_max_i(L.lim), wfull = wave_min_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
 
   const float c = p.scale * LOG2E;
-  const uint32_t thr = drop_threshold(p.p_drop);
-  const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p.p_drop) >> 16;           // 16-bit threshold
+  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
-  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)min(q, N - 1)) * (uint32_t)N;
+  const uint32_t Nh = (uint32_t)(N + 1) >> 1;
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)min(q, N - 1)) * Nh;
 
   f32x16 O0, O1;
 #pragma unroll
@@ -162,18 +175,49 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   float mrun = -INFINITY, lrun = 0.f;
 
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int kt0 = 0; kt0 < N; kt0 += KT) {
-    const bool need = (kt0 < mlim) || (kt0 < bchi && kt0 + KT > bclo);
-    if (!need) continue;  // block-uniform
-    __syncthreads();
-    load_tile<false>(Ks, K, p.ld, kt0, N, tid);
-    load_tile<true>(Vs, V, p.ld, kt0, N, tid);
+  auto next_tile = [&](int kt0) {  // first needed 64-key tile at or after kt0 (block-uniform)
+    while (kt0 < N && !((kt0 < mlim) || (kt0 < bchi && kt0 + KT > bclo))) kt0 += KT;
+    return kt0;
+  };
+  u32x4 rk[2], rv[2];
+  float rbias = 0.f;
+  auto gload = [&](int kt0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
+      rk[j] = u32x4{0u, 0u, 0u, 0u};
+      rv[j] = u32x4{0u, 0u, 0u, 0u};
+      if (kt0 + row < N) {
+        rk[j] = *(const u32x4*)(K + (long)(kt0 + row) * p.ld + ch * 8);
+        rv[j] = *(const u32x4*)(V + (long)(kt0 + row) * p.ld + ch * 8);
+      }
+    }
     if (tid < KT) {
       int key = kt0 + tid;
-      kbias[tid] = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
+      rbias = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
     }
-    __syncthreads();
-    const bool tile_clean = !__any(kbias[lane] != 0.f);  // no padded / out-of-range key in this tile
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
+      *(u32x4*)(Ks[buf] + kswz(row, ch)) = rk[j];
+      *(u32x4*)(Vs[buf] + vswz(row, ch * 8)) = rv[j];
+    }
+    if (tid < KT) kbias[buf][tid] = rbias;
+  };
+
+  int cur = next_tile(0), buf = 0;
+  if (cur < N) { gload(cur); lstore(0); }
+  __syncthreads();
+  while (cur < N) {
+    const int kt0 = cur;
+    const int nxt = next_tile(cur + KT);
+    if (nxt < N) gload(nxt);
+    const bf16* Kb = Ks[buf];
+    const bf16* Vb = Vs[buf];
+    const float* kb = kbias[buf];
+    const bool tile_clean = !__any(kb[lane] != 0.f);  // no padded / out-of-range key in this tile
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int k0 = kt0 + sub * 32;
@@ -184,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       for (int i = 0; i < 16; ++i) S[i] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bf16x8 a = *(const bf16x8*)(Ks + kswz(sub * 32 + r32, 2 * s + hh));
+        bf16x8 a = *(const bf16x8*)(Kb + kswz(sub * 32 + r32, 2 * s + hh));
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], S, 0, 0, 0);
       }
       float mloc = -INFINITY;
@@ -196,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         for (int i = 0; i < 16; ++i) {
           int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
           bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
-          float sv = ok ? S[i] * c + kbias[kl] : -INFINITY;
+          float sv = ok ? S[i] * c + kb[kl] : -INFINITY;
           S[i] = sv;
           mloc = fmaxf(mloc, sv);
         }
@@ -204,15 +248,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float mnew = fmaxf(mrun, mloc);
       const float muse = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = exp2f(mrun - muse);
+      const float alpha = fast_exp2(mrun - muse);
       mrun = mnew;
       float ls = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float e = exp2f(S[i] - muse);
-        ls += e;
-        if (p.p_drop > 0.f) e *= keep_scale(s0, s1, drow + (uint32_t)(k0 + acc_row(i, hh)), thr, inv_keep);
-        S[i] = e;
+      for (int i = 0; i < 16; ++i) { S[i] = fast_exp2(S[i] - muse); ls += S[i]; }
+      if (thr > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {   // rows i, i+1 are keys 2j, 2j+1: one hash word
+          const uint32_t hw = pair_hash(s0, s1, drow + (uint32_t)((k0 + acc_row(i, hh)) >> 1));
+          S[i] *= (hw & 0xFFFFu) >= thr ? inv_keep : 0.f;
+          S[i + 1] *= (hw >> 16) >= thr ? inv_keep : 0.f;
+        }
       }
       lrun = lrun * alpha + ls;
       if (!__all(alpha == 1.f)) {
@@ -224,12 +271,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         bf16x8 pb = pack8(S, s2);
         const int krow = sub * 32 + 16 * s2 + 4 * (g >> 1) + tq;
         const int dcol = (g & 1) * 16 + 4 * tp;
-        bf16x8 a0 = tr_pair(Vs + vswz(krow, dcol), Vs + vswz(krow + 8, dcol));
-        bf16x8 a1 = tr_pair(Vs + vswz(krow, 32 + dcol), Vs + vswz(krow + 8, 32 + dcol));
+        bf16x8 a0 = tr_pair(Vb + vswz(krow, dcol), Vb + vswz(krow + 8, dcol));
+        bf16x8 a1 = tr_pair(Vb + vswz(krow, 32 + dcol), Vb + vswz(krow + 8, 32 + dcol));
         O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pb, O0, 0, 0, 0);
         O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb, O1, 0, 0, 0);
       }
     }
+    if (nxt < N) lstore(buf ^ 1);
+    __syncthreads();
+    cur = nxt;
+    buf ^= 1;
   }
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
@@ -275,10 +326,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 // =================================================================================================
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
-  __shared__ __attribute__((aligned(16))) bf16 Ks[KT * HD];   // row reads (S^T)
-  __shared__ __attribute__((aligned(16))) bf16 Kt[KT * HD];   // tr reads (K^T operand of dQ^T)
-  __shared__ __attribute__((aligned(16))) bf16 Vs[KT * HD];   // row reads (dP^T)
-  __shared__ __attribute__((aligned(16))) float kbias[KT];
+  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * HD];   // row reads (S^T)
+  __shared__ __attribute__((aligned(16))) bf16 Kt[2][KT * HD];   // tr reads (K^T operand of dQ^T)
+  __shared__ __attribute__((aligned(16))) bf16 Vs[2][KT * HD];   // row reads (dP^T)
+  __shared__ __attribute__((aligned(16))) float kbias[2][KT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -310,26 +361,58 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
   const int wmlim = wave_max_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
   const float c = p.scale * LOG2E;
-  const uint32_t thr = drop_threshold(p.p_drop);
-  const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
+  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
-  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)qc) * (uint32_t)N;
+  const uint32_t Nh = (uint32_t)(N + 1) >> 1;
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)qc) * Nh;
   f32x16 D0, D1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { D0[i] = 0.f; D1[i] = 0.f; }
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int kt0 = 0; kt0 < N; kt0 += KT) {
-    const bool need = (kt0 < mlim) || (kt0 < bchi && kt0 + KT > bclo);
-    if (!need) continue;
-    __syncthreads();
-    load_tile<false>(Ks, K, p.ld, kt0, N, tid);
-    load_tile<true>(Kt, K, p.ld, kt0, N, tid);
-    load_tile<false>(Vs, V, p.ld, kt0, N, tid);
+  auto next_tile = [&](int kt0) {
+    while (kt0 < N && !((kt0 < mlim) || (kt0 < bchi && kt0 + KT > bclo))) kt0 += KT;
+    return kt0;
+  };
+  u32x4 rk[2], rv[2];
+  float rbias = 0.f;
+  auto gload = [&](int kt0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
+      rk[j] = u32x4{0u, 0u, 0u, 0u};
+      rv[j] = u32x4{0u, 0u, 0u, 0u};
+      if (kt0 + row < N) {
+        rk[j] = *(const u32x4*)(K + (long)(kt0 + row) * p.ld + ch * 8);
+        rv[j] = *(const u32x4*)(V + (long)(kt0 + row) * p.ld + ch * 8);
+      }
+    }
     if (tid < KT) {
       int key = kt0 + tid;
-      kbias[tid] = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
+      rbias = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
     }
-    __syncthreads();
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
+      *(u32x4*)(Ks[buf] + kswz(row, ch)) = rk[j];
+      *(u32x4*)(Kt[buf] + vswz(row, ch * 8)) = rk[j];
+      *(u32x4*)(Vs[buf] + kswz(row, ch)) = rv[j];
+    }
+    if (tid < KT) kbias[buf][tid] = rbias;
+  };
+  int cur = next_tile(0), buf = 0;
+  if (cur < N) { gload(cur); lstore(0); }
+  __syncthreads();
+  while (cur < N) {
+    const int kt0 = cur;
+    const int nxt = next_tile(cur + KT);
+    if (nxt < N) gload(nxt);
+    const bf16* Kb = Ks[buf];
+    const bf16* Ktb = Kt[buf];
+    const bf16* Vb = Vs[buf];
+    const float* kb = kbias[buf];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int k0 = kt0 + sub * 32;
@@ -339,32 +422,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
       for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bf16x8 a = *(const bf16x8*)(Ks + kswz(sub * 32 + r32, 2 * s + hh));
+        bf16x8 a = *(const bf16x8*)(Kb + kswz(sub * 32 + r32, 2 * s + hh));
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], S, 0, 0, 0);
-        bf16x8 av = *(const bf16x8*)(Vs + kswz(sub * 32 + r32, 2 * s + hh));
+        bf16x8 av = *(const bf16x8*)(Vb + kswz(sub * 32 + r32, 2 * s + hh));
         dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dof[s], dP, 0, 0, 0);
+      }
+      if (thr > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const uint32_t hw = pair_hash(s0, s1, drow + (uint32_t)((k0 + acc_row(i, hh)) >> 1));
+          dP[i] *= (hw & 0xFFFFu) >= thr ? inv_keep : 0.f;
+          dP[i + 1] *= (hw >> 16) >= thr ? inv_keep : 0.f;
+        }
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
         bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
-        float sv = ok ? S[i] * c + kbias[kl] : -INFINITY;
-        float pe = exp2f(sv - lse2);
-        float dp = dP[i];
-        if (p.p_drop > 0.f) dp *= keep_scale(s0, s1, drow + (uint32_t)key, thr, inv_keep);
-        S[i] = pe * (dp - delta) * p.scale;
+        float sv = ok ? S[i] * c + kb[kl] : -INFINITY;
+        float pe = fast_exp2(sv - lse2);
+        S[i] = pe * (dP[i] - delta) * p.scale;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 db = pack8(S, s2);
         const int krow = sub * 32 + 16 * s2 + 4 * (g >> 1) + tq;
         const int dcol = (g & 1) * 16 + 4 * tp;
-        bf16x8 a0 = tr_pair(Kt + vswz(krow, dcol), Kt + vswz(krow + 8, dcol));
-        bf16x8 a1 = tr_pair(Kt + vswz(krow, 32 + dcol), Kt + vswz(krow + 8, 32 + dcol));
+        bf16x8 a0 = tr_pair(Ktb + vswz(krow, dcol), Ktb + vswz(krow + 8, dcol));
+        bf16x8 a1 = tr_pair(Ktb + vswz(krow, 32 + dcol), Ktb + vswz(krow + 8, 32 + dcol));
         D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, db, D0, 0, 0, 0);
         D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, db, D1, 0, 0, 0);
       }
     }
+    if (nxt < N) lstore(buf ^ 1);
+    __syncthreads();
+    cur = nxt;
+    buf ^= 1;
   }
   if (q < N) {
     bf16* drow_p = p.dq + (long)b * p.sb + (long)q * p.ld + h * HD;
@@ -387,13 +480,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 // =================================================================================================
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
   constexpr int QT = 64;  // queries per LDS tile
-  __shared__ __attribute__((aligned(16))) bf16 Qs[QT * HD];   // row reads
-  __shared__ __attribute__((aligned(16))) bf16 Qt[QT * HD];   // tr reads
-  __shared__ __attribute__((aligned(16))) bf16 Ds[QT * HD];   // dO row reads
-  __shared__ __attribute__((aligned(16))) bf16 Dt[QT * HD];   // dO tr reads
-  __shared__ __attribute__((aligned(16))) float lse_s[QT];
-  __shared__ __attribute__((aligned(16))) float del_s[QT];
-  __shared__ int qlim_s[QT], qclo_s[QT], qchi_s[QT];
+  __shared__ __attribute__((aligned(16))) bf16 Qs[2][QT * HD];   // row reads
+  __shared__ __attribute__((aligned(16))) bf16 Qt[2][QT * HD];   // tr reads
+  __shared__ __attribute__((aligned(16))) bf16 Ds[2][QT * HD];   // dO row reads
+  __shared__ __attribute__((aligned(16))) bf16 Dt[2][QT * HD];   // dO tr reads
+  __shared__ __attribute__((aligned(16))) float lse_s[2][QT];
+  __shared__ __attribute__((aligned(16))) float del_s[2][QT];
+  __shared__ int qlim_s[2][QT], qclo_s[2][QT], qchi_s[2][QT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -417,36 +510,74 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
     }
   }
   const float c = p.scale * LOG2E;
-  const uint32_t thr = drop_threshold(p.p_drop);
-  const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
+  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
+  const uint32_t Nh = (uint32_t)(N + 1) >> 1;
   const uint32_t dbase = (uint32_t)(b * p.H + h) * (uint32_t)N;
+  const uint32_t khalf = (uint32_t)min(key, N - 1) >> 1, kodd = (uint32_t)min(key, N - 1) & 1u;
   const int klo = kblk0, khi = min(kblk0 + QB, N);  // this block's keys [klo, khi)
   const int wk0 = kblk0 + wid * 32, wk1 = min(wk0 + 32, N);  // this wave's keys [wk0, wk1)
   f32x16 dV0, dV1, dK0, dK1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  for (int q0 = 0; q0 < N; q0 += QT) {
-    // does any query of [q0, q0+QT) see any key of [klo, khi)?  (block-uniform)
-    int mlim, bclo, bchi;
-    tile_ranges(q0, min(q0 + QT, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
-    const bool need = (klo < mlim) || (klo < bchi && khi > bclo);
-    if (!need) continue;
-    __syncthreads();
-    load_tile<false>(Qs, Q, p.ld, q0, N, tid);
-    load_tile<true>(Qt, Q, p.ld, q0, N, tid);
-    load_tile<false>(Ds, dO, p.ldo, q0, N, tid);
-    load_tile<true>(Dt, dO, p.ldo, q0, N, tid);
+  auto next_tile = [&](int q0) {  // first query tile at or after q0 that sees any key of this block
+    while (q0 < N) {
+      int mlim, bclo, bchi;
+      tile_ranges(q0, min(q0 + QT, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+      if ((klo < mlim) || (klo < bchi && khi > bclo)) break;
+      q0 += QT;
+    }
+    return q0;
+  };
+  u32x4 rq[2], rd[2];
+  float rlse = 0.f, rdel = 0.f;
+  int rlim = 0, rclo = 0, rchi = 0;
+  auto gload = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
+      rq[j] = u32x4{0u, 0u, 0u, 0u};
+      rd[j] = u32x4{0u, 0u, 0u, 0u};
+      if (q0 + row < N) {
+        rq[j] = *(const u32x4*)(Q + (long)(q0 + row) * p.ld + ch * 8);
+        rd[j] = *(const u32x4*)(dO + (long)(q0 + row) * p.ldo + ch * 8);
+      }
+    }
     if (tid < QT) {
       int qq = q0 + tid;
       int qcl = min(qq, N - 1);
-      lse_s[tid] = (qq < N) ? p.lse[(long)(b * p.H + h) * N + qq] * LOG2E : INFINITY;  // +inf -> P = 0
-      del_s[tid] = (qq < N) ? p.delta[(long)(b * p.H + h) * N + qq] : 0.f;
+      rlse = (qq < N) ? p.lse[(long)(b * p.H + h) * N + qq] * LOG2E : INFINITY;  // +inf -> P = 0
+      rdel = (qq < N) ? p.delta[(long)(b * p.H + h) * N + qq] : 0.f;
       QLimits L = q_limits(qcl, p.Tp, p.m, p.r, N);
-      qlim_s[tid] = L.lim; qclo_s[tid] = L.clo; qchi_s[tid] = L.chi;
+      rlim = L.lim; rclo = L.clo; rchi = L.chi;
     }
-    __syncthreads();
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
+      *(u32x4*)(Qs[buf] + kswz(row, ch)) = rq[j];
+      *(u32x4*)(Qt[buf] + vswz(row, ch * 8)) = rq[j];
+      *(u32x4*)(Ds[buf] + kswz(row, ch)) = rd[j];
+      *(u32x4*)(Dt[buf] + vswz(row, ch * 8)) = rd[j];
+    }
+    if (tid < QT) {
+      lse_s[buf][tid] = rlse; del_s[buf][tid] = rdel;
+      qlim_s[buf][tid] = rlim; qclo_s[buf][tid] = rclo; qchi_s[buf][tid] = rchi;
+    }
+  };
+  int cur = next_tile(0), buf = 0;
+  if (cur < N) { gload(cur); lstore(0); }
+  __syncthreads();
+  while (cur < N) {
+    const int q0 = cur;
+    const int nxt = next_tile(cur + QT);
+    if (nxt < N) gload(nxt);
+    const bf16* Qb = Qs[buf]; const bf16* Qtb = Qt[buf]; const bf16* Db = Ds[buf]; const bf16* Dtb = Dt[buf];
+    const float* lse_b = lse_s[buf]; const float* del_b = del_s[buf];
+    const int* qlim_b = qlim_s[buf]; const int* qclo_b = qclo_s[buf]; const int* qchi_b = qchi_s[buf];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       {  // can any query of this 32-row sub-tile see any key of this wave?  (wave-uniform)
@@ -461,38 +592,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
       for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bf16x8 a = *(const bf16x8*)(Qs + kswz(sub * 32 + r32, 2 * s + hh));
+        bf16x8 a = *(const bf16x8*)(Qb + kswz(sub * 32 + r32, 2 * s + hh));
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[s], S, 0, 0, 0);
-        bf16x8 ad = *(const bf16x8*)(Ds + kswz(sub * 32 + r32, 2 * s + hh));
+        bf16x8 ad = *(const bf16x8*)(Db + kswz(sub * 32 + r32, 2 * s + hh));
         dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[s], dP, 0, 0, 0);
       }
       f32x16 Pd;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         int ql = sub * 32 + acc_row(i, hh), qq = q0 + ql;
-        bool ok = key_ok && ((key < qlim_s[ql]) || (key >= qclo_s[ql] && key < qchi_s[ql]));
+        bool ok = key_ok && ((key < qlim_b[ql]) || (key >= qclo_b[ql] && key < qchi_b[ql]));
         float sv = ok ? S[i] * c : -INFINITY;
-        float pe = exp2f(sv - lse_s[ql]);
+        float pe = fast_exp2(sv - lse_b[ql]);
         float ks = 1.f;
-        if (p.p_drop > 0.f) ks = keep_scale(s0, s1, (dbase + (uint32_t)min(qq, N - 1)) * (uint32_t)N + (uint32_t)min(key, N - 1), thr, inv_keep);
+        if (thr > 0) {
+          const uint32_t hw = pair_hash(s0, s1, (dbase + (uint32_t)min(qq, N - 1)) * Nh + khalf);
+          ks = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? inv_keep : 0.f;
+        }
         Pd[i] = pe * ks;
-        S[i] = pe * (dP[i] * ks - del_s[ql]) * p.scale;
+        S[i] = pe * (dP[i] * ks - del_b[ql]) * p.scale;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pb = pack8(Pd, s2), sb = pack8(S, s2);
         const int qrow = sub * 32 + 16 * s2 + 4 * (g >> 1) + tq;
         const int dcol = (g & 1) * 16 + 4 * tp;
-        bf16x8 d0 = tr_pair(Dt + vswz(qrow, dcol), Dt + vswz(qrow + 8, dcol));
-        bf16x8 d1 = tr_pair(Dt + vswz(qrow, 32 + dcol), Dt + vswz(qrow + 8, 32 + dcol));
+        bf16x8 d0 = tr_pair(Dtb + vswz(qrow, dcol), Dtb + vswz(qrow + 8, dcol));
+        bf16x8 d1 = tr_pair(Dtb + vswz(qrow, 32 + dcol), Dtb + vswz(qrow + 8, 32 + dcol));
         dV0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, pb, dV0, 0, 0, 0);
         dV1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, pb, dV1, 0, 0, 0);
-        bf16x8 q0f = tr_pair(Qt + vswz(qrow, dcol), Qt + vswz(qrow + 8, dcol));
-        bf16x8 q1f = tr_pair(Qt + vswz(qrow, 32 + dcol), Qt + vswz(qrow + 8, 32 + dcol));
+        bf16x8 q0f = tr_pair(Qtb + vswz(qrow, dcol), Qtb + vswz(qrow + 8, dcol));
+        bf16x8 q1f = tr_pair(Qtb + vswz(qrow, 32 + dcol), Qtb + vswz(qrow + 8, 32 + dcol));
         dK0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0f, sb, dK0, 0, 0, 0);
         dK1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1f, sb, dK1, 0, 0, 0);
       }
     }
+    if (nxt < N) lstore(buf ^ 1);
+    __syncthreads();
+    cur = nxt;
+    buf ^= 1;
   }
   if (key < N) {
     bf16* dkr = p.dk + (long)b * p.sb + (long)key * p.ld + h * HD;
@@ -526,7 +664,7 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
   if (p.N != p.Tp + (p.Tp / p.m) * p.r) return set_error("attention: N must equal Tp + (Tp/m)*r");
   if ((p.ld % 8) || (p.ldo % 8) || (p.sb % 8) || (p.sbo % 8)) return set_error("attention: strides must be multiples of 8 elements");
   if (p.p_drop < 0.f || p.p_drop >= 1.f) return set_error("attention: dropout must be in [0,1)");
-  if ((long)p.B * p.H * p.N * (long)p.N >= (1L << 32)) return set_error("attention: B*H*N*N must be < 2^32 (dropout index)");
+  if ((long)p.B * p.H * p.N * (long)((p.N + 1) / 2) >= (1L << 32)) return set_error("attention: B*H*N*N/2 must be < 2^32 (dropout index)");
   return 0;
 }
 
