@@ -61,6 +61,7 @@ typedef struct w2vs_gemm_desc {
   int64_t a_bytes, b_bytes;/* valid bytes per batch (0 = derive) : reads beyond return 0 */
   int64_t c_elems;         /* valid output elements per batch (0 = derive)            */
   int32_t epi; float alpha;
+  float* colsum;           /* TN only, optional: colsum[m] += alpha * sum_k A[k, m] (bias gradient fused in) */
 } w2vs_gemm_desc;
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
@@ -184,6 +185,7 @@ typedef struct w2vs_nce_desc {
   const void* x; const void* y; const int64_t* neg_idx; float* logits;
   float* xn; float* yn;              /* [B*M] fp32 row norms, written by fwd, read by bwd */
   const float* dlogits; void* dx; void* dy;   /* bwd: dx, dy bf16 [B*M, C] */
+  float* dy_ws;                      /* optional fp32 [B*M, C] scratch: lets bwd split rows over more blocks */
   int32_t B, M, K, C; float temp;
 } w2vs_nce_desc;
 int w2vs_nce_fwd(const w2vs_nce_desc* d, void* stream);

@@ -74,9 +74,11 @@ def test_gemm_nt_dgrad_dgelu(ops):
 def test_gemm_tn_wgrad(ops, R, N, K):
     dy, x = rnd(R, N, seed=1), rnd(R, K, seed=2)
     dw = torch.zeros(N, K, device="cuda")
-    ops.linear_wgrad(dev(dy), dev(x), dw, alpha=0.5)
+    dbf = torch.zeros(N, device="cuda")
+    ops.linear_wgrad(dev(dy), dev(x), dw, alpha=0.5, db_f32=dbf)
     ref = 0.5 * dy.float().t() @ x.float()
     assert rel(dw, ref) < 2e-3
+    assert rel(dbf, 0.5 * dy.float().sum(0)) < 1e-3      # bias gradient fused into the wgrad GEMM
     db = torch.zeros(N, device="cuda")
     ops.colsum(dev(dy), db)
     assert rel(db, dy.float().sum(0)) < 1e-3

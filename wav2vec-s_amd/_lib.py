@@ -16,7 +16,7 @@ class GemmDesc(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
                 ("lda", i64), ("ldb", i64), ("ldc", i64), ("a_off", i64),
                 ("sA", i64), ("sB", i64), ("sC", i64), ("a_bytes", i64), ("b_bytes", i64), ("c_elems", i64),
-                ("epi", i32), ("alpha", f32)]
+                ("epi", i32), ("alpha", f32), ("colsum", vp)]
 
 
 class LnFwdDesc(C.Structure):
@@ -58,7 +58,7 @@ class QuantDesc(C.Structure):
 
 class NceDesc(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("neg_idx", vp), ("logits", vp), ("xn", vp), ("yn", vp), ("dlogits", vp),
-                ("dx", vp), ("dy", vp),
+                ("dx", vp), ("dy", vp), ("dy_ws", vp),
                 ("B", i32), ("M", i32), ("K", i32), ("C", i32), ("temp", f32)]
 
 

@@ -66,12 +66,28 @@ __device__ __forceinline__ float u01(uint32_t h) {  // (0,1]
   return ((float)(h >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
-__device__ __forceinline__ float gelu_exact(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution): one v_rcp, one
+// v_exp and a 5-term Horner chain instead of libm's branchy erff.  Hundreds of millions of GELUs per
+// step sit in GEMM / conv epilogues, so this is a first-order cost.  Returns erf(x) and exp(-x^2).
+__device__ __forceinline__ float fast_erf(float x, float& ex2) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  ex2 = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float r = 1.0f - poly * t * ex2;
+  return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_grad(float x) {
-  const float c = 0.3989422804014327f;  // 1/sqrt(2*pi)
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * c * __expf(-0.5f * x * x);
+__device__ __forceinline__ float gelu_exact(float x) {  // 0.5 x (1 + erf(x / sqrt 2))
+  float e;
+  return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f, e));
+}
+__device__ __forceinline__ float gelu_grad(float x) {  // Phi(x) + x phi(x); exp(-x^2/2) comes with the erf
+  float e;
+  const float er = fast_erf(x * 0.70710678118654752440f, e);
+  return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
 }
 
 }  // namespace w2vs

@@ -34,6 +34,7 @@ struct GemmP {
   uint32_t a_bytes, b_bytes;  // valid bytes per batch for the A / B descriptors
   long c_elems;               // valid output elements per batch
   int k_split, n_split;       // TN only: K range per split, splits per batch
+  float* colsum;              // TN only: optional out[m] += sum_k A[k, m]  (bias gradient)
   float alpha;
 };
 
@@ -45,7 +46,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) bf16 lds[2 * 128 * 136];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so give
+  // every XCD a contiguous run of tiles - the N-tiles of one M-tile then share that XCD's L2 copy of A.
+  int tile_id;
+  {
+    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+    tile_id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  }
+  const int m0 = (tile_id / gridDim.x) * BM, n0 = (tile_id % gridDim.x) * BN;
   const int bz = blockIdx.z;
 
   const bf16* Ab = p.A + (long)bz * p.sA;
@@ -238,6 +247,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
     b_col[j] = (n0 + cc * 8 < p.N) ? (uint32_t)((n0 + cc * 8) * 2) : 0xFFFFFFF0u;
   }
   u32x4 ra_reg[4], rb_reg[4];
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
   auto gload = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -256,6 +267,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) {
       *(u32x4*)(sa + l_off[j]) = ra_reg[j];
       *(u32x4*)(sb + l_off[j]) = rb_reg[j];
+    }
+    if (do_colsum) {  // the A tile passes through these registers exactly once: add it up on the way
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        union { u32x4 u; bf16x8 h; } cv; cv.u = ra_reg[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += bf2f(cv.h[e]);
+      }
     }
   };
   f32x4 acc[4][4];
@@ -311,6 +330,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
         int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
         if (row < p.M && col < p.N) atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
       }
+  if (do_colsum) {
+    // 16 threads (tid>>4) share a column chunk cc = tid&15: fold them in LDS, then one atomic per column
+    float* red = (float*)lds;
+    __syncthreads();
+    if (tid < BM) red[tid] = 0.f;
+    __syncthreads();
+    const int cc = tid & 15;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&red[cc * 8 + e], csum[e]);
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum[m0 + tid], red[tid] * p.alpha);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -360,6 +391,7 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   GemmP p{};
   p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.Cf = d.Cf;
   p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.a_off = d.a_off; p.alpha = d.alpha;
+  p.colsum = d.colsum;
   long a_ext = d.a_bytes ? d.a_bytes : ((long)d.a_off + (long)(d.K - 1) * d.lda + d.M) * 2;
   long b_ext = d.b_bytes ? d.b_bytes : ((long)(d.K - 1) * d.ldb + d.N) * 2;
   if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_tn: operand extent must be < 2 GiB per batch");

@@ -223,6 +223,7 @@ struct NceP {
   float* logits;                                       // [R, K+1]
   float* xn; float* yn;                                // [R] row norms (clamped at eps), saved by fwd
   const float* dlogits; bf16* dx; bf16* dy;            // bwd outputs bf16 [R, C]
+  float* dy_ws; int nsplit;                            // fp32 [R, C] accumulator when rows are split over blocks
   int B, M, K, C; float inv_temp; int cw;
 };
 
@@ -303,13 +304,14 @@ __global__ __launch_bounds__(1024) void nce_bwd_kernel(NceP p) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b = blockIdx.y, c0 = blockIdx.x * p.cw;
   const int M = p.M, K = p.K, C = p.C, cw = p.cw;
+  const int split = blockIdx.z, nsplit = p.nsplit;   // query rows are dealt over nsplit blocks
   const float temp = 1.f / p.inv_temp;
   for (int i = threadIdx.x; i < M * cw; i += 1024) dyl[i] = 0.f;
   __syncthreads();
   bool act[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) act[e] = (c0 + lane + 64 * e) < C;
-  for (int i = wid; i < M; i += 16) {
+  for (int i = wid * nsplit + split; i < M; i += 16 * nsplit) {
     const long row = (long)b * M + i;
     float xs[EPL], gx[EPL];
 #pragma unroll
@@ -362,9 +364,17 @@ __global__ __launch_bounds__(1024) void nce_bwd_kernel(NceP p) {
       if (act[e]) p.dx[row * C + c0 + lane + 64 * e] = f2bf(gx[e] - sbx * xs[e]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < M * cw; i += 1024) {
-    int t = i / cw, c = i % cw;
-    if (c0 + c < C) p.dy[((long)b * M + t) * C + c0 + c] = f2bf(dyl[i]);
+  if (nsplit == 1) {
+    for (int i = threadIdx.x; i < M * cw; i += 1024) {
+      int t = i / cw, c = i % cw;
+      if (c0 + c < C) p.dy[((long)b * M + t) * C + c0 + c] = f2bf(dyl[i]);
+    }
+  } else {  // partial sums of this row split: 256-B contiguous fp32 atomics per wave instruction
+    for (int i = threadIdx.x; i < M * cw; i += 1024) {
+      int t = i / cw, c = i % cw;
+      float v = dyl[i];
+      if (c0 + c < C && v != 0.f) atomicAdd(&p.dy_ws[((long)b * M + t) * C + c0 + c], v);
+    }
   }
 }
 
@@ -407,7 +417,18 @@ int nce_bwd(const NceDesc& d, hipStream_t st) {
   if (!cw) return set_error("infonce_bwd: too many masked frames per utterance for the LDS accumulator (M > 576)");
   if (cw > p.C) cw = ((p.C + 63) / 64) * 64;
   p.cw = cw;
-  dim3 grid((p.C + cw - 1) / cw, p.B);
+  const int slices = (p.C + cw - 1) / cw;
+  // enough blocks to occupy the chip: split the query rows of an utterance over several blocks whose
+  // partial dy are combined with fp32 atomics into dy_ws (then rounded to bf16 once)
+  int nsplit = 1;
+  if (d.dy_ws) {
+    while (nsplit < 16 && slices * p.B * nsplit < 192) nsplit *= 2;
+  }
+  p.nsplit = nsplit; p.dy_ws = d.dy_ws;
+  const long R = (long)p.B * p.M;
+  if (nsplit > 1)
+    if (int e = hip_check(hipMemsetAsync(p.dy_ws, 0, sizeof(float) * R * p.C, st), "memset")) return e;
+  dim3 grid(slices, p.B, nsplit);
   size_t lds = (size_t)p.M * cw * 4;
 #define NCE_LAUNCH(E)                                                                                          \
   do {                                                                                                         \
@@ -422,6 +443,8 @@ int nce_bwd(const NceDesc& d, hipStream_t st) {
     default: NCE_LAUNCH(4); break;
   }
 #undef NCE_LAUNCH
+  if (nsplit > 1)
+    if (int e = f32_to_bf16(p.dy_ws, p.dy, R * p.C, 1.0f, st)) return e;
   return hip_check(hipGetLastError(), "infonce_bwd");
 }
 

@@ -30,8 +30,8 @@ static int lin_wgrad(const void* dy, const void* x, float* dw, float* db, int R,
   GemmDesc d{};
   d.A = dy; d.B = x; d.Cf = dw;
   d.M = N; d.N = K; d.K = R; d.batch = 1; d.lda = N; d.ldb = K; d.ldc = K; d.alpha = 1.f;
-  if (int e = gemm_tn(d, num_cu, s)) return e;
-  return colsum(dy, db, R, N, N, s);
+  d.colsum = db;  // bias gradient rides along in the wgrad GEMM's A-tile staging
+  return gemm_tn(d, num_cu, s);
 }
 
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)

@@ -423,8 +423,7 @@ def grad_shapes(cfg, W) -> Dict[str, tuple]:
 
 
 def _linear_bwd(dy, x, w_name, b_name, W, A, *, need_dx=True, dgelu_aux=None, add_aux=None):
-    ops.linear_wgrad(dy, x, A.view(w_name))
-    ops.colsum(dy, A.view(b_name))
+    ops.linear_wgrad(dy, x, A.view(w_name), db_f32=A.view(b_name))
     if not need_dx:
         return None
     wt = ops.transpose2d(W[w_name])
@@ -589,9 +588,8 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         else:
             d_c = d_cur
         x_in = rec["x_in"]
-        ops.conv_cl_wgrad(d_c, x_in, k, s, A.view(_pname(i, "0.weight")).view(dim, -1))
-        if _pname(i, "0.bias") in A:
-            ops.colsum(d_c.view(-1, dim), A.view(_pname(i, "0.bias")))
+        ops.conv_cl_wgrad(d_c, x_in, k, s, A.view(_pname(i, "0.weight")).view(dim, -1),
+                          db_f32=A.view(_pname(i, "0.bias")) if _pname(i, "0.bias") in A else None)
         prev = st.conv[i - 1]
         prev_aux = prev.get("pre") if (i - 1 >= 1 and not prev["ln"]) else None
         d_cur = ops.conv_cl_dgrad(d_c, st.packed[i], k, s, x_in.shape[1], dgelu_aux=prev_aux)
@@ -618,8 +616,7 @@ def _attn_block_bwd(st, rec, pre, d_a, x_in, add_to_dx, A):
     off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
     dW = A.flat[off_w:off_w + 3 * E * E].view(3 * E, E)
     db = A.flat[off_b:off_b + 3 * E]
-    ops.linear_wgrad(dqkv, x_in, dW)
-    ops.colsum(dqkv, db)
+    ops.linear_wgrad(dqkv, x_in, dW, db_f32=db)
     wqkv, _ = _qkv_pack(W, pre)
     wt = ops.transpose2d(wqkv)
     return ops.linear_dgrad(dqkv, wt, add_aux=add_to_dx)

@@ -158,7 +158,7 @@ def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, 
 
 
 def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB=0, a_bytes=0, b_bytes=0,
-            alpha=1.0, num_cu=256):
+            alpha=1.0, num_cu=256, colsum_out=None):
     d = GemmDesc()
     d.A, d.B, d.Cf = _p(a), _p(b), _p(out_f32)
     d.M, d.N, d.K, d.batch = M, N, K, batch
@@ -166,6 +166,7 @@ def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB
     d.sA, d.sB = sA, sB
     d.a_bytes, d.b_bytes = a_bytes, b_bytes
     d.alpha = alpha
+    d.colsum = _p(colsum_out)
     _lib.call("w2vs_gemm_tn", C.byref(d), num_cu, _stream())
 
 
@@ -196,12 +197,12 @@ def linear_dgrad(dy, w_t, *, dgelu_aux=None, add_aux=None):
     return dx
 
 
-def linear_wgrad(dy, x, dw_f32, alpha=1.0):
-    """dw[N, K] += alpha * dy[R, N]^T @ x[R, K]   (fp32 accumulate, atomics)."""
-    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw_f32, torch.float32, "dw")
+def linear_wgrad(dy, x, dw_f32, alpha=1.0, db_f32=None):
+    """dw[N, K] += alpha * dy[R, N]^T @ x[R, K]; optionally db[N] += alpha * colsum(dy)  (fp32 atomics)."""
+    _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw_f32, torch.float32, "dw"); _chk(db_f32, torch.float32, "db")
     R, N = dy.shape
     K = x.shape[1]
-    gemm_tn(dy, x, dw_f32, M=N, N=K, K=R, lda=N, ldb=K, ldc=K, alpha=alpha)
+    gemm_tn(dy, x, dw_f32, M=N, N=K, K=R, lda=N, ldb=K, ldc=K, alpha=alpha, colsum_out=db_f32)
 
 
 def colsum(x, out_f32):
@@ -283,13 +284,14 @@ def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None):
     return dx
 
 
-def conv_cl_wgrad(dy, x, k, s, dw2_f32, alpha=1.0):
+def conv_cl_wgrad(dy, x, k, s, dw2_f32, alpha=1.0, db_f32=None):
     """dw2[Cout, k*Cin] += sum_{b,t} dy[b,t,:]^T x_window[b,t,:]  (fp32 accumulate)."""
     _chk(dy, BF16, "dy"); _chk(x, BF16, "x"); _chk(dw2_f32, torch.float32, "dw2")
     B, Lout, Cout = dy.shape
     _, Lin, Cin = x.shape
     gemm_tn(dy, x, dw2_f32, M=Cout, N=k * Cin, K=Lout, lda=Cout, ldb=s * Cin, ldc=k * Cin, batch=B,
-            sA=Lout * Cout, sB=Lin * Cin, a_bytes=Lout * Cout * 2, b_bytes=Lin * Cin * 2, alpha=alpha)
+            sA=Lout * Cout, sB=Lin * Cin, a_bytes=Lout * Cout * 2, b_bytes=Lin * Cin * 2, alpha=alpha,
+            colsum_out=db_f32)
 
 
 # ---------------------------------------------------------------------------------- conv0
@@ -497,6 +499,8 @@ def nce_bwd(dlogits, logits, norms, x, y, neg_idx, B, M, K, temp):
     dy = empty((B * M, Cc), BF16, x.device)
     d = NceDesc()
     d.x, d.y, d.neg_idx, d.logits, d.dlogits, d.dx, d.dy = _p(x), _p(y), _p(neg_idx), _p(logits), _p(dlogits), _p(dx), _p(dy)
+    ws = empty((B * M, Cc), torch.float32, x.device)
+    d.dy_ws = _p(ws)
     d.xn, d.yn = _p(norms[0]), _p(norms[1])
     d.B, d.M, d.K, d.C, d.temp = B, M, K, Cc, temp
     _lib.call("w2vs_nce_bwd", C.byref(d), _stream())
