@@ -14,6 +14,7 @@
 //  * 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles.
 //    LDS rows are 128 B; 16-B chunk c of row r lives at chunk (c ^ ((r>>1)&7)) which makes
 //    the ds_read_b128 fragment reads and the ds_write_b128 staging writes conflict free.
+#include <stdlib.h>
 #include "common.h"
 #include "w2vs_internal.h"
 
@@ -40,10 +41,12 @@ struct GemmP {
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6 };
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
-  // A0 A1 B0 B1 during the K loop (64 KiB); two padded [128][136] output tiles in the epilogue
-  __shared__ __attribute__((aligned(16))) bf16 lds[2 * 128 * 136];
+// SB = single LDS buffer: 34 KiB per block instead of 68, which lets THREE blocks share a CU (12 waves);
+// the tile for step kt+1 waits in registers while step kt computes, at the price of a second barrier.
+template <int EPI, bool SB>
+__global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_nt_kernel(GemmP p) {
+  // A0 A1 B0 B1 during the K loop (64 KiB; SB: A B, 32 KiB); padded [128][136] output tile(s) in the epilogue
+  __shared__ __attribute__((aligned(16))) bf16 lds[(SB ? 1 : 2) * 128 * 136];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so give
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   };
   auto lstore = [&](int buf) {
     bf16* sa = lds + buf * TILE_ELEMS;
-    bf16* sb = lds + (2 + buf) * TILE_ELEMS;
+    bf16* sb = lds + ((SB ? 1 : 2) + buf) * TILE_ELEMS;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       *(u32x4*)(sa + l_off[j]) = ra_reg[j];
@@ -111,14 +114,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   gload(0);
-  lstore(0);
-  __syncthreads();
+  if (!SB) {
+    lstore(0);
+    __syncthreads();
+  }
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = SB ? 0 : (kt & 1);
+    if (SB) {
+      if (kt > 0) __syncthreads();   // every wave is done reading the previous tile
+      lstore(0);
+      __syncthreads();
+    }
     if (kt + 1 < nk) gload(kt + 1);
     const bf16* sa = lds + buf * TILE_ELEMS;
-    const bf16* sb = lds + (2 + buf) * TILE_ELEMS;
+    const bf16* sb = lds + ((SB ? 1 : 2) + buf) * TILE_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
@@ -132,9 +142,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
+    if (!SB) {
+      if (kt + 1 < nk) lstore(buf ^ 1);
+      __syncthreads();
+    }
   }
+  if (SB) __syncthreads();
 
   // ---- epilogue: registers -> (fp32 math) -> LDS bf16 tile -> 16-B row-contiguous stores ----
   bf16* Cb = p.C + (long)bz * p.sC;
@@ -153,58 +166,66 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   }
   // staging tile [128][128] bf16 with a 16-B pad per row (row pitch 272 B) to spread banks
   constexpr int CP = 136;
-  bf16* st = lds;            // 128*136*2 = 34816 B
-  bf16* st2 = lds + 128 * CP;  // second output (pre-activation) when saving both
+  bf16* st = lds;                          // 128*136*2 = 34816 B
+  bf16* st2 = SB ? lds : lds + 128 * CP;   // pre-activation tile (SB: same buffer, emitted in a first pass)
+  constexpr bool TWO_PASS = SB && EPI == EPI_BIAS_GELU_SAVE;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int col = n0 + wn * 64 + j * 16 + fr;
-    float bv = 0.f;
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE)
-      if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
+  for (int pass = 0; pass < (TWO_PASS ? 2 : 1); ++pass) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      int col = n0 + wn * 64 + j * 16 + fr;
+      float bv = 0.f;
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE)
+        if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int lr = wm * 64 + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
-        float v = acc[i][j][r] + bv;
-        if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
-          if (EPI == EPI_BIAS_GELU_SAVE) {
-            bf16 pre = f2bf(v);
-            st2[lr * CP + lc] = pre;
-            v = bf2f(pre);  // the activation is taken of the value that is actually saved
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int lr = wm * 64 + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
+          float v = acc[i][j][r] + bv;
+          if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+            if (EPI == EPI_BIAS_GELU_SAVE) {
+              bf16 pre = f2bf(v);
+              if (!TWO_PASS || pass == 0) st2[lr * CP + lc] = pre;
+              v = bf2f(pre);  // the activation is taken of the value that is actually saved
+            }
+            v = gelu_exact(v);
           }
-          v = gelu_exact(v);
+          if (!TWO_PASS || pass == 1) st[lr * CP + lc] = f2bf(v);
         }
-        st[lr * CP + lc] = f2bf(v);
-      }
-  }
-  __syncthreads();
-  // 128 rows x 16 chunks of 16 B; thread t handles chunks t + 256*j, j=0..7
+    }
+    __syncthreads();
+    // 128 rows x 16 chunks of 16 B; thread t handles chunks t + 256*j, j=0..7
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int c = tid + 256 * j, lr = c >> 4, cc = c & 15;
-    int row = m0 + lr, col = n0 + cc * 8;
-    long o = (long)row * p.ldc + col;
-    if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
-      if (EPI == EPI_DGELU) {
-        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
-        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
-        bf16x8 outv;
+    for (int j = 0; j < 8; ++j) {
+      int c = tid + 256 * j, lr = c >> 4, cc = c & 15;
+      int row = m0 + lr, col = n0 + cc * 8;
+      long o = (long)row * p.ldc + col;
+      if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
+        if (EPI == EPI_DGELU) {
+          bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+          bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+          bf16x8 outv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * gelu_grad(bf2f(a[e])));
-        *(bf16x8*)(Cb + o) = outv;
-      } else if (EPI == EPI_ADD) {
-        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
-        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
-        bf16x8 outv;
+          for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * gelu_grad(bf2f(a[e])));
+          *(bf16x8*)(Cb + o) = outv;
+        } else if (EPI == EPI_ADD) {
+          bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+          bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+          bf16x8 outv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) + bf2f(a[e]));
-        *(bf16x8*)(Cb + o) = outv;
-      } else {
-        *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
-        if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+          for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) + bf2f(a[e]));
+          *(bf16x8*)(Cb + o) = outv;
+        } else if (TWO_PASS) {
+          if (pass == 0) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+          else *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
+        } else {
+          *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
+          if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+        }
       }
     }
+    if (TWO_PASS && pass == 0) __syncthreads();
   }
 }
 
@@ -371,16 +392,27 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_nt: operand extent must be < 2 GiB per batch");
   p.a_bytes = (uint32_t)a_ext; p.b_bytes = (uint32_t)b_ext;
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch > 0 ? d.batch : 1), block(256);
+  // single-buffer / 3-blocks-per-CU form when the grid has enough tiles to fill it (measured +6..10 % on
+  // the QKV / fc1 / conv shapes), double-buffer / 2-per-CU for short grids with a long K (fc2, out_proj)
+  static const int sb_env = [] { const char* e = getenv("W2VS_GEMM_SB"); return e ? atoi(e) : -1; }();
+  const long ntiles = (long)grid.x * grid.y * grid.z;
+  const bool sb_mode = sb_env >= 0 ? sb_env != 0 : ntiles >= 640;
+#define NT_LAUNCH(E)                                                                          \
+  do {                                                                                        \
+    if (sb_mode) hipLaunchKernelGGL((gemm_nt_kernel<E, true>), grid, block, 0, s, p);         \
+    else hipLaunchKernelGGL((gemm_nt_kernel<E, false>), grid, block, 0, s, p);                \
+  } while (0)
   switch (d.epi) {
-    case EPI_NONE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_NONE>, grid, block, 0, s, p); break;
-    case EPI_BIAS: hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS>, grid, block, 0, s, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS_GELU>, grid, block, 0, s, p); break;
-    case EPI_BIAS_GELU_SAVE: hipLaunchKernelGGL(gemm_nt_kernel<EPI_BIAS_GELU_SAVE>, grid, block, 0, s, p); break;
-    case EPI_DGELU: hipLaunchKernelGGL(gemm_nt_kernel<EPI_DGELU>, grid, block, 0, s, p); break;
-    case EPI_F32: hipLaunchKernelGGL(gemm_nt_kernel<EPI_F32>, grid, block, 0, s, p); break;
-    case EPI_ADD: hipLaunchKernelGGL(gemm_nt_kernel<EPI_ADD>, grid, block, 0, s, p); break;
+    case EPI_NONE: NT_LAUNCH(EPI_NONE); break;
+    case EPI_BIAS: NT_LAUNCH(EPI_BIAS); break;
+    case EPI_BIAS_GELU: NT_LAUNCH(EPI_BIAS_GELU); break;
+    case EPI_BIAS_GELU_SAVE: NT_LAUNCH(EPI_BIAS_GELU_SAVE); break;
+    case EPI_DGELU: NT_LAUNCH(EPI_DGELU); break;
+    case EPI_F32: NT_LAUNCH(EPI_F32); break;
+    case EPI_ADD: NT_LAUNCH(EPI_ADD); break;
     default: return set_error("gemm_nt: unknown epilogue");
   }
+#undef NT_LAUNCH
   return hip_check(hipGetLastError(), "gemm_nt launch");
 }
 

@@ -113,6 +113,7 @@ class _GemmTimer:
         return e
 
     def end(self, e0, epi, flops):
+        """epi: gemm_nt epilogue id, or "tn" for the wgrad kernel."""
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
@@ -132,12 +133,17 @@ class _GemmTimer:
         names = {0: "none", 1: "bias", 2: "bias_gelu", 3: "bias_gelu_save", 4: "dgelu", 5: "f32", 6: "add"}
         epi, (t, fl, n) = max(groups.items(), key=lambda kv: kv[1][0])
         ach = fl / t / 1e12
-        tot_t = sum(g[0] for g in groups.values())
-        tot_f = sum(g[1] for g in groups.values())
-        return {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % names.get(epi, epi), "achieved": round(ach, 1),
-                "peak": peak_tflops, "unit": "TFLOP/s", "frac": round(ach / peak_tflops, 4), "traffic": None,
-                "launches_timed": n, "avg_launch_us": round(t / n * 1e6, 2),
-                "all_gemm_nt_tflops": round(tot_f / tot_t / 1e12, 1)}
+        nt = [g for k, g in groups.items() if k != "tn"]
+        kname = "gemm_tn_kernel" if epi == "tn" else "gemm_nt_kernel<%s>" % names.get(epi, epi)
+        out = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s",
+               "frac": round(ach / peak_tflops, 4), "traffic": None, "launches_timed": n,
+               "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": round(fl / n / 1e9, 3)}
+        if nt:
+            out["all_gemm_nt_tflops"] = round(sum(g[1] for g in nt) / sum(g[0] for g in nt) / 1e12, 1)
+        if "tn" in groups:
+            g = groups["tn"]
+            out["gemm_tn_tflops"] = round(g[1] / g[0] / 1e12, 1)
+        return out
 
 
 GEMM_TIMER = _GemmTimer()
@@ -167,7 +173,9 @@ def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB
     d.a_bytes, d.b_bytes = a_bytes, b_bytes
     d.alpha = alpha
     d.colsum = _p(colsum_out)
+    ev = GEMM_TIMER.begin()
     _lib.call("w2vs_gemm_tn", C.byref(d), num_cu, _stream())
+    GEMM_TIMER.end(ev, "tn", 2.0 * M * N * K * batch)
 
 
 def linear_fwd(x, w, bias=None, *, gelu=False, save_pre=False):
