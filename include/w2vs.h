@@ -64,6 +64,11 @@ typedef struct w2vs_gemm_desc {
   float* colsum;           /* TN only, optional: colsum[m] += alpha * sum_k A[k, m] (bias gradient fused in) */
 } w2vs_gemm_desc;
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
+/* Measurement hooks: bracket every stride-th GEMM launch with HIP events on its own stream (0 = off).
+ * id = NT epilogue (0..6) or 7 for gemm_tn; read returns summed launch time [ms], algorithmic FLOPs
+ * and the number of launches timed since the last enable. */
+int w2vs_prof_enable(int stride);
+int w2vs_prof_read(int id, double* total_ms, double* total_flops, int* launches);
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
 
 /* ---- conv layer 0: Conv1d(1->C,k,s) + Fp32LayerNorm(C) + GELU ------------------------------

@@ -81,6 +81,8 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_A
 _SIGS = {
     "w2vs_gemm_nt": [C.POINTER(GemmDesc), vp],
     "w2vs_gemm_tn": [C.POINTER(GemmDesc), i32, vp],
+    "w2vs_prof_enable": [i32],
+    "w2vs_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)],
     "w2vs_conv0_fwd": [vp] * 8 + [i32] * 5 + [vp],
     "w2vs_conv0_bwd": [vp] * 12 + [i32] * 5 + [vp],
     "w2vs_ln_fwd": [C.POINTER(LnFwdDesc), vp],

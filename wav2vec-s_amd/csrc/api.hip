@@ -33,6 +33,8 @@ int w2vs_sizeof(int which) {
   }
   return -1;
 }
+int w2vs_prof_enable(int stride) { prof_enable(stride); return 0; }
+int w2vs_prof_read(int id, double* ms, double* flops, int* n) { return prof_read(id, ms, flops, n); }
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* s) { NONNULL(d); return gemm_nt(*d, ST(s)); }
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int cu, void* s) { NONNULL(d); return gemm_tn(*d, cu, ST(s)); }
 int w2vs_conv0_fwd(const void* wave, const void* w, const void* cb, const void* lw, const void* lb, void* y, float* mean,

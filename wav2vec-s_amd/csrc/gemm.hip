@@ -15,6 +15,7 @@
 //    LDS rows are 128 B; 16-B chunk c of row r lives at chunk (c ^ ((r>>1)&7)) which makes
 //    the ds_read_b128 fragment reads and the ds_write_b128 staging writes conflict free.
 #include <stdlib.h>
+#include <vector>
 #include "common.h"
 #include "w2vs_internal.h"
 
@@ -366,6 +367,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Launch-level profiling hooks (bench.py "roofline"): every stride-th GEMM launch is bracketed by a
+// pair of HIP events ON THE STREAM IT IS LAUNCHED ON; totals are read back after the timed region.
+struct ProfSample { hipEvent_t e0, e1; int id; double flops; };
+static std::vector<ProfSample> g_prof;
+static int g_prof_stride = 0;
+static long g_prof_count = 0;
+void prof_enable(int stride) {
+  for (auto& s : g_prof) { hipEventDestroy(s.e0); hipEventDestroy(s.e1); }
+  g_prof.clear();
+  g_prof_stride = stride;
+  g_prof_count = 0;
+}
+static inline hipEvent_t prof_begin(hipStream_t st) {
+  if (g_prof_stride <= 0) return nullptr;
+  if ((g_prof_count++ % g_prof_stride) != 0) return nullptr;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  hipEventRecord(e, st);
+  return e;
+}
+static inline void prof_end(hipEvent_t e0, int id, double flops, hipStream_t st) {
+  if (!e0) return;
+  hipEvent_t e1;
+  if (hipEventCreate(&e1) != hipSuccess) return;
+  hipEventRecord(e1, st);
+  g_prof.push_back({e0, e1, id, flops});
+}
+int prof_read(int id, double* total_ms, double* total_flops, int* launches) {
+  double ms = 0, fl = 0;
+  int n = 0;
+  for (auto& s : g_prof) {
+    if (s.id != id) continue;
+    if (hipEventSynchronize(s.e1) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, s.e0, s.e1) != hipSuccess) continue;
+    ms += t; fl += s.flops; ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  return 0;
+}
+
 static int check_common(const GemmDesc& d) {
   if (!d.A || !d.B) return set_error("gemm: null operand");
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return set_error("gemm: non-positive dimension");
@@ -394,6 +438,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch > 0 ? d.batch : 1), block(256);
   // single-buffer / 3-blocks-per-CU form when the grid has enough tiles to fill it (measured +6..10 % on
   // the QKV / fc1 / conv shapes), double-buffer / 2-per-CU for short grids with a long K (fc2, out_proj)
+  hipEvent_t pe = prof_begin(s);
   static const int sb_env = [] { const char* e = getenv("W2VS_GEMM_SB"); return e ? atoi(e) : -1; }();
   const long ntiles = (long)grid.x * grid.y * grid.z;
   const bool sb_mode = sb_env >= 0 ? sb_env != 0 : ntiles >= 640;
@@ -413,6 +458,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     default: return set_error("gemm_nt: unknown epilogue");
   }
 #undef NT_LAUNCH
+  prof_end(pe, d.epi, 2.0 * d.M * d.N * d.K * (d.batch > 0 ? d.batch : 1), s);
   return hip_check(hipGetLastError(), "gemm_nt launch");
 }
 
@@ -441,7 +487,9 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   splits = (d.K + ks - 1) / ks;
   p.k_split = ks; p.n_split = splits;
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, splits * nb), block(256);
+  hipEvent_t pe = prof_begin(s);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, s, p);
+  prof_end(pe, 7, 2.0 * d.M * d.N * d.K * nb, s);
   return hip_check(hipGetLastError(), "gemm_tn launch");
 }
 

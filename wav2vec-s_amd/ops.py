@@ -91,58 +91,48 @@ def _chk(t, dtype=None, name="tensor"):
 
 # ------------------------------------------------------------------------------------------ GEMM
 class _GemmTimer:
-    """HIP-event timing of gemm_nt launches on the stream they are launched on (bench.py roofline).
-    Every ``stride``-th launch is bracketed by a pair of events; durations are read after the timed
-    region, grouped per epilogue instantiation."""
+    """bench.py roofline: libw2vs brackets every stride-th GEMM launch (Python- or C++-issued alike) with
+    HIP events on the launching stream; totals are read back after the timed region."""
 
     def __init__(self, stride=4):
-        self.stride, self.on, self.count, self.samples = stride, False, 0, []
+        self.stride = stride
 
     def enable(self):
-        self.on, self.count, self.samples = True, 0, []
+        _lib.call("w2vs_prof_enable", self.stride)
 
     def disable(self):
-        self.on = False
+        pass  # samples are kept until the next enable()
 
     def begin(self):
-        self.count += 1
-        if not self.on or self.count % self.stride:
-            return None
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
+        return None
 
-    def end(self, e0, epi, flops):
-        """epi: gemm_nt epilogue id, or "tn" for the wgrad kernel."""
-        if e0 is None:
-            return
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        self.samples.append((e0, e1, epi, flops))
+    def end(self, *a):
+        return None
 
     def report(self, peak_tflops):
         torch.cuda.synchronize()
+        names = {0: "gemm_nt_kernel<none>", 1: "gemm_nt_kernel<bias>", 2: "gemm_nt_kernel<bias_gelu>",
+                 3: "gemm_nt_kernel<bias_gelu_save>", 4: "gemm_nt_kernel<dgelu>", 5: "gemm_nt_kernel<f32>",
+                 6: "gemm_nt_kernel<add>", 7: "gemm_tn_kernel"}
         groups = {}
-        for e0, e1, epi, flops in self.samples:
-            g = groups.setdefault(epi, [0.0, 0.0, 0])
-            g[0] += e0.elapsed_time(e1) * 1e-3
-            g[1] += flops
-            g[2] += 1
+        for k in names:
+            ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
+            _lib.call("w2vs_prof_read", k, C.byref(ms), C.byref(fl), C.byref(n))
+            if n.value:
+                groups[k] = (ms.value * 1e-3, fl.value, n.value)
+        _lib.call("w2vs_prof_enable", 0)
         if not groups:
             return None
-        names = {0: "none", 1: "bias", 2: "bias_gelu", 3: "bias_gelu_save", 4: "dgelu", 5: "f32", 6: "add"}
-        epi, (t, fl, n) = max(groups.items(), key=lambda kv: kv[1][0])
+        k, (t, fl, n) = max(groups.items(), key=lambda kv: kv[1][0])
         ach = fl / t / 1e12
-        nt = [g for k, g in groups.items() if k != "tn"]
-        kname = "gemm_tn_kernel" if epi == "tn" else "gemm_nt_kernel<%s>" % names.get(epi, epi)
-        out = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s",
+        out = {"bound": "mfma", "kernel": names[k], "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s",
                "frac": round(ach / peak_tflops, 4), "traffic": None, "launches_timed": n,
                "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": round(fl / n / 1e9, 3)}
+        nt = [g for kk, g in groups.items() if kk != 7]
         if nt:
             out["all_gemm_nt_tflops"] = round(sum(g[1] for g in nt) / sum(g[0] for g in nt) / 1e12, 1)
-        if "tn" in groups:
-            g = groups["tn"]
-            out["gemm_tn_tflops"] = round(g[1] / g[0] / 1e12, 1)
+        if 7 in groups:
+            out["gemm_tn_tflops"] = round(groups[7][1] / groups[7][0] / 1e12, 1)
         return out
 
 
