@@ -1,0 +1,92 @@
+"""N > 1 path on CPU: trainer.GradExchange (the bucketed, backward-overlapped gradient all-reduce that
+bench.py runs over RCCL) exercised with world_size = 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, bucket, offsets, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import wav2vec_s_amd  # noqa: F401
+    from wav2vec_s_amd.trainer import GradExchange
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    mine = flat.clone()
+    if rank == 1:
+        flat[n // 3: n // 2] = 0          # a LayerDrop-ped layer on one rank only: zeros still take part
+        mine = flat.clone()
+    ex = GradExchange(flat, dist, bucket_elems=bucket)
+    for step in range(2):                  # two steps: state must reset between them
+        flat.copy_(mine)
+        ex.begin_step()
+        for off in offsets:
+            ex.on_ready(off)
+        ex.finish()
+        covered = np.zeros(n, dtype=np.int32)
+        for lo, hi in ex.launched:
+            covered[lo:hi] += 1
+        assert (covered == 1).all(), "every element must be reduced exactly once"
+        assert all(hi - lo >= min(bucket, n) or lo == 0 for lo, hi in ex.launched)
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    want = sum(gathered)
+    ok = bool(torch.allclose(flat, want, atol=1e-6))
+    out_q.put((rank, ok, len(ex.launched)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,bucket,offsets", [
+    (10_000, 3_000, [9_500, 8_000, 6_100, 4_000, 2_500, 900, 0]),     # milestones as the backward reports them
+    (10_000, 50_000, [9_000, 5_000, 0]),                              # bucket larger than the arena: one collective
+    (4_097, 1_024, [4_000, 4_000, 10]),                               # repeated / missing final milestone
+])
+def test_grad_exchange_gloo_world2(n, bucket, offsets):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, bucket, offsets, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]          # both ranks issued the same sequence of collectives
+
+
+def test_arena_is_in_forward_order_so_backward_finalises_a_suffix():
+    import wav2vec_s_amd as w
+    from wav2vec_s_amd import engine
+    m = w.Wav2VecSModel(w.base_librispeech_config())
+    W = {n: p for n, p in m.named_parameters()}
+    A = engine.Arena(engine.grad_shapes(m.cfg, W), "cpu")
+    off = lambda pre: engine.milestone_offset(A, pre)  # noqa: E731
+    seq = [off("feature_extractor."), off("layer_norm."), off("post_extract_proj."), off("mask_emb"),
+           off("encoder.layer_norm.")] + [off(f"encoder.layers.{i}.") for i in range(12)] + \
+          [off("quantizer."), off("project_q."), off("final_proj.")]
+    assert seq == sorted(seq) and seq[0] == 0
+    # fused QKV block: q, k, v weights adjacent
+    o = A.offsets
+    e2 = 768 * 768
+    assert o["encoder.layers.3.self_attn.k_proj.weight"][0] == o["encoder.layers.3.self_attn.q_proj.weight"][0] + e2
+    assert o["encoder.layers.3.self_attn.v_proj.weight"][0] == o["encoder.layers.3.self_attn.q_proj.weight"][0] + 2 * e2
+    assert A.numel >= 90_325_120

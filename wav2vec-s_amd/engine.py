@@ -402,24 +402,54 @@ def _qkv_pack(W, pre):
 
 # ==================================================================================================
 def grad_shapes(cfg, W) -> Dict[str, tuple]:
-    """Arena layout: q/k/v weights (and biases) of a layer are adjacent so the fused QKV GEMM
-    writes one [3E, E] block; conv weights are kept tap-major [Cout, k, Cin]."""
+    """Arena layout = FORWARD order of the network (extractor, feature LN, projection, mask_emb, encoder
+    LN, layers 0..L-1, quantizer, project_q, final_proj).  The backward pass therefore finalises the
+    arena from its END towards its start, and the data-parallel exchange can all-reduce a growing
+    suffix while earlier layers are still being differentiated.  q/k/v weights (and biases) of a layer
+    are adjacent so the fused QKV GEMM writes one [3E, E] block; conv weights are tap-major."""
+    def rank(n):
+        if n.startswith("feature_extractor."):
+            return (0, int(n.split(".")[2]))
+        if n.startswith("layer_norm."):
+            return (1, 0)
+        if n.startswith("post_extract_proj."):
+            return (2, 0)
+        if n == "mask_emb":
+            return (3, 0)
+        if n.startswith("encoder.layer_norm."):
+            return (4, 0)
+        if n.startswith("encoder.layers."):
+            return (5, int(n.split(".")[2]))
+        if n.startswith("quantizer."):
+            return (6, 0)
+        if n.startswith("project_q."):
+            return (7, 0)
+        if n.startswith("final_proj."):
+            return (8, 0)
+        return (9, 0)
+
+    def within(n):
+        if n.startswith("encoder.layers."):
+            tail = n.split(".", 3)[3]
+            order = ["self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                     "self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias"]
+            return order.index(tail) if tail in order else len(order)
+        return 0
+
+    names = sorted(W.keys(), key=lambda n: (rank(n), within(n)))   # stable: keeps module order otherwise
     shapes = {}
-    order = []
-    for i in range(cfg.encoder_layers):
-        pre = f"encoder.layers.{i}."
-        order += [pre + f"self_attn.{n}_proj.weight" for n in "qkv"]
-        order += [pre + f"self_attn.{n}_proj.bias" for n in "qkv"]
-    seen = set(order)
-    order += [n for n in W if n not in seen]
-    for n in order:
-        if n not in W:
-            continue
+    for n in names:
         shp = tuple(W[n].shape)
         if n.startswith("feature_extractor.conv_layers.") and n.endswith(".0.weight"):
             shp = (shp[0], shp[2], shp[1])
         shapes[n] = shp
     return shapes
+
+
+def milestone_offset(A: "Arena", prefix: str) -> int:
+    """Lowest arena offset among parameters whose name starts with ``prefix`` (= start of that group)."""
+    offs = [o for n, (o, _, _) in A.offsets.items() if n.startswith(prefix)]
+    return min(offs) if offs else A.numel
 
 
 def _linear_bwd(dy, x, w_name, b_name, W, A, *, need_dx=True, dgelu_aux=None, add_aux=None):
@@ -430,10 +460,12 @@ def _linear_bwd(dy, x, w_name, b_name, W, A, *, need_dx=True, dgelu_aux=None, ad
     return ops.linear_dgrad(dy, wt, dgelu_aux=dgelu_aux, add_aux=add_aux)
 
 
-def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None, d_out=None):
+def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None, d_out=None, on_ready=None):
     """Accumulates parameter gradients into the arena.  d_logits fp32 [B*M, K+1] (rows (b, m));
     d_pen = dLoss/d features_pen, d_prob_ppl = dLoss/d prob_perplexity as fp32 DEVICE scalars (read by
-    the kernels, never by the host: no sync); d_out bf16 [B, T, E] for features_only."""
+    the kernels, never by the host: no sync); d_out bf16 [B, T, E] for features_only.
+    on_ready(offset): called at milestones - every arena element at index >= offset is final."""
+    ready = on_ready if on_ready is not None else (lambda off: None)
     cfg, W = st.cfg, st.W
     B, T, C0, N, Tp = st.B, st.T, st.C0, st.N, st.Tp
     E = cfg.encoder_embed_dim
@@ -469,6 +501,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         d_feats_unmasked = ops.zeros((B * T, C0), BF16, dev)
         ops.gather_rows(d_yin, st.frame_idx, RM, scatter=True, out=d_feats_unmasked)
 
+    ready(milestone_offset(A, "quantizer.") if "quantizer.weight_proj.weight" in A else A.numel)   # heads done
     # ------------------------------------------------------------------ encoder layers, reversed
     post_ln = not cfg.layer_norm_first
     if post_ln:
@@ -509,6 +542,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                                ("g_ln2_g", "final_layer_norm.weight"), ("g_ln2_b", "final_layer_norm.bias")):
                     setattr(d, f_, fp + 4 * A.offsets[pre + n_][0])
                 _lib.call("w2vs_layer_bwd", C.byref(d), stream)
+                ready(milestone_offset(A, pre))
                 if jj & 1:
                     cur = alt
                 else:
@@ -547,6 +581,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                                  st.layers[0]["mean1"], st.layers[0]["rstd1"], A.view(pre + "self_attn_layer_norm.weight"),
                                  A.view(pre + "self_attn_layer_norm.bias"), dy=d_n, dsum=d_s)
 
+    ready(milestone_offset(A, "encoder.layers.0."))
     # ------------------------------------------------------------------ prologue
     table = _pos_table(E, dev)
     d_xproj = ops.enc_prologue_bwd(
@@ -565,6 +600,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         d_feats = d_xproj.view(B * T, C0)
         if d_feats_unmasked is not None:
             raise W2vsError("conv dim == encoder dim with the pre-training head is not built")
+    ready(milestone_offset(A, "post_extract_proj.") if "post_extract_proj.weight" in A else milestone_offset(A, "mask_emb"))
     # ------------------------------------------------------------------ feature LN + penalty + GradMultiply
     convs = cfg.conv_layers
     last = st.conv[-1]
@@ -573,6 +609,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
     if gm <= 0:
         ops.ln_bwd(st.y_last, W["layer_norm.weight"], W["layer_norm.bias"], st.f_mean, st.f_rstd,
                    A.view("layer_norm.weight"), A.view("layer_norm.bias"), dy=d_feats, want_dx=False)
+        ready(0)
         return
     aux = last.get("pre") if (len(st.conv) > 1 and not last["ln"]) else None
     d_cur, _ = ops.ln_bwd(st.y_last, W["layer_norm.weight"], W["layer_norm.bias"], st.f_mean, st.f_rstd,

@@ -233,7 +233,8 @@ class _HotPath(torch.autograd.Function):
             d_logits, d_pen, d_ppl = grads[0], grads[1], grads[2]
             d_logits = torch.zeros_like(st.logits) if d_logits is None else d_logits.float().contiguous()
             fix = lambda t: None if t is None else t.detach().float().reshape(1).contiguous()  # noqa: E731
-            engine.backward(st, A, d_logits=d_logits, d_pen=fix(d_pen), d_prob_ppl=fix(d_ppl))
+            engine.backward(st, A, d_logits=d_logits, d_pen=fix(d_pen), d_prob_ppl=fix(d_ppl),
+                            on_ready=model._on_grad_ready)
         if flat_mode:
             ctx.st = None
             return (None,) * (6 + len(names))   # gradients stay in the arena (see trainer.FlatParams)
@@ -299,6 +300,7 @@ class Wav2Vec2Model(nn.Module):
         self.final_proj = nn.Linear(cfg.encoder_embed_dim, final_dim)
         self._rng_counter = 0
         self._flat = None                    # trainer.FlatParams when flat storage is active
+        self._on_grad_ready = None           # trainer.GradExchange hook: overlap all-reduce with backward
         self._last_state = None
         self._draws = None
         self.load_pretrained_model(cfg)

@@ -52,6 +52,56 @@ class FlatParams:
         self.arena.flat.zero_()
 
 
+class GradExchange:
+    """Data-parallel gradient exchange over a flat fp32 arena (device agnostic: RCCL on MI355X, gloo in
+    the CPU tests).  Replaces LegacyDistributedDataParallel.all_reduce_grads
+    (fs/distributed/legacy_distributed_data_parallel.py:81-170), which copies every gradient into a
+    2^28-element buffer and issues ONE all-reduce strictly after backward.
+
+    Here the backward pass reports milestones ("every element at index >= offset is final"; the arena
+    is laid out so that backward finalises it from the end, engine.grad_shapes) and each newly final
+    range is all-reduced immediately with async_op=True, in buckets of >= ``bucket_elems`` elements:
+    the collective of layer i+1 runs on RCCL's stream while layer i is still being differentiated.
+    xGMI is point-to-point (7 links x ~153 GB/s): buckets are kept large (default 16 M floats = 64 MB)
+    so the per-collective latency of a ring over 8 GPUs is amortised.  SUM only - the division by the
+    global sample_size happens once, inside the fused Adam kernel."""
+
+    def __init__(self, flat: torch.Tensor, dist_module, bucket_elems: int = 16 << 20, group=None):
+        self.flat, self.dist, self.bucket, self.group = flat, dist_module, int(bucket_elems), group
+        self.hi = flat.numel()
+        self.works = []
+        self.launched = []      # (lo, hi) ranges, for tests / tracing
+
+    def begin_step(self):
+        self.hi = self.flat.numel()
+        self.works, self.launched = [], []
+
+    def on_ready(self, offset: int):
+        """Elements [offset, numel) are final.  Launch whole buckets; keep a remainder < bucket for later
+        unless offset == 0 (flush everything)."""
+        offset = max(0, min(int(offset), self.hi))
+        while self.hi - offset >= self.bucket or (offset == 0 and self.hi > 0):
+            lo = max(offset, self.hi - self.bucket) if self.hi - offset >= self.bucket else 0
+            if offset == 0 and self.hi - lo < self.bucket:
+                lo = 0
+            self._launch(lo, self.hi)
+            self.hi = lo
+
+    def _launch(self, lo, hi):
+        if hi <= lo:
+            return
+        w = self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.works.append(w)
+        self.launched.append((lo, hi))
+
+    def finish(self):
+        """Flush what is left and make the current stream wait for every collective."""
+        self.on_ready(0)
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 class TrainStep:
     """zero_grad -> forward -> criterion -> backward -> [all-reduce] -> Adam.  One call = one update
     with update_freq = 1 (the bench's step)."""
@@ -63,9 +113,12 @@ class TrainStep:
         self.use_optimizer = use_optimizer
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
         self.dist = None
+        self.exchange = None
         if world_size > 1:
             import torch.distributed as dist
             self.dist = dist
+            self.exchange = GradExchange(self.flat.arena.flat, dist)
+            model._on_grad_ready = self.exchange.on_ready
         self.norm_buf = torch.zeros(1, device=self.flat.p16.device, dtype=torch.float32)
         # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB
         ops.ARENA.activate(int(arena_gib * (1 << 30)), self.flat.p16.device)
@@ -74,16 +127,25 @@ class TrainStep:
         f = self.flat
         ops.ARENA.reset()
         f.zero_grad()
+        if self.exchange is not None:
+            self.exchange.begin_step()
         loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
-        loss.backward()
+        loss.backward()                           # milestones inside launch the bucketed all-reduces
         total = sample_size
-        if self.dist is not None:
-            # sum of gradients over ranks (legacy_ddp: pre-divide by world, trainer multiplies back)
-            self.dist.all_reduce(f.arena.flat, op=self.dist.ReduceOp.SUM)
-            total = sample_size * self.world      # every rank has the same M in this workload
+        if self.exchange is not None:
+            self.exchange.finish()
+            # the global sample_size: mask lengths can differ across ranks (own batches, own masks)
+            ss = torch.tensor([float(sample_size)], device=f.p16.device)
+            self.dist.all_reduce(ss)
+            self.ss_dev = ss
+            total = None
         if self.use_optimizer:
             f.step += 1
-            scale = 1.0 / float(total)
+            scale_dev = None
+            if total is None:
+                scale, scale_dev = 1.0, self.ss_dev.reciprocal_()     # 1 / sum of sample_size over ranks, on device
+            else:
+                scale = 1.0 / float(total)
             if self.clip > 0:
                 self.norm_buf.zero_()
                 ops.sumsq(f.arena.flat, self.norm_buf)
@@ -91,5 +153,5 @@ class TrainStep:
                 if gnorm > self.clip:
                     scale *= self.clip / (gnorm + 1e-6)
             ops.adam_step(f.p32, f.p16, f.m, f.v, f.arena.flat, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                          eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale)
+                          eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale, scale_dev=scale_dev)
         return loss.detach()
