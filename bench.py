@@ -94,9 +94,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("W2VS_FORCE_DIST") == "1"   # exercise the RCCL path with a 1-rank group
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -110,7 +114,8 @@ def main():
     torch.manual_seed(1)                       # identical replicas on every rank
     model = w.Wav2VecSModel(cfg).to(torch.bfloat16).to(dev).train()
     crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0], log_keys=["prob_perplexity", "code_perplexity", "temp"])
-    step_fn = trainer.TrainStep(model, crit, world_size=world, use_optimizer=not args.no_optimizer,
+    step_fn = trainer.TrainStep(model, crit, world_size=max(world, 2) if force_dist else world,
+                                use_optimizer=not args.no_optimizer,
                                 lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
     B, L = args.batch, args.samples
     g = torch.Generator().manual_seed(1234 + rank)
