@@ -24,6 +24,23 @@ namespace w2vs {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_ELEMS = BM * BK;  // == BN*BK
 
+// Tile order.  (1) Workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an L2), so each
+// XCD is given a CONTIGUOUS run of tile ids.  (2) Inside that run, ids walk GM M-tiles x all N-tiles
+// "group-M" fashion (m fastest within a group of GM), so the ~64-96 blocks in flight on an XCD touch
+// only ~GM A-panels and a few B-panels: their footprint stays inside the 4 MiB L2 instead of streaming
+// the whole B operand once per M-tile (measured with FETCH_SIZE: 3.5-5x the algorithmic bytes before).
+__device__ __forceinline__ void tile_order(int orig, int ntm, int ntn, int GM, int& tm, int& tn) {
+  const int nwg = ntm * ntn;
+  const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+  const int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  const int per_group = GM * ntn;
+  const int group = id / per_group, first_m = group * GM;
+  const int gsz = min(ntm - first_m, GM);
+  const int in_group = id - group * per_group;
+  tm = first_m + in_group % gsz;
+  tn = in_group / gsz;
+}
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
 struct GemmP {
@@ -52,13 +69,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_nt_kernel(GemmP p) {
   const int wm = wid >> 1, wn = wid & 1;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so give
   // every XCD a contiguous run of tiles - the N-tiles of one M-tile then share that XCD's L2 copy of A.
-  int tile_id;
-  {
-    const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
-    tile_id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
-  }
-  const int m0 = (tile_id / gridDim.x) * BM, n0 = (tile_id % gridDim.x) * BN;
+  int tm_, tn_;
+  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, 8, tm_, tn_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int bz = blockIdx.z;
 
   const bf16* Ab = p.A + (long)bz * p.sA;
@@ -238,18 +251,25 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_nt_kernel(GemmP p) {
 // ds_read_b64_tr_b16 (hardware transpose), two reads per 8-deep k group.
 // ---------------------------------------------------------------------------------------------
 constexpr int TK = 64;  // k rows per tile
-// tile [64 k][128 m] bf16: row pitch 256 B + 16 B pad -> 272 B (136 elems) keeps tr reads spread
-constexpr int TP = 136;
+// tile [64 k][128 m] bf16, unpadded 256-B rows.  A 16-lane tr-read group touches 4 rows x 32 B and the
+// two groups of a 32-lane half sit 8 rows apart: XOR-ing the 32-B-window index with
+// w = (row & 3) + 4 * ((row >> 3) & 1) puts those 8 (row, window) pieces on 8 disjoint bank windows.
+constexpr int TP = 128;
+__device__ __forceinline__ int tswz(int row, int col) {
+  return row * TP + (col ^ ((((row & 3) | (((row >> 3) & 1) << 2))) << 4));
+}
 
 __device__ __forceinline__ s16x4 ds_tr(const bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
-  __shared__ __attribute__((aligned(16))) bf16 lds[4 * TK * TP];  // A0 A1 B0 B1 : 4*64*136*2 = 69632 B
+  __shared__ __attribute__((aligned(16))) bf16 lds[4 * TK * TP];  // A0 A1 B0 B1 : 4*64*128*2 = 65536 B
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tm_, tn_;
+  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, 4, tm_, tn_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int bz = blockIdx.z / p.n_split, sp = blockIdx.z % p.n_split;
   const int k_begin = sp * p.k_split;
   const int k_end = min(p.K, k_begin + p.k_split);
@@ -264,13 +284,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
   for (int j = 0; j < 4; ++j) {
     int c = tid + 256 * j, row = c >> 4, cc = c & 15;
     krow[j] = row;
-    l_off[j] = row * TP + cc * 8;
+    l_off[j] = tswz(row, cc * 8);
     a_col[j] = (m0 + cc * 8 < p.M) ? (uint32_t)((m0 + cc * 8) * 2) : 0xFFFFFFF0u;
     b_col[j] = (n0 + cc * 8 < p.N) ? (uint32_t)((n0 + cc * 8) * 2) : 0xFFFFFFF0u;
   }
   u32x4 ra_reg[4], rb_reg[4];
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = p.colsum != nullptr && tn_ == 0;
   auto gload = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -323,14 +343,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
       const int kr = ks * 32 + g * 8 + q;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bf16* base = sa + kr * TP + wm * 64 + i * 16 + pp * 4;
-        s16x4 lo = ds_tr(base), hi = ds_tr(base + 4 * TP);
+        const int col = wm * 64 + i * 16 + pp * 4;
+        s16x4 lo = ds_tr(sa + tswz(kr, col)), hi = ds_tr(sa + tswz(kr + 4, col));
         union { bf16x8 v; s16x4 h[2]; } u; u.h[0] = lo; u.h[1] = hi; af[i] = u.v;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bf16* base = sb + kr * TP + wn * 64 + j * 16 + pp * 4;
-        s16x4 lo = ds_tr(base), hi = ds_tr(base + 4 * TP);
+        const int col = wn * 64 + j * 16 + pp * 4;
+        s16x4 lo = ds_tr(sb + tswz(kr, col)), hi = ds_tr(sb + tswz(kr + 4, col));
         union { bf16x8 v; s16x4 h[2]; } u; u.h[0] = lo; u.h[1] = hi; bfr[j] = u.v;
       }
 #pragma unroll
