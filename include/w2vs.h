@@ -80,6 +80,15 @@ int w2vs_conv0_bwd(const void* wave, const void* w, const void* conv_bias, const
                    const float* mean, const float* rstd, const void* dy, float* dw, float* dconv_bias,
                    float* dln_w, float* dln_b, int B, int L, int C, int k, int s, void* stream);
 
+/* conv layer 0 of extractor_mode="default": Conv1d + Fp32GroupNorm(C, C) + GELU (wav2vec2.py:744-750).
+ * Statistics run over time per (b, c): stat [B, C, 2] = {sum, sumsq} written by fwd and read by bwd;
+ * bstat [B, C, 2] is backward scratch.  Each direction is two passes (stats, apply) over the waveform. */
+int w2vs_conv0_gn_fwd(const void* wave, const void* w, const void* conv_bias, const void* gn_w, const void* gn_b,
+                      void* y, float* stat, int B, int L, int C, int k, int s, void* stream);
+int w2vs_conv0_gn_bwd(const void* wave, const void* w, const void* conv_bias, const void* gn_w, const void* gn_b,
+                      const float* stat, const void* dy, float* bstat, float* dw, float* dconv_bias, float* dgn_w,
+                      float* dgn_b, int B, int L, int C, int k, int s, void* stream);
+
 /* ---- row LayerNorm family --------------------------------------------------------------------
  * fwd:  s = dropout(x) [+ res] ; sum_out = s ; y = [gelu] LN(s)
  *   self.layer_norm wav2vec2.py:556-557 (+ features_pen :554 via sumsq),

@@ -137,6 +137,28 @@ def test_conv0_ln_gelu(ops):
     assert rel(db, P["feature_extractor.conv_layers.0.2.1.bias"].grad) < 5e-3
 
 
+def test_conv0_groupnorm_gelu(ops):
+    """extractor_mode='default': conv layer 0 + Fp32GroupNorm(C, C) + GELU (wav2vec2.py:744-750)."""
+    B, L, Cc, k, s = 3, 3003, 512, 10, 5
+    wave = rnd(B, L, seed=1)
+    w = rnd(Cc, 1, k, seed=2, scale=0.4)
+    g, b = (1 + 0.1 * torch.randn(Cc)).to(BF), (0.1 * torch.randn(Cc)).to(BF)
+    y, stat = ops.conv0_gn_fwd(dev(wave), dev(w), dev(g), dev(b), k, s)
+    P = {"feature_extractor.conv_layers.0.0.weight": w.float().requires_grad_(True),
+         "feature_extractor.conv_layers.0.2.weight": g.float().requires_grad_(True),
+         "feature_extractor.conv_layers.0.2.bias": b.float().requires_grad_(True)}
+    cfg = O.OracleCfg(conv_feature_layers="[(512, 10, 5)]", extractor_mode="default")
+    ref = O.conv_feature_extractor(wave.float(), P, cfg)
+    assert rel(y, ref.transpose(1, 2)) < 5e-3
+    dy = rnd(*y.shape, seed=5)
+    ref.backward(dy.float().transpose(1, 2))
+    dw = torch.zeros(Cc, k, device="cuda"); dg = torch.zeros(Cc, device="cuda"); db = torch.zeros(Cc, device="cuda")
+    ops.conv0_gn_bwd(dev(wave), dev(w), dev(g), dev(b), stat, dev(dy), k, s, dw, dg, db)
+    assert rel(dw, P["feature_extractor.conv_layers.0.0.weight"].grad.view(Cc, k)) < 8e-3
+    assert rel(dg, P["feature_extractor.conv_layers.0.2.weight"].grad) < 5e-3
+    assert rel(db, P["feature_extractor.conv_layers.0.2.bias"].grad) < 5e-3
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("Cc", [512, 768, 1024])
 def test_layernorm_fwd_bwd(ops, Cc):

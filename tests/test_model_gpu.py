@@ -35,7 +35,7 @@ def _setup(cfg_kw, B, L, seed, m_ctx, r_ctx, train=True):
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for n, p in model.named_parameters():
-            if n.endswith("bias") or "layer_norm" in n or ".2.1." in n:
+            if n.endswith("bias") or "layer_norm" in n or ".2.1." in n or ".2.weight" in n:
                 p.add_(torch.randn(p.shape, generator=g) * 0.05)
     model = model.to(BF)
     # oracle sees exactly the bf16-rounded parameters, in fp32
@@ -131,6 +131,18 @@ def test_large_style_model_step_matches_oracle():
     rep, grads = _run_both(kw, B=3, L=16400, seed=2, m_ctx=8, r_ctx=4, loss_weights=(0.1, 0.0), tag="large_style")
     assert rep["loss_rel"] < 2e-3, rep
     assert rep["enc_out"] < 2e-2 and rep["features"] < 2e-2, rep
+    bad = {n: e for n, e in grads.items() if e > 0.1 and "k_proj.bias" not in n}
+    assert not bad, bad
+
+
+def test_groupnorm_extractor_model_step_matches_oracle():
+    """extractor_mode='default' (wav2vec 2.0 base checkpoints): GroupNorm on conv layer 0, no norm elsewhere."""
+    kw = dict(BASE, extractor_mode="default", encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+              encoder_attention_heads=2, final_dim=128, latent_vars=40, num_negatives=20,
+              conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
+    rep, grads = _run_both(kw, B=2, L=16000, seed=5, m_ctx=8, r_ctx=4, loss_weights=(0.1, 10.0), tag="groupnorm")
+    assert rep["loss_rel"] < 2e-3, rep
+    assert rep["conv0"] < 1e-2 and rep["enc_out"] < 2e-2, rep
     bad = {n: e for n, e in grads.items() if e > 0.1 and "k_proj.bias" not in n}
     assert not bad, bad
 

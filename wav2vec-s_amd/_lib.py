@@ -85,6 +85,8 @@ _SIGS = {
     "w2vs_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)],
     "w2vs_conv0_fwd": [vp] * 8 + [i32] * 5 + [vp],
     "w2vs_conv0_bwd": [vp] * 12 + [i32] * 5 + [vp],
+    "w2vs_conv0_gn_fwd": [vp] * 7 + [i32] * 5 + [vp],
+    "w2vs_conv0_gn_bwd": [vp] * 12 + [i32] * 5 + [vp],
     "w2vs_ln_fwd": [C.POINTER(LnFwdDesc), vp],
     "w2vs_ln_bwd": [C.POINTER(LnBwdDesc), vp],
     "w2vs_enc_prologue_fwd": [C.POINTER(EncPrologueDesc), vp],

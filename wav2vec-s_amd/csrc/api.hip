@@ -46,6 +46,15 @@ int w2vs_conv0_bwd(const void* wave, const void* w, const void* cb, const void* 
                    int k, int st, void* s) {
   return conv0_bwd(wave, w, cb, lw, lb, mean, rstd, dy, dw, dcb, dlw, dlb, B, L, C, k, st, ST(s));
 }
+int w2vs_conv0_gn_fwd(const void* wave, const void* w, const void* cb, const void* g, const void* b, void* y, float* stat,
+                      int B, int L, int C, int k, int st, void* s) {
+  return conv0_gn_fwd(wave, w, cb, g, b, y, stat, B, L, C, k, st, ST(s));
+}
+int w2vs_conv0_gn_bwd(const void* wave, const void* w, const void* cb, const void* g, const void* b, const float* stat,
+                      const void* dy, float* bstat, float* dw, float* dcb, float* dg, float* db, int B, int L, int C, int k,
+                      int st, void* s) {
+  return conv0_gn_bwd(wave, w, cb, g, b, stat, dy, bstat, dw, dcb, dg, db, B, L, C, k, st, ST(s));
+}
 int w2vs_ln_fwd(const w2vs_ln_fwd_desc* d, void* s) { NONNULL(d); return ln_fwd(*d, ST(s)); }
 int w2vs_ln_bwd(const w2vs_ln_bwd_desc* d, void* s) { NONNULL(d); return ln_bwd(*d, ST(s)); }
 int w2vs_enc_prologue_fwd(const w2vs_enc_prologue_desc* d, void* s) { NONNULL(d); return enc_prologue_fwd(*d, ST(s)); }

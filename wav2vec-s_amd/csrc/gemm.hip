@@ -394,7 +394,7 @@ static std::vector<ProfSample> g_prof;
 static int g_prof_stride = 0;
 static long g_prof_count = 0;
 void prof_enable(int stride) {
-  for (auto& s : g_prof) { hipEventDestroy(s.e0); hipEventDestroy(s.e1); }
+  for (auto& s : g_prof) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
   g_prof.clear();
   g_prof_stride = stride;
   g_prof_count = 0;
@@ -404,14 +404,14 @@ static inline hipEvent_t prof_begin(hipStream_t st) {
   if ((g_prof_count++ % g_prof_stride) != 0) return nullptr;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
-  hipEventRecord(e, st);
+  (void)hipEventRecord(e, st);
   return e;
 }
 static inline void prof_end(hipEvent_t e0, int id, double flops, hipStream_t st) {
   if (!e0) return;
   hipEvent_t e1;
   if (hipEventCreate(&e1) != hipSuccess) return;
-  hipEventRecord(e1, st);
+  (void)hipEventRecord(e1, st);
   g_prof.push_back({e0, e1, id, flops});
 }
 int prof_read(int id, double* total_ms, double* total_flops, int* launches) {

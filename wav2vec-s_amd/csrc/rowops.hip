@@ -224,6 +224,160 @@ int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* ln
 }
 
 // =====================================================================================
+// conv layer 0, extractor_mode="default": Conv1d(1->C,k,s) -> Fp32GroupNorm(C groups = C channels)
+// -> GELU (fs/models/wav2vec/wav2vec2.py:744-750).  The statistics run over TIME per (b, c), so
+// each direction is two passes over the (tiny) waveform; the conv output is recomputed, never stored.
+//   FWD_STATS : stat[b][c] += {sum, sumsq} of the conv output
+//   FWD_APPLY : y = gelu((c0 - mean) * rstd * gamma + beta)
+//   BWD_STATS : s[b][c] += {sum dxhat, sum dxhat*xhat};  dgamma, dbeta
+//   BWD_APPLY : dconv = rstd * (dxhat - s1/L0 - xhat * s2/L0);  dW, dbias
+// =====================================================================================
+enum { GN_FWD_STATS = 0, GN_FWD_APPLY = 1, GN_BWD_STATS = 2, GN_BWD_APPLY = 3 };
+struct Conv0GnP {
+  const bf16* wave; const bf16* w; const bf16* cbias; const bf16* g; const bf16* b;
+  bf16* y; float* stat;          // [B][C][2] sum, sumsq
+  const bf16* dy; float* bstat;  // [B][C][2] s1, s2
+  float* dw; float* dcbias; float* dg; float* db;
+  int B, L, L0, C, k, s, rows_per_block;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv0_gn_kernel(Conv0GnP p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int C = p.C, K = p.k, bi = blockIdx.y;
+  const bool act = lane < nchunks(C);
+  float w[8][10], cb[8], g[8], bb[8], mean[8], rstd[8], m1[8], m2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = lane * 8 + e;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w[e][j] = (act && j < K) ? bf2f(p.w[c * K + j]) : 0.f;
+    cb[e] = (act && p.cbias) ? bf2f(p.cbias[c]) : 0.f;
+    g[e] = act ? bf2f(p.g[c]) : 0.f;
+    bb[e] = act ? bf2f(p.b[c]) : 0.f;
+    mean[e] = 0.f; rstd[e] = 0.f; m1[e] = 0.f; m2[e] = 0.f;
+    if (MODE != GN_FWD_STATS && act) {
+      float sm = p.stat[((long)bi * C + c) * 2], sq = p.stat[((long)bi * C + c) * 2 + 1];
+      mean[e] = sm / (float)p.L0;
+      rstd[e] = rsqrtf(fmaxf(sq / (float)p.L0 - mean[e] * mean[e], 0.f) + LN_EPS);
+    }
+    if (MODE == GN_BWD_APPLY && act) {
+      m1[e] = p.bstat[((long)bi * C + c) * 2] / (float)p.L0;
+      m2[e] = p.bstat[((long)bi * C + c) * 2 + 1] / (float)p.L0;
+    }
+  }
+  float a0[8], a1[8], dwv[8][10];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a0[e] = a1[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) dwv[e][j] = 0.f;
+  }
+  float a2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int t0 = blockIdx.x * p.rows_per_block, t1 = min(p.L0, t0 + p.rows_per_block);
+  for (int t = t0 + wid; t < t1; t += 4) {
+    const bf16* xw = p.wave + (long)bi * p.L + (long)t * p.s;
+    float x[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) x[j] = (j < K) ? bf2f(xw[j]) : 0.f;
+    const long row = (long)bi * p.L0 + t;
+    bf16x8 dyv;
+    if ((MODE == GN_BWD_STATS || MODE == GN_BWD_APPLY) && act) dyv = *(const bf16x8*)(p.dy + row * C + lane * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float c0 = cb[e];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) c0 = fmaf(w[e][j], x[j], c0);
+      if (MODE == GN_FWD_STATS) { a0[e] += c0; a1[e] += c0 * c0; continue; }
+      const float xh = (c0 - mean[e]) * rstd[e];
+      const float z = xh * g[e] + bb[e];
+      if (MODE == GN_FWD_APPLY) { o[e] = f2bf(gelu_exact(z)); continue; }
+      const float dz = act ? bf2f(dyv[e]) * gelu_grad(z) : 0.f;
+      const float dxh = dz * g[e];
+      if (MODE == GN_BWD_STATS) { a0[e] += dxh; a1[e] += dxh * xh; a2[e] += dz * xh; a3[e] += dz; continue; }
+      const float dc = rstd[e] * (dxh - m1[e] - xh * m2[e]);
+      a0[e] += dc;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) dwv[e][j] = fmaf(dc, x[j], dwv[e][j]);
+    }
+    if (MODE == GN_FWD_APPLY && act) *(bf16x8*)(p.y + row * C + lane * 8) = o;
+  }
+  if (MODE == GN_FWD_APPLY) return;
+  // block reduction through LDS, then one global atomic per value per block
+  __shared__ float red[512 * 14];
+  const int nval = (MODE == GN_BWD_APPLY) ? (1 + K) : (MODE == GN_BWD_STATS ? 4 : 2);
+  for (int i = threadIdx.x; i < C * nval; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = lane * 8 + e;
+      atomicAdd(&red[c * nval + 0], a0[e]);
+      if (MODE != GN_BWD_APPLY) atomicAdd(&red[c * nval + 1], a1[e]);
+      if (MODE == GN_BWD_STATS) { atomicAdd(&red[c * nval + 2], a2[e]); atomicAdd(&red[c * nval + 3], a3[e]); }
+      if (MODE == GN_BWD_APPLY) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+          if (j < K) atomicAdd(&red[c * nval + 1 + j], dwv[e][j]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    if (MODE == GN_FWD_STATS) {
+      atomicAdd(&p.stat[((long)bi * C + c) * 2], red[c * nval]);
+      atomicAdd(&p.stat[((long)bi * C + c) * 2 + 1], red[c * nval + 1]);
+    } else if (MODE == GN_BWD_STATS) {
+      atomicAdd(&p.bstat[((long)bi * C + c) * 2], red[c * nval]);
+      atomicAdd(&p.bstat[((long)bi * C + c) * 2 + 1], red[c * nval + 1]);
+      atomicAdd(&p.dg[c], red[c * nval + 2]);
+      atomicAdd(&p.db[c], red[c * nval + 3]);
+    } else {
+      if (p.dcbias) atomicAdd(&p.dcbias[c], red[c * nval]);
+      for (int j = 0; j < K; ++j) atomicAdd(&p.dw[c * K + j], red[c * nval + 1 + j]);
+    }
+  }
+}
+
+static int conv0_gn_fill(Conv0GnP& p, const void* wave, const void* w, const void* cbias, const void* g, const void* b,
+                         float* stat, int B, int L, int C, int k, int s) {
+  if (!wave || !w || !g || !b || !stat) return set_error("conv0_gn: null pointer");
+  if (C % 8 || C > 512 || k > 10 || k < 1 || s < 1 || L < k) return set_error("conv0_gn: need C%8==0, C<=512, k<=10, L>=k");
+  p.wave = (const bf16*)wave; p.w = (const bf16*)w; p.cbias = (const bf16*)cbias; p.g = (const bf16*)g; p.b = (const bf16*)b;
+  p.stat = stat; p.B = B; p.L = L; p.L0 = (L - k) / s + 1; p.C = C; p.k = k; p.s = s;
+  p.rows_per_block = std::max(64, (p.L0 * B + 1023) / 1024);
+  return 0;
+}
+
+int conv0_gn_fwd(const void* wave, const void* w, const void* cbias, const void* g, const void* b, void* y, float* stat,
+                 int B, int L, int C, int k, int s, hipStream_t st) {
+  Conv0GnP p{};
+  if (int e = conv0_gn_fill(p, wave, w, cbias, g, b, stat, B, L, C, k, s)) return e;
+  if (!y) return set_error("conv0_gn_fwd: null output");
+  p.y = (bf16*)y;
+  if (int e = hip_check(hipMemsetAsync(stat, 0, sizeof(float) * 2 * B * C, st), "memset")) return e;
+  dim3 grid((p.L0 + p.rows_per_block - 1) / p.rows_per_block, B);
+  hipLaunchKernelGGL(conv0_gn_kernel<GN_FWD_STATS>, grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(conv0_gn_kernel<GN_FWD_APPLY>, grid, dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "conv0_gn_fwd");
+}
+
+int conv0_gn_bwd(const void* wave, const void* w, const void* cbias, const void* g, const void* b, const float* stat,
+                 const void* dy, float* bstat, float* dw, float* dcbias, float* dg, float* db, int B, int L, int C, int k,
+                 int s, hipStream_t st) {
+  Conv0GnP p{};
+  if (int e = conv0_gn_fill(p, wave, w, cbias, g, b, const_cast<float*>(stat), B, L, C, k, s)) return e;
+  if (!dy || !bstat || !dw || !dg || !db) return set_error("conv0_gn_bwd: null pointer");
+  p.dy = (const bf16*)dy; p.bstat = bstat; p.dw = dw; p.dcbias = dcbias; p.dg = dg; p.db = db;
+  if (int e = hip_check(hipMemsetAsync(bstat, 0, sizeof(float) * 2 * B * C, st), "memset")) return e;
+  dim3 grid((p.L0 + p.rows_per_block - 1) / p.rows_per_block, B);
+  hipLaunchKernelGGL(conv0_gn_kernel<GN_BWD_STATS>, grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(conv0_gn_kernel<GN_BWD_APPLY>, grid, dim3(256), 0, st, p);
+  return hip_check(hipGetLastError(), "conv0_gn_bwd");
+}
+
+// =====================================================================================
 // Generic LayerNorm forward / backward over rows (used by feat_ln, conv LN layers of the
 // large model, add_dropout_ln).  Modes are compile-time flags.
 // =====================================================================================

@@ -27,6 +27,11 @@ int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* ln
 int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, const float* mean,
               const float* rstd, const void* dy, float* dw, float* dcbias, float* dlnw, float* dlnb, int B, int L, int C,
               int k, int s, hipStream_t st);
+int conv0_gn_fwd(const void* wave, const void* w, const void* cbias, const void* g, const void* b, void* y, float* stat,
+                 int B, int L, int C, int k, int s, hipStream_t st);
+int conv0_gn_bwd(const void* wave, const void* w, const void* cbias, const void* g, const void* b, const float* stat,
+                 const void* dy, float* bstat, float* dw, float* dcbias, float* dg, float* db, int B, int L, int C, int k,
+                 int s, hipStream_t st);
 int ln_fwd(const LnFwdDesc& d, hipStream_t st);
 int ln_bwd(const LnBwdDesc& d, hipStream_t st);
 int enc_prologue_fwd(const EncPrologueDesc& d, hipStream_t st);

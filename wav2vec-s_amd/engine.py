@@ -105,9 +105,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     dev = source.device
     B, L = source.shape
     convs = cfg.conv_layers
-    if cfg.extractor_mode != "layer_norm":
-        raise W2vsError("extractor_mode='default' (GroupNorm on conv layer 0) is not built yet; wav2vec-S "
-                        "configs use 'layer_norm'")
+    group_norm = cfg.extractor_mode == "default"
     if cfg.activation_dropout != 0.0 and training:
         raise W2vsError("activation_dropout > 0 is not built (wav2vec-S configs use 0.0)")
     if cfg.quantize_input or cfg.target_glu or cfg.negatives_from_everywhere or cfg.cross_sample_negatives \
@@ -209,10 +207,15 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     if w0 is None:
         w0 = W[_pname(0, "0.weight")]
     st.packed[0] = w0                      # Cin == 1: [C, 1, k] and [C, k*1] are the same bytes
-    y, mean, rstd = ops.conv0_fwd(source, w0, W[_pname(0, "2.1.weight")],
-                                  W[_pname(0, "2.1.bias")], k0, s0, conv_bias=W.get(_pname(0, "0.bias")))
     st.source = source
-    st.conv.append(dict(y=y, mean=mean, rstd=rstd))
+    if group_norm:   # Fp32GroupNorm(C, C) on layer 0 only (wav2vec2.py:744-750, 767)
+        y, gstat = ops.conv0_gn_fwd(source, w0, W[_pname(0, "2.weight")], W[_pname(0, "2.bias")], k0, s0,
+                                    conv_bias=W.get(_pname(0, "0.bias")))
+        st.conv.append(dict(y=y, gstat=gstat))
+    else:
+        y, mean, rstd = ops.conv0_fwd(source, w0, W[_pname(0, "2.1.weight")],
+                                      W[_pname(0, "2.1.bias")], k0, s0, conv_bias=W.get(_pname(0, "0.bias")))
+        st.conv.append(dict(y=y, mean=mean, rstd=rstd))
     x = y
     for i in range(1, len(convs)):
         dim, k, s = convs[i]
@@ -221,7 +224,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
             w2 = ops.conv_pack_weight(W[_pname(i, "0.weight")])
         st.packed[i] = w2
         bias = W.get(_pname(i, "0.bias"))
-        rec = dict(x_in=x, k=k, s=s, ln=(i < ln_num))
+        rec = dict(x_in=x, k=k, s=s, ln=(not group_norm and i < ln_num))
         if rec["ln"]:
             c = ops.conv_cl_fwd(x, w2, k, s, bias, gelu=False, save_pre=False)
             y, _, mean, rstd = ops.ln_fwd(c, W[_pname(i, "2.1.weight")], W[_pname(i, "2.1.bias")], gelu=True)
@@ -632,6 +635,13 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         d_cur = ops.conv_cl_dgrad(d_c, st.packed[i], k, s, x_in.shape[1], dgelu_aux=prev_aux)
     dim0, k0, s0 = convs[0]
     r0 = st.conv[0]
+    if cfg.extractor_mode == "default":
+        ops.conv0_gn_bwd(st.source, st.packed[0], W[_pname(0, "2.weight")], W[_pname(0, "2.bias")], r0["gstat"], d_cur,
+                         k0, s0, A.view(_pname(0, "0.weight")).view(dim0, k0), A.view(_pname(0, "2.weight")),
+                         A.view(_pname(0, "2.bias")), conv_bias=W.get(_pname(0, "0.bias")),
+                         dconv_bias=A.view(_pname(0, "0.bias")) if _pname(0, "0.bias") in A else None)
+        ready(0)
+        return
     ops.conv0_bwd(st.source, st.packed[0], W[_pname(0, "2.1.weight")], W[_pname(0, "2.1.bias")], r0["mean"],
                   r0["rstd"], d_cur, k0, s0, A.view(_pname(0, "0.weight")).view(dim0, k0), A.view(_pname(0, "2.1.weight")),
                   A.view(_pname(0, "2.1.bias")), conv_bias=W.get(_pname(0, "0.bias")),

@@ -314,6 +314,27 @@ def conv0_bwd(wave, w, ln_w, ln_b, mean, rstd, dy, k, s, dw, dln_w, dln_b, conv_
               _p(dw), _p(dconv_bias), _p(dln_w), _p(dln_b), B, L, Cc, k, s, _stream())
 
 
+def conv0_gn_fwd(wave, w, gn_w, gn_b, k, s, conv_bias=None):
+    _chk(wave, BF16, "wave"); _chk(w, BF16, "w"); _chk(gn_w, BF16, "gn_w"); _chk(gn_b, BF16, "gn_b")
+    B, L = wave.shape
+    Cc = w.shape[0]
+    L0 = (L - k) // s + 1
+    y = empty((B, L0, Cc), BF16, wave.device)
+    stat = empty((B, Cc, 2), torch.float32, wave.device)
+    _lib.call("w2vs_conv0_gn_fwd", _p(wave), _p(w), _p(conv_bias), _p(gn_w), _p(gn_b), _p(y), _p(stat), B, L, Cc, k, s,
+              _stream())
+    return y, stat
+
+
+def conv0_gn_bwd(wave, w, gn_w, gn_b, stat, dy, k, s, dw, dgn_w, dgn_b, conv_bias=None, dconv_bias=None):
+    _chk(dy, BF16, "dy")
+    B, L = wave.shape
+    Cc = w.shape[0]
+    bstat = empty((B, Cc, 2), torch.float32, wave.device)
+    _lib.call("w2vs_conv0_gn_bwd", _p(wave), _p(w), _p(conv_bias), _p(gn_w), _p(gn_b), _p(stat), _p(dy), _p(bstat),
+              _p(dw), _p(dconv_bias), _p(dgn_w), _p(dgn_b), B, L, Cc, k, s, _stream())
+
+
 # ------------------------------------------------------------------------------ LayerNorm rows
 def ln_fwd(x, gamma, beta, *, res=None, want_y=True, want_sum=False, sumsq=None, gelu=False, p_drop=0.0, seed=0):
     _chk(x, BF16, "x"); _chk(res, BF16, "res"); _chk(gamma, BF16, "gamma"); _chk(beta, BF16, "beta")
