@@ -497,7 +497,8 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   const int nb = d.batch > 0 ? d.batch : 1;
   p.sA = d.sA; p.sB = d.sB;
   int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * nb;
-  int target = (num_cu_hint > 0 ? num_cu_hint : 256) * 2;
+  static const int tn_target = [] { const char* e = getenv("W2VS_TN_TARGET"); return e ? atoi(e) : 0; }();
+  int target = tn_target > 0 ? tn_target : (num_cu_hint > 0 ? num_cu_hint : 256) * 3 / 2;  // 1.5 blocks per CU: measured best trade between fill and atomic traffic
   int splits = (target + tiles - 1) / tiles;
   int max_splits = (d.K + TK - 1) / TK;
   if (splits > max_splits) splits = max_splits;
