@@ -61,10 +61,17 @@ enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EP
 
 // SB = single LDS buffer: 34 KiB per block instead of 68, which lets THREE blocks share a CU (12 waves);
 // the tile for step kt+1 waits in registers while step kt computes, at the price of a second barrier.
-template <int EPI, bool SB>
-__global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_nt_kernel(GemmP p) {
+//   MODE 0: register-staged, double LDS buffer (2 blocks/CU)
+//   MODE 1: register-staged, single LDS buffer (3 blocks/CU)
+//   MODE 2: LDS-DMA (buffer_load ... lds): global -> LDS without VGPRs or ds_write; PMC showed the
+//           register-staged forms LDS-bound (ds_write_b128 costs ~13 LDS cycles against 4 for a
+//           ds_read_b128: 12 waves x (16 reads + 8 writes) per K-tile > the MFMA time of that K-tile)
+template <int EPI, int MODE>
+__global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p) {
+  constexpr bool SB = MODE == 1;
+  constexpr bool DMA = MODE == 2;
   // A0 A1 B0 B1 during the K loop (64 KiB; SB: A B, 32 KiB); padded [128][136] output tile(s) in the epilogue
-  __shared__ __attribute__((aligned(16))) bf16 lds[(SB ? 1 : 2) * 128 * 136];
+  __shared__ __attribute__((aligned(16))) bf16 lds[MODE == 0 ? 2 * 128 * 136 : (MODE == 1 ? 128 * 136 : 4 * TILE_ELEMS)];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so give
@@ -127,13 +134,70 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  gload(0);
-  if (!SB) {
-    lstore(0);
-    __syncthreads();
+  // ---- LDS-DMA staging: wave w fills rows [32w, 32w+32) of the A and of the B tile, 8 rows (1 KiB) per
+  // instruction.  The LDS image is written linearly (lane l -> row l>>3, physical chunk l&7), so the
+  // XOR swizzle goes on the SOURCE: that lane fetches logical chunk (l&7) ^ ((row>>1)&7).
+  uint32_t da_off[4], db_off[4];
+  bool da_ok[4], db_ok[4];
+  if (DMA) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wid * 32 + j * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      da_ok[j] = (m0 + row < p.M) && (c * 8 < p.K);
+      db_ok[j] = (n0 + row < p.N) && (c * 8 < p.K);
+      da_off[j] = (uint32_t)((p.a_off + (long)(m0 + row) * p.lda + c * 8) * 2);
+      db_off[j] = (uint32_t)(((long)(n0 + row) * p.ldb + c * 8) * 2);
+    }
+  }
+  auto dma_issue = [&](int kt, int buf) {
+    bf16* sa = lds + buf * TILE_ELEMS + wid * 32 * 64;
+    bf16* sb = lds + (2 + buf) * TILE_ELEMS + wid * 32 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = (lane & 7) ^ (((wid * 32 + j * 8 + (lane >> 3)) >> 1) & 7);
+      const bool kok = (kt * BK + c * 8) < p.K;
+      const uint32_t ao = (kok && da_ok[j]) ? da_off[j] + (uint32_t)(kt * BK * 2) : 0xFFFFFFF0u;
+      const uint32_t bo = (kok && db_ok[j]) ? db_off[j] + (uint32_t)(kt * BK * 2) : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (void __attribute__((address_space(3)))*)(sa + j * 8 * 64), 16, ao, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)(sb + j * 8 * 64), 16, bo, 0, 0, 0);
+    }
+  };
+  if (DMA) {
+    dma_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    gload(0);
+    if (!SB) {
+      lstore(0);
+      __syncthreads();
+    }
   }
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
+    if (DMA) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) dma_issue(kt + 1, buf ^ 1);   // lands in the other buffer while this one is consumed
+      const bf16* sa = lds + buf * TILE_ELEMS;
+      const bf16* sb = lds + (2 + buf) * TILE_ELEMS;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + swz(wm * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + swz(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (this wave's part)
+      __builtin_amdgcn_s_barrier();                       // ... everyone's part; and everyone is done reading `buf`
+      continue;
+    }
     const int buf = SB ? 0 : (kt & 1);
     if (SB) {
       if (kt > 0) __syncthreads();   // every wave is done reading the previous tile
@@ -181,8 +245,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void gemm_nt_kernel(GemmP p) {
   // staging tile [128][128] bf16 with a 16-B pad per row (row pitch 272 B) to spread banks
   constexpr int CP = 136;
   bf16* st = lds;                          // 128*136*2 = 34816 B
-  bf16* st2 = SB ? lds : lds + 128 * CP;   // pre-activation tile (SB: same buffer, emitted in a first pass)
-  constexpr bool TWO_PASS = SB && EPI == EPI_BIAS_GELU_SAVE;
+  bf16* st2 = (SB || DMA) ? lds : lds + 128 * CP;   // pre-activation tile (SB/DMA: same buffer, emitted in a first pass)
+  constexpr bool TWO_PASS = (SB || DMA) && EPI == EPI_BIAS_GELU_SAVE;
 #pragma unroll
   for (int pass = 0; pass < (TWO_PASS ? 2 : 1); ++pass) {
 #pragma unroll
@@ -459,13 +523,16 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   // single-buffer / 3-blocks-per-CU form when the grid has enough tiles to fill it (measured +6..10 % on
   // the QKV / fc1 / conv shapes), double-buffer / 2-per-CU for short grids with a long K (fc2, out_proj)
   hipEvent_t pe = prof_begin(s);
-  static const int sb_env = [] { const char* e = getenv("W2VS_GEMM_SB"); return e ? atoi(e) : -1; }();
+  static const int mode_env = [] { const char* e = getenv("W2VS_GEMM_MODE"); return e ? atoi(e) : -1; }();
   const long ntiles = (long)grid.x * grid.y * grid.z;
-  const bool sb_mode = sb_env >= 0 ? sb_env != 0 : ntiles >= 640;
+  // measured on MI355X: LDS-DMA staging wins on encoder-sized grids (+8..15 % on the N=768 and QKV shapes),
+  // the register-staged 3-blocks-per-CU form on the very large conv grids (+5..8 %)
+  const int mode = mode_env >= 0 ? mode_env : (ntiles >= 1500 ? 1 : 2);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
-    if (sb_mode) hipLaunchKernelGGL((gemm_nt_kernel<E, true>), grid, block, 0, s, p);         \
-    else hipLaunchKernelGGL((gemm_nt_kernel<E, false>), grid, block, 0, s, p);                \
+    if (mode == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, s, p);          \
+    else if (mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, s, p);     \
+    else hipLaunchKernelGGL((gemm_nt_kernel<E, 0>), grid, block, 0, s, p);                    \
   } while (0)
   switch (d.epi) {
     case EPI_NONE: NT_LAUNCH(EPI_NONE); break;
