@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libw2vs.so")
+LIB_PATH = os.environ.get("W2VS_LIB", os.path.join(_HERE, "libw2vs.so"))   # W2VS_LIB: experiment builds only
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 

@@ -179,41 +179,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     while (kt0 < N && !((kt0 < mlim) || (kt0 < bchi && kt0 + KT > bclo))) kt0 += KT;
     return kt0;
   };
-  u32x4 rk[2], rv[2];
-  float rbias = 0.f;
-  auto gload = [&](int kt0) {
+  // Register-staged prefetch TWO tiles ahead (two register sets): an ablation showed the loop bound by the
+  // latency of the global loads, which one tile of compute (~1.5 us) does not cover.
+  struct TileRegs { u32x4 k[2], v[2]; float bias; };
+  auto gload = [&](int kt0, TileRegs& r) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
-      rk[j] = u32x4{0u, 0u, 0u, 0u};
-      rv[j] = u32x4{0u, 0u, 0u, 0u};
+      r.k[j] = u32x4{0u, 0u, 0u, 0u};
+      r.v[j] = u32x4{0u, 0u, 0u, 0u};
       if (kt0 + row < N) {
-        rk[j] = *(const u32x4*)(K + (long)(kt0 + row) * p.ld + ch * 8);
-        rv[j] = *(const u32x4*)(V + (long)(kt0 + row) * p.ld + ch * 8);
+        r.k[j] = *(const u32x4*)(K + (long)(kt0 + row) * p.ld + ch * 8);
+        r.v[j] = *(const u32x4*)(V + (long)(kt0 + row) * p.ld + ch * 8);
       }
     }
+    r.bias = 0.f;
     if (tid < KT) {
       int key = kt0 + tid;
-      rbias = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
+      r.bias = (key < N && !(kp && kp[key])) ? 0.f : -INFINITY;
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const TileRegs& r) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
-      *(u32x4*)(Ks[buf] + kswz(row, ch)) = rk[j];
-      *(u32x4*)(Vs[buf] + vswz(row, ch * 8)) = rv[j];
+      *(u32x4*)(Ks[buf] + kswz(row, ch)) = r.k[j];
+      *(u32x4*)(Vs[buf] + vswz(row, ch * 8)) = r.v[j];
     }
-    if (tid < KT) kbias[buf][tid] = rbias;
+    if (tid < KT) kbias[buf][tid] = r.bias;
   };
-
-  int cur = next_tile(0), buf = 0;
-  if (cur < N) { gload(cur); lstore(0); }
-  __syncthreads();
-  while (cur < N) {
-    const int kt0 = cur;
-    const int nxt = next_tile(cur + KT);
-    if (nxt < N) gload(nxt);
+  auto compute = [&](int kt0, int buf) {
     const bf16* Kb = Ks[buf];
     const bf16* Vb = Vs[buf];
     const float* kb = kbias[buf];
@@ -246,10 +241,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         }
       }
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float mnew = fmaxf(mrun, mloc);
-      const float muse = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = fast_exp2(mrun - muse);
-      mrun = mnew;
+      // Lazy rescale: keep exponentiating against the reference max `mrun` while no row's maximum grew by
+      // more than 2^6; p then lies in (0, 64], which fp32 sums and bf16 P (floating point) carry without
+      // loss.  Moving the 32 O accumulators AGPR->VGPR->AGPR costs ~80 instructions, so skip it when idle.
+      float muse;
+      if (__all(mloc <= mrun + 6.0f)) {
+        muse = (mrun == -INFINITY) ? 0.f : mrun;
+      } else {
+        const float mnew = fmaxf(mrun, mloc);
+        muse = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = fast_exp2(mrun - muse);
+        mrun = mnew;
+        lrun *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+      }
       float ls = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { S[i] = fast_exp2(S[i] - muse); ls += S[i]; }
@@ -261,11 +267,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
           S[i + 1] *= (hw >> 16) >= thr ? inv_keep : 0.f;
         }
       }
-      lrun = lrun * alpha + ls;
-      if (!__all(alpha == 1.f)) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
-      }
+      lrun += ls;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pb = pack8(S, s2);
@@ -277,10 +279,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb, O1, 0, 0, 0);
       }
     }
-    if (nxt < N) lstore(buf ^ 1);
+  };
+
+  TileRegs R0, R1;
+  int t0 = next_tile(0);
+  int t1 = t0 < N ? next_tile(t0 + KT) : N;
+  if (t0 < N) gload(t0, R0);
+  if (t1 < N) gload(t1, R1);
+  if (t0 < N) lstore(0, R0);
+  __syncthreads();
+  while (t0 < N) {
+    // even step: tile t0 in LDS[0], tile t1 in R1; fetch t2 into R0
+    int t2 = t1 < N ? next_tile(t1 + KT) : N;
+    if (t2 < N) gload(t2, R0);
+    compute(t0, 0);
+    if (t1 < N) lstore(1, R1);
     __syncthreads();
-    cur = nxt;
-    buf ^= 1;
+    if (t1 >= N) break;
+    // odd step: tile t1 in LDS[1], tile t2 in R0; fetch t3 into R1
+    int t3 = t2 < N ? next_tile(t2 + KT) : N;
+    if (t3 < N) gload(t3, R1);
+    compute(t1, 1);
+    if (t2 < N) lstore(0, R0);
+    __syncthreads();
+    t0 = t2; t1 = t3;
   }
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
