@@ -107,6 +107,8 @@ typedef struct w2vs_ln_bwd_desc {
   void* dx; void* dres; float* dgamma; float* dbeta;
   int64_t rows; int32_t C; int32_t gelu; float p_drop; uint64_t seed; float out_scale; float pen_coef;
   const float* pen_coef_dev;   /* optional device scalar multiplied into pen_coef (no host sync) */
+  void* ws; int64_t ws_bytes;  /* optional scratch (>= 512*2*C*4 B is enough): dgamma/dbeta partials are reduced
+                                  through it in a second launch; without it every block adds them atomically */
 } w2vs_ln_bwd_desc;
 int w2vs_ln_fwd(const w2vs_ln_fwd_desc* d, void* stream);
 int w2vs_ln_bwd(const w2vs_ln_bwd_desc* d, void* stream);

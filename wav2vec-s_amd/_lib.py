@@ -29,7 +29,7 @@ class LnBwdDesc(C.Structure):
     _fields_ = [("x", vp), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp), ("dy", vp), ("dsum", vp),
                 ("aux", vp), ("dx", vp), ("dres", vp), ("dgamma", vp), ("dbeta", vp), ("rows", i64),
                 ("C", i32), ("gelu", i32), ("p_drop", f32), ("seed", u64), ("out_scale", f32), ("pen_coef", f32),
-                ("pen_coef_dev", vp)]
+                ("pen_coef_dev", vp), ("ws", vp), ("ws_bytes", i64)]
 
 
 class EncPrologueDesc(C.Structure):

@@ -62,6 +62,34 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
   if (t > 4294967295.0) t = 4294967295.0;
   return (uint32_t)t;
 }
+// Chunk-granular dropout for the row kernels: the 8 consecutive elements of chunk `cidx` (= element index / 8)
+// take their keep decisions from four hash words, two 16-bit fields each (p_eff = round-down(p * 65536) / 65536,
+// e.g. 0.099991 for p = 0.1; inv_keep is 1 / (1 - p_eff), so E[mask * inv_keep] = 1 exactly).  Two 32-bit
+// multiplies per word instead of hash32's six per element: the full-rate-equivalent VALU cost of the
+// mask drops ~5x, which is what bounds the LayerNorm kernels (v_mul_lo_u32 issues at quarter rate).
+struct Drop {
+  uint32_t s0, s1, thr16;
+  float inv_keep;
+};
+__host__ __device__ __forceinline__ Drop make_drop(float p, uint64_t seed) {
+  Drop d;
+  d.s0 = (uint32_t)seed; d.s1 = (uint32_t)(seed >> 32);
+  d.thr16 = drop_threshold(p) >> 16;
+  d.inv_keep = d.thr16 > 0 ? 65536.f / (65536.f - (float)d.thr16) : 1.f;
+  return d;
+}
+__device__ __forceinline__ void drop8(const Drop& d, uint32_t cidx, float (&m)[8]) {
+  const uint32_t base = cidx * (4u * 0x9E3779B1u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t x = (base + (uint32_t)j * 0x9E3779B1u) ^ d.s0;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x ^= d.s1; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    m[2 * j] = (x & 0xFFFFu) >= d.thr16 ? d.inv_keep : 0.f;
+    m[2 * j + 1] = (x >> 16) >= d.thr16 ? d.inv_keep : 0.f;
+  }
+}
 __device__ __forceinline__ float u01(uint32_t h) {  // (0,1]
   return ((float)(h >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }

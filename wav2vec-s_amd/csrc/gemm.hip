@@ -437,15 +437,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
         if (row < p.M && col < p.N) atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
       }
   if (do_colsum) {
-    // 16 threads (tid>>4) share a column chunk cc = tid&15: fold them in LDS, then one atomic per column
+    // 16 threads (tid>>4) share a column chunk cc = tid&15: each parks its 8 sums in its own LDS row, 128 threads
+    // then fold the 16 rows (no LDS float atomics: ds_add_f32 runs at ~130 cycles per wave-instruction)
     float* red = (float*)lds;
     __syncthreads();
-    if (tid < BM) red[tid] = 0.f;
+    {
+      float* mine = red + (tid >> 4) * BM + (tid & 15) * 8;
+      *(f32x4*)(mine) = f32x4{csum[0], csum[1], csum[2], csum[3]};
+      *(f32x4*)(mine + 4) = f32x4{csum[4], csum[5], csum[6], csum[7]};
+    }
     __syncthreads();
-    const int cc = tid & 15;
+    if (tid < BM) {
+      float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&red[cc * 8 + e], csum[e]);
-    __syncthreads();
+      for (int gq = 0; gq < 16; ++gq) sum += red[gq * BM + tid];
+      red[tid] = sum;   // row 0 is only read by its own thread before this store
+    }
     if (tid < BM && m0 + tid < p.M) atomicAdd(&p.colsum[m0 + tid], red[tid] * p.alpha);
   }
 }

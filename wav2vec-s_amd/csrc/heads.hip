@@ -558,19 +558,21 @@ int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st)
 }
 
 // out = in * keep(seed, i) / (1-p) : standalone dropout (dropout_features), same call for the bwd
-__global__ void dropout_kernel(const bf16* in, bf16* out, long n, uint64_t seed, uint32_t thr, float inv_keep) {
-  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+__global__ void dropout_kernel(const bf16* in, bf16* out, long n, Drop D) {
+  long c = (long)blockIdx.x * 256 + threadIdx.x, i = c * 8;
   if (i >= n) return;
   bf16x8 v = *(const bf16x8*)(in + i), o;
+  float m[8];
+  drop8(D, (uint32_t)c, m);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = f2bf(hash32(seed, (uint64_t)(i + e)) >= thr ? bf2f(v[e]) * inv_keep : 0.f);
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(v[e]) * m[e]);
   *(bf16x8*)(out + i) = o;
 }
 int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream_t st) {
   if (!in || !out || n <= 0 || (n % 8)) return set_error("dropout: n must be a positive multiple of 8");
   if (p < 0.f || p >= 1.f) return set_error("dropout: p must be in [0,1)");
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, (const bf16*)in, (bf16*)out, n,
-                     seed, drop_threshold(p), 1.f / (1.f - p));
+                     make_drop(p, seed));
   return hip_check(hipGetLastError(), "dropout");
 }
 

@@ -92,6 +92,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   b2.x = L.s2; b2.gamma = L.ln2_g; b2.beta = L.ln2_b; b2.mean = L.mean2; b2.rstd = L.rstd2; b2.dy = L.d_out;
   b2.dx = L.ws_e0; b2.dres = L.ws_e1; b2.dgamma = L.g_ln2_g; b2.dbeta = L.g_ln2_b; b2.rows = R; b2.C = E;
   b2.p_drop = L.p_drop; b2.seed = L.seed_drop2; b2.out_scale = 1.f;
+  b2.ws = L.ws_f; b2.ws_bytes = (int64_t)R * F * 2;   // ws_f is not live yet: dgamma/dbeta partial slab
   TRY(ln_bwd(b2, s));
   // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
   TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, cu, s));
@@ -106,6 +107,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   b1.x = L.s1; b1.gamma = L.ln1_g; b1.beta = L.ln1_b; b1.mean = L.mean1; b1.rstd = L.rstd1; b1.dy = L.ws_e2;
   b1.dx = L.ws_e0; b1.dres = L.ws_e1; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = R; b1.C = E;
   b1.p_drop = L.p_drop; b1.seed = L.seed_drop1; b1.out_scale = 1.f;
+  b1.ws = L.ws_f; b1.ws_bytes = (int64_t)R * F * 2;   // fc1's wgrad/dgrad (enqueued above) were its last readers
   TRY(ln_bwd(b1, s));
   // out_proj
   TRY(lin_wgrad(L.ws_e0, L.ctx, L.g_wo, L.g_bo, R, E, E, cu, s));

@@ -34,6 +34,26 @@ __device__ __forceinline__ void load_row(const bf16* p, int C, int lane, Row& r)
     }
   }
 }
+struct RawRow {  // the same two chunks as undecoded bf16 bits (8 registers instead of 16)
+  u32x4 v[2];
+};
+__device__ __forceinline__ void load_raw(const bf16* p, int C, int lane, RawRow& r) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int ch = lane + 64 * h;
+    r.v[h] = u32x4{0u, 0u, 0u, 0u};
+    if (ch < nchunks(C)) r.v[h] = *(const u32x4*)(p + ch * 8);
+  }
+}
+__device__ __forceinline__ void unpack_row(const RawRow& r, Row& o) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o.v[h][2 * j] = __uint_as_float(r.v[h][j] << 16);
+      o.v[h][2 * j + 1] = __uint_as_float(r.v[h][j] & 0xFFFF0000u);
+    }
+}
 __device__ __forceinline__ void store_row(bf16* p, int C, int lane, const Row& r) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -65,8 +85,15 @@ __device__ __forceinline__ void row_stats(const Row& r, int C, int lane, float& 
 }
 
 // dropout: element index = row_id*C + channel; identical in fwd and bwd
-__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
-  return hash32(seed, idx) >= thr ? inv_keep : 0.f;
+// multiply a row by its dropout keep/scale factors; chunk index = row * (C/8) + chunk
+__device__ __forceinline__ void drop_row(const Drop& D, long row, int C, int lane, Row& x) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float m[8];
+    drop8(D, (uint32_t)(row * (C >> 3) + lane + 64 * h), m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x.v[h][e] *= m[e];
+  }
 }
 
 // =====================================================================================
@@ -405,8 +432,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int C = p.C;
-  const uint32_t thr = drop_threshold(p.p_drop);
-  const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+  const Drop D = make_drop(p.p_drop, p.seed);
   Row g, b;
   load_row(p.g, C, lane, g);
   load_row(p.b, C, lane, b);
@@ -421,11 +447,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
         for (int e = 0; e < 8; ++e) sq += x.v[h][e] * x.v[h][e];
     }
     if (p.p_drop > 0.f) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          x.v[h][e] *= drop_scale(p.seed, (uint64_t)row * C + (lane + 64 * h) * 8 + e, thr, inv_keep);
+      drop_row(D, row, C, lane, x);
     }
     if (p.res) {
       Row r;
@@ -465,24 +487,41 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
 
 // dx = LNbwd(dy) [+ dsum];   dres = dx;   d(x) = dx * dropmask/(1-p)
 // `x` here must be the LN *input* (sum).  When gelu: dy is wrt gelu(LN(x)).
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
+// One wave per row; NW waves per block.  FULL = false is the lean encoder-layer form (no fused GELU, no
+// penalty / GradMultiply / aux chain): half the registers, so 16 waves per CU cover the load latency.
+// dgamma / dbeta: per-lane register partials -> one LDS reduction per block -> either a [grid][2C]
+// partial slab (`part`, reduced by ln_bwd_reduce_kernel) or, without a workspace, atomics per block.
+template <bool FULL, int NW>
+__global__ __launch_bounds__(NW * 64, FULL ? 2 : 3) void ln_bwd_kernel(LnP p, float* part) {
   const int lane = threadIdx.x & 63;
-  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int wave_id = blockIdx.x * NW + (threadIdx.x >> 6), nwaves = gridDim.x * NW;
   const int C = p.C;
-  const uint32_t thr = drop_threshold(p.p_drop);
-  const float inv_keep = p.p_drop > 0.f ? 1.0f / (1.0f - p.p_drop) : 1.0f;
+  const Drop D = make_drop(p.p_drop, p.seed);
   Row g, b, dg, db;
   load_row(p.g, C, lane, g);
-  load_row(p.b, C, lane, b);
+  if (FULL) load_row(p.b, C, lane, b);
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int e = 0; e < 8; ++e) dg.v[h][e] = db.v[h][e] = 0.f;
+  // software pipeline over rows: the raw bf16 bits of the NEXT row are in flight while this one is reduced
+  RawRow nx, ndy;
+  float nmean = 0.f, nrstd = 0.f;
+  if (wave_id < p.rows) {
+    load_raw(p.x + (long)wave_id * C, C, lane, nx);
+    if (p.dy) load_raw(p.dy + (long)wave_id * C, C, lane, ndy);
+    nmean = p.mean[wave_id]; nrstd = p.rstd[wave_id];
+  }
   for (long row = wave_id; row < p.rows; row += nwaves) {
     Row x, dy;
-    load_row(p.x + row * C, C, lane, x);
-    if (p.dy) load_row(p.dy + row * C, C, lane, dy);
-    const float mean = p.mean[row], rstd = p.rstd[row];
+    unpack_row(nx, x);
+    if (p.dy) unpack_row(ndy, dy);
+    const float mean = nmean, rstd = nrstd;
+    if (row + nwaves < p.rows) {
+      load_raw(p.x + (row + nwaves) * C, C, lane, nx);
+      if (p.dy) load_raw(p.dy + (row + nwaves) * C, C, lane, ndy);
+      nmean = p.mean[row + nwaves]; nrstd = p.rstd[row + nwaves];
+    }
     float s1 = 0.f, s2 = 0.f;
     Row dxh;
 #pragma unroll
@@ -491,7 +530,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
       for (int e = 0; e < 8; ++e) {
         float xh = (x.v[h][e] - mean) * rstd;
         float d = p.dy ? dy.v[h][e] : 0.f;
-        if (p.gelu) d *= gelu_grad(xh * g.v[h][e] + b.v[h][e]);
+        if (FULL && p.gelu) d *= gelu_grad(xh * g.v[h][e] + b.v[h][e]);
         if (lane + 64 * h >= nchunks(C)) { d = 0.f; xh = 0.f; }
         dg.v[h][e] += d * xh;
         db.v[h][e] += d;
@@ -518,25 +557,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
     }
     if (p.dres) store_row(p.dres + row * C, C, lane, dx);
     if (p.dx) {
-      const float pen = p.pen_dev ? p.pen_coef * p.pen_dev[0] : p.pen_coef;
-      if (pen != 0.f || p.out_scale != 1.f) {
-        // x.v currently holds xhat: rebuild the raw input for the penalty term
+      if (FULL) {
+        const float pen = p.pen_dev ? p.pen_coef * p.pen_dev[0] : p.pen_coef;
+        if (pen != 0.f || p.out_scale != 1.f) {
+          // x.v currently holds xhat: rebuild the raw input for the penalty term
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+          for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float raw = x.v[h][e] / rstd + mean;
-            dx.v[h][e] = (dx.v[h][e] + 2.f * raw * pen) * p.out_scale;
-          }
+            for (int e = 0; e < 8; ++e) {
+              float raw = x.v[h][e] / rstd + mean;
+              dx.v[h][e] = (dx.v[h][e] + 2.f * raw * pen) * p.out_scale;
+            }
+        }
       }
       if (p.p_drop > 0.f) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            dx.v[h][e] *= drop_scale(p.seed, (uint64_t)row * C + (lane + 64 * h) * 8 + e, thr, inv_keep);
+        drop_row(D, row, C, lane, dx);
       }
-      if (p.aux) {  // chain through the producing layer's GELU: dx *= gelu'(pre)
+      if (FULL && p.aux) {  // chain through the producing layer's GELU: dx *= gelu'(pre)
         Row a;
         load_row(p.aux + row * C, C, lane, a);
 #pragma unroll
@@ -547,24 +584,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnP p) {
       store_row(p.dx + row * C, C, lane, dx);
     }
   }
-  __shared__ float red[2 * 1024];
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  // block reduction without LDS atomics (ds_add_f32 costs ~130 cycles per wave-instruction on gfx950: measured
+  // 25 of this kernel's 35 us): every wave stores its partials to its own slab red[w][kind][e][chunk] (row pitch
+  // 136 floats: conflict-free for the lane-per-chunk stores and for the column-order reads), then each thread
+  // sums its columns over the NW slabs.
+  constexpr int RP = 136, SLAB = 2 * 8 * RP;
+  __shared__ float red[NW * SLAB];
+  {
+    float* mine = red + (threadIdx.x >> 6) * SLAB;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    int ch = lane + 64 * h;
-    if (ch < nchunks(C)) {
+    for (int h = 0; h < 2; ++h) {
+      int ch = lane + 64 * h;
+      if (ch < nchunks(C)) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&red[ch * 8 + e], dg.v[h][e]);
-        atomicAdd(&red[C + ch * 8 + e], db.v[h][e]);
+        for (int e = 0; e < 8; ++e) {
+          mine[e * RP + ch] = dg.v[h][e];
+          mine[8 * RP + e * RP + ch] = db.v[h][e];
+        }
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(&p.dg[i], red[i]);
-    atomicAdd(&p.db[i], red[C + i]);
+  for (int i = threadIdx.x; i < 2 * C; i += NW * 64) {
+    const int kind = i >= C, col = kind ? i - C : i;
+    const int off = kind * 8 * RP + (col & 7) * RP + (col >> 3);
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += red[w * SLAB + off];
+    if (part) part[(long)blockIdx.x * 2 * C + i] = sum;
+    else atomicAdd(kind ? &p.db[col] : &p.dg[col], sum);
+  }
+}
+
+// dgamma[c] += sum_g part[g][c], dbeta[c] += sum_g part[g][C + c].  grid (ceil(2C/64), RY); a block is
+// 64 columns x 4 row lanes; every thread sums a strided subset of the G partial rows.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* part, int G, int C, float* dg, float* db) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx, C2 = 2 * C;
+  float s = 0.f;
+  if (col < C2) {
+    const int step = 4 * gridDim.y;
+    int gi = blockIdx.y * 4 + ty;
+    for (; gi + 3 * step < G; gi += 4 * step) {
+      float a0 = part[(long)gi * C2 + col], a1 = part[(long)(gi + step) * C2 + col];
+      float a2 = part[(long)(gi + 2 * step) * C2 + col], a3 = part[(long)(gi + 3 * step) * C2 + col];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; gi < G; gi += step) s += part[(long)gi * C2 + col];
+  }
+  __shared__ float red[4][64];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < C2) {
+    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (col < C) atomicAdd(&dg[col], s);
+    else atomicAdd(&db[col - C], s);
   }
 }
 
@@ -596,8 +670,23 @@ int ln_bwd(const LnBwdDesc& d, hipStream_t st) {
   p.out_scale = d.out_scale; p.pen_coef = d.pen_coef; p.pen_dev = d.pen_coef_dev; p.gelu = d.gelu; p.rows = d.rows; p.C = d.C;
   if (!p.x || !p.g || !p.b || !p.mean || !p.rstd || !p.dg || !p.db) return set_error("ln_bwd: null pointer");
   if (int e = ln_check(p, "ln_bwd")) return e;
-  int grid = (int)std::min<long>((p.rows + 3) / 4, p.rows > 65536 ? 1024 : 256);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, st, p);
+  constexpr int NW = 4;
+  const bool full = p.gelu || p.aux || p.pen_coef != 0.f || p.pen_dev || p.out_scale != 1.f;
+  int grid = (int)std::min<long>((p.rows + NW - 1) / NW, p.rows > 65536 ? 2048 : 768);
+  // partial slab [grid][2C] fp32 in the caller's workspace; shrink the grid to what the workspace holds
+  float* part = nullptr;
+  if (d.ws && d.ws_bytes >= (int64_t)sizeof(float) * 2 * p.C * 64) {
+    grid = (int)std::min<long>(grid, d.ws_bytes / ((long)sizeof(float) * 2 * p.C));
+    part = (float*)d.ws;
+  } else {
+    grid = std::min(grid, 256);   // no workspace: per-block atomics, keep their number down
+  }
+  if (full) hipLaunchKernelGGL((ln_bwd_kernel<true, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);
+  else hipLaunchKernelGGL((ln_bwd_kernel<false, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);
+  if (part) {
+    const int ry = std::max(1, std::min(16, grid / 16));
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * p.C + 63) / 64, ry), dim3(256), 0, st, part, grid, p.C, p.dg, p.db);
+  }
   return hip_check(hipGetLastError(), "ln_bwd");
 }
 
@@ -627,8 +716,7 @@ __global__ __launch_bounds__(256) void enc_prologue_fwd_kernel(EncProP p) {
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int C = p.C;
-  const uint32_t thr_in = drop_threshold(p.p_in), thr_enc = drop_threshold(p.p_enc);
-  const float ik_in = p.p_in > 0.f ? 1.f / (1.f - p.p_in) : 1.f, ik_enc = p.p_enc > 0.f ? 1.f / (1.f - p.p_enc) : 1.f;
+  const Drop Din = make_drop(p.p_in, p.seed_in), Denc = make_drop(p.p_enc, p.seed_enc);
   Row g, b, me;
   load_row(p.g, C, lane, g);
   load_row(p.b, C, lane, b);
@@ -655,10 +743,12 @@ __global__ __launch_bounds__(256) void enc_prologue_fwd_kernel(EncProP p) {
     for (int h = 0; h < 2; ++h) {
       int ch = lane + 64 * h;
       if (ch >= nchunks(C)) continue;
+      float mi[8];
+      if (p.p_in > 0.f) drop8(Din, (uint32_t)(fr * (C >> 3) + ch), mi);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = x.v[h][e];
-        if (p.p_in > 0.f) v = bf2f(f2bf(v * drop_scale(p.seed_in, (uint64_t)fr * C + ch * 8 + e, thr_in, ik_in)));
+        if (p.p_in > 0.f) v = bf2f(f2bf(v * mi[e]));
         if (is_mask) v = me.v[h][e];
         if (is_pad) v = 0.f;
         x.v[h][e] = bf2f(f2bf(v + pt[ch * 8 + e]));
@@ -674,11 +764,7 @@ __global__ __launch_bounds__(256) void enc_prologue_fwd_kernel(EncProP p) {
         for (int e = 0; e < 8; ++e) x.v[h][e] = bf2f(f2bf((x.v[h][e] - mean) * rstd * g.v[h][e] + b.v[h][e]));
     }
     if (p.p_enc > 0.f) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          x.v[h][e] *= drop_scale(p.seed_enc, (uint64_t)fr * C + (lane + 64 * h) * 8 + e, thr_enc, ik_enc);
+      drop_row(Denc, fr, C, lane, x);
     }
     store_row(p.out + row * C, C, lane, x);
   }
@@ -689,8 +775,7 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int C = p.C;
-  const uint32_t thr_in = drop_threshold(p.p_in), thr_enc = drop_threshold(p.p_enc);
-  const float ik_in = p.p_in > 0.f ? 1.f / (1.f - p.p_in) : 1.f, ik_enc = p.p_enc > 0.f ? 1.f / (1.f - p.p_enc) : 1.f;
+  const Drop Din = make_drop(p.p_in, p.seed_in), Denc = make_drop(p.p_enc, p.seed_enc);
   Row g, me, dgm, dbt, dme;
   load_row(p.g, C, lane, g);
   load_row(p.mask_emb, C, lane, me);
@@ -714,11 +799,7 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
         for (int e = 0; e < 8; ++e) d.v[h][e] += dc.v[h][e];
     }
     if (p.p_enc > 0.f) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          d.v[h][e] *= drop_scale(p.seed_enc, (uint64_t)fr * C + (lane + 64 * h) * 8 + e, thr_enc, ik_enc);
+      drop_row(Denc, fr, C, lane, d);
     }
     Row dx = d;
     if (p.apply_ln) {
@@ -732,11 +813,13 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int ch = lane + 64 * h;
+        float mi[8];
+        if (p.p_in > 0.f) drop8(Din, (uint32_t)(fr * (C >> 3) + ch), mi);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float v = x.v[h][e], xh = 0.f, t1 = 0.f;
           if (ch < nchunks(C)) {
-            if (p.p_in > 0.f) v = bf2f(f2bf(v * drop_scale(p.seed_in, (uint64_t)fr * C + ch * 8 + e, thr_in, ik_in)));
+            if (p.p_in > 0.f) v = bf2f(f2bf(v * mi[e]));
             if (is_mask) v = me.v[h][e];
             if (is_pad) v = 0.f;
             v = bf2f(f2bf(v + pt[ch * 8 + e]));
@@ -762,12 +845,14 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int ch = lane + 64 * h;
+      float mi[8];
+      if (p.p_in > 0.f) drop8(Din, (uint32_t)(fr * (C >> 3) + ch), mi);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = dx.v[h][e];
         if (is_pad) v = 0.f;
         if (is_mask) { dme.v[h][e] += v; v = 0.f; }
-        if (p.p_in > 0.f && ch < nchunks(C)) v *= drop_scale(p.seed_in, (uint64_t)fr * C + ch * 8 + e, thr_in, ik_in);
+        if (p.p_in > 0.f && ch < nchunks(C)) v *= mi[e];
         dx.v[h][e] = v;
       }
     }

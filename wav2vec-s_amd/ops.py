@@ -364,6 +364,8 @@ def ln_bwd(x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy=None, dsum=None, aux
     d.dy, d.dsum, d.aux, d.dx, d.dres, d.dgamma, d.dbeta = _p(dy), _p(dsum), _p(aux), _p(dx), _p(dres), _p(dgamma), _p(dbeta)
     d.rows, d.C, d.gelu, d.p_drop, d.seed, d.out_scale, d.pen_coef = rows, Cc, int(gelu), p_drop, seed, out_scale, pen_coef
     d.pen_coef_dev = _p(pen_coef_dev)
+    ws = empty((768 * 2 * Cc,), torch.float32, x.device)     # dgamma/dbeta partial slab
+    d.ws, d.ws_bytes = _p(ws), ws.numel() * 4
     _lib.call("w2vs_ln_bwd", C.byref(d), _stream())
     return dx, dres
 
