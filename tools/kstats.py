@@ -9,7 +9,7 @@ db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 tot, cnt = collections.Counter(), collections.Counter()
 for n, s, e in rows:
-    n = re.sub(r"^void ", "", n).split("(")[0][:80]
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "").split("(")[0][:80]
     tot[n] += e - s
     cnt[n] += 1
 for n, t in tot.most_common(60):

@@ -225,6 +225,8 @@ int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* ln
               float* mean, float* rstd, int B, int L, int C, int k, int s, hipStream_t st) {
   if (!wave || !w || !lnw || !lnb || !y || !mean || !rstd) return set_error("conv0_fwd: null pointer");
   if (C % 8 || C > 512 || k > 10 || k < 1 || s < 1 || L < k) return set_error("conv0_fwd: need C%8==0, C<=512, k<=10, L>=k");
+  if ((long)B * ((L - k) / s + 1) >= 0x7FFFFFFFL) return set_error("conv0_fwd: more than 2^31 output frames");
+  if (conv0_mfma_ok(C, k)) return conv0_mfma_fwd(wave, w, cbias, lnw, lnb, y, mean, rstd, B, L, k, s, st);
   Conv0P p{};
   p.wave = (const bf16*)wave; p.w = (const bf16*)w; p.cbias = (const bf16*)cbias; p.lnw = (const bf16*)lnw; p.lnb = (const bf16*)lnb;
   p.y = (bf16*)y; p.mean = mean; p.rstd = rstd; p.B = B; p.L = L; p.L0 = (L - k) / s + 1; p.C = C; p.k = k; p.s = s;
@@ -239,6 +241,8 @@ int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* ln
               int k, int s, hipStream_t st) {
   if (!wave || !w || !lnw || !lnb || !dy || !mean || !rstd || !dw || !dlnw || !dlnb) return set_error("conv0_bwd: null pointer");
   if (C % 8 || C > 512 || k > 10 || k < 1 || s < 1 || L < k) return set_error("conv0_bwd: need C%8==0, C<=512, k<=10, L>=k");
+  if ((long)B * ((L - k) / s + 1) >= 0x7FFFFFFFL) return set_error("conv0_bwd: more than 2^31 output frames");
+  if (conv0_mfma_ok(C, k)) return conv0_mfma_bwd(wave, w, cbias, lnw, lnb, mean, rstd, dy, dw, dcbias, dlnw, dlnb, B, L, k, s, st);
   Conv0P p{};
   p.wave = (const bf16*)wave; p.w = (const bf16*)w; p.cbias = (const bf16*)cbias; p.lnw = (const bf16*)lnw; p.lnb = (const bf16*)lnb;
   p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd); p.dy = (const bf16*)dy;

@@ -27,6 +27,13 @@ int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* ln
 int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, const float* mean,
               const float* rstd, const void* dy, float* dw, float* dcbias, float* dlnw, float* dlnb, int B, int L, int C,
               int k, int s, hipStream_t st);
+// conv0.hip: matrix-core form for C == 512, k <= 10 (what conv0_fwd/bwd dispatch to when it applies)
+bool conv0_mfma_ok(int C, int k);
+int conv0_mfma_fwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, void* y,
+                   float* mean, float* rstd, int B, int L, int k, int s, hipStream_t st);
+int conv0_mfma_bwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, const float* mean,
+                   const float* rstd, const void* dy, float* dw, float* dcbias, float* dlnw, float* dlnb, int B, int L, int k,
+                   int s, hipStream_t st);
 int conv0_gn_fwd(const void* wave, const void* w, const void* cbias, const void* g, const void* b, void* y, float* stat,
                  int B, int L, int C, int k, int s, hipStream_t st);
 int conv0_gn_bwd(const void* wave, const void* w, const void* cbias, const void* g, const void* b, const float* stat,
