@@ -862,28 +862,31 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
     }
     store_row(p.dx + fr * C, C, lane, dx);
   }
-  __shared__ float red[3 * 1024];
-  for (int i = threadIdx.x; i < 3 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  // per-wave slabs red[w][kind][e][chunk] (pitch 136), folded by column afterwards - see ln_bwd_kernel
+  constexpr int RP = 136, KIND = 8 * RP, SLAB = 3 * KIND;
+  __shared__ float red[4 * SLAB];
+  {
+    float* mine = red + (threadIdx.x >> 6) * SLAB;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    int ch = lane + 64 * h;
-    if (ch < nchunks(C)) {
+    for (int h = 0; h < 2; ++h) {
+      int ch = lane + 64 * h;
+      if (ch < nchunks(C)) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&red[ch * 8 + e], dgm.v[h][e]);
-        atomicAdd(&red[C + ch * 8 + e], dbt.v[h][e]);
-        atomicAdd(&red[2 * C + ch * 8 + e], dme.v[h][e]);
+        for (int e = 0; e < 8; ++e) {
+          mine[e * RP + ch] = dgm.v[h][e];
+          mine[KIND + e * RP + ch] = dbt.v[h][e];
+          mine[2 * KIND + e * RP + ch] = dme.v[h][e];
+        }
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    if (p.apply_ln) {
-      atomicAdd(&p.dg[i], red[i]);
-      atomicAdd(&p.db[i], red[C + i]);
-    }
-    atomicAdd(&p.dmask_emb[i], red[2 * C + i]);
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    const int kind = i / C, col = i - kind * C;
+    if (kind < 2 && !p.apply_ln) continue;
+    const int off = kind * KIND + (col & 7) * RP + (col >> 3);
+    const float sum = (red[off] + red[SLAB + off]) + (red[2 * SLAB + off] + red[3 * SLAB + off]);
+    atomicAdd(kind == 0 ? &p.dg[col] : (kind == 1 ? &p.db[col] : &p.dmask_emb[col]), sum);
   }
 }
 
