@@ -168,6 +168,9 @@ typedef struct w2vs_layer_desc {
   const void* d_out; void* d_in;
   float *g_wqkv, *g_bqkv, *g_wo, *g_bo, *g_ln1_g, *g_ln1_b, *g_w1, *g_b1, *g_w2, *g_b2, *g_ln2_g, *g_ln2_b;
   void *ws_e0, *ws_e1, *ws_e2, *ws_f, *ws_qkv, *wt_scratch; float* delta;
+  /* optional: the four weights already transposed ([E,3E], [E,E], [E,F], [F,E]), e.g. by ONE w2vs_transpose_multi
+   * for every layer of the step; layer_bwd then skips its own four transposes (wt_scratch may be NULL) */
+  const void *wqkv_t, *wo_t, *w1_t, *w2_t;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);
@@ -217,6 +220,9 @@ int w2vs_ce_rows(const float* logits, int64_t R, int32_t W, float* out3, float* 
  * x[mask_indices] / unmasked_features[mask_indices] (wav2vec2.py:590-592, 641) and their grads.  */
 int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, int32_t C, int32_t scatter, void* stream);
 int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* stream);
+/* many independent 2-D transposes in one launch (n <= 64): out[i] [C_i, R_i] = in[i] [R_i, C_i]^T */
+typedef struct w2vs_transpose_item { const void* in; void* out; int32_t R, C; } w2vs_transpose_item;
+int w2vs_transpose_multi(const w2vs_transpose_item* items, int32_t n, void* stream);
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* stream);
 /* out[i] = in[i] * keep(seed, i) / (1 - p) : nn.Dropout (dropout_features, wav2vec2.py:571);
  * the backward is the same call on the gradient with the same seed. */

@@ -501,3 +501,13 @@ def test_fused_adam_matches_fairseq_formula(ops):
     out = torch.zeros(1, device="cuda")
     ops.sumsq(grad.cuda(), out)
     assert abs(float(out) - float((grad ** 2).sum())) / float((grad ** 2).sum()) < 1e-5
+
+
+def test_transpose_multi(ops):
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (40, 24), (65, 130)]
+    xs = [dev(rnd(r, c, seed=20 + i)) for i, (r, c) in enumerate(shapes)]
+    outs = [torch.empty(c, r, device="cuda", dtype=BF) for (r, c) in shapes]
+    ops.transpose_multi([(x.data_ptr(), o.data_ptr(), r, c) for x, o, (r, c) in zip(xs, outs, shapes)])
+    torch.cuda.synchronize()
+    for x, o in zip(xs, outs):
+        assert torch.equal(o, x.t().contiguous())      # bit-exact data movement

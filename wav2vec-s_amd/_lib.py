@@ -62,6 +62,10 @@ class NceDesc(C.Structure):
                 ("B", i32), ("M", i32), ("K", i32), ("C", i32), ("temp", f32)]
 
 
+class TransposeItem(C.Structure):
+    _fields_ = [("inp", vp), ("out", vp), ("R", i32), ("C", i32)]
+
+
 class LayerDesc(C.Structure):
     _fields_ = ([(n, i32) for n in ("B", "N", "E", "F", "H", "Tp", "m", "r", "post_ln", "num_cu")]
                 + [("p_drop", f32), ("p_attn", f32), ("seed_attn", u64), ("seed_drop1", u64), ("seed_drop2", u64)]
@@ -70,7 +74,8 @@ class LayerDesc(C.Structure):
                     "x_in", "qkv", "ctx", "lse", "s1", "mean1", "rstd1", "x1", "hpre", "h", "s2", "mean2", "rstd2",
                     "x_out", "tmp", "d_out", "d_in",
                     "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_ln1_g", "g_ln1_b", "g_w1", "g_b1", "g_w2", "g_b2",
-                    "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta")])
+                    "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta",
+                    "wqkv_t", "wo_t", "w1_t", "w2_t")])
 
 
 _DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc]
@@ -102,6 +107,7 @@ _SIGS = {
     "w2vs_ce_rows": [vp, i64, i32, vp, vp, vp],
     "w2vs_gather_rows": [vp, vp, vp, i64, i32, i32, vp],
     "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],
+    "w2vs_transpose_multi": [vp, i32, vp],
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],
     "w2vs_colsum": [vp, vp, i64, i32, i64, vp],
     "w2vs_dropout": [vp, vp, i64, f32, u64, vp],

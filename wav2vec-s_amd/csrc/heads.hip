@@ -539,6 +539,66 @@ int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t 
   return hip_check(hipGetLastError(), "transpose2d");
 }
 
+// Up to 64 transposes in one launch: the four weight matrices of every encoder layer are turned once per step
+// (the dgrad GEMMs want W^T), 48 launches of 5 us each before.  64x64 tiles, 16-byte loads and stores.
+struct TrBatch {
+  const bf16* in[64]; bf16* out[64];
+  int R[64], C[64], tile0[65], tc[64];
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TrBatch b) {
+  __shared__ bf16 t[64][72];
+  int it = 0;
+  while (it + 1 < b.n && (int)blockIdx.x >= b.tile0[it + 1]) ++it;
+  const int local = blockIdx.x - b.tile0[it];
+  const int R = b.R[it], C = b.C[it];
+  const int r0 = (local / b.tc[it]) * 64, c0 = (local % b.tc[it]) * 64;
+  const bf16* in = b.in[it];
+  bf16* out = b.out[it];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {       // 64 rows x 8 chunks of 8 elements
+    const int ch = tid + 256 * j, rr = ch >> 3, cc = (ch & 7) * 8;
+    bf16x8 v;
+    if (r0 + rr < R && c0 + cc + 8 <= C) v = *(const bf16x8*)(in + (long)(r0 + rr) * C + c0 + cc);
+    else
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (r0 + rr < R && c0 + cc + e < C) ? in[(long)(r0 + rr) * C + c0 + cc + e] : f2bf(0.f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[rr][cc + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {       // output rows = input columns
+    const int ch = tid + 256 * j, oc = ch >> 3, rr = (ch & 7) * 8;
+    if (c0 + oc >= C) continue;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = t[rr + e][oc];
+    bf16* dst = out + (long)(c0 + oc) * R + r0 + rr;
+    if (r0 + rr + 8 <= R && (R % 8) == 0) *(bf16x8*)dst = v;
+    else
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (r0 + rr + e < R) dst[e] = v[e];
+  }
+}
+int transpose_multi(const w2vs_transpose_item* items, int n, hipStream_t st) {
+  if (!items || n <= 0 || n > 64) return set_error("transpose_multi: need 1..64 items");
+  TrBatch b{};
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!items[i].in || !items[i].out || items[i].R <= 0 || items[i].C <= 0) return set_error("transpose_multi: bad item");
+    b.in[i] = (const bf16*)items[i].in; b.out[i] = (bf16*)items[i].out; b.R[i] = items[i].R; b.C[i] = items[i].C;
+    b.tile0[i] = tiles;
+    b.tc[i] = (items[i].C + 63) / 64;
+    tiles += b.tc[i] * ((items[i].R + 63) / 64);
+  }
+  b.tile0[n] = tiles;
+  b.n = n;
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3(tiles), dim3(256), 0, st, b);
+  return hip_check(hipGetLastError(), "transpose_multi");
+}
+
 __global__ void f32_to_bf16_kernel(const float* in, bf16* out, long n, float scale) {
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i + 3 < n) {

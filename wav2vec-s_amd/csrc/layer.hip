@@ -81,7 +81,8 @@ int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
 
 int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(layer_check(L));
-  if (!L.d_out || !L.d_in || !L.wt_scratch || !L.ws_e0 || !L.ws_e1 || !L.ws_e2 || !L.ws_f || !L.ws_qkv || !L.delta)
+  const bool pre_t = L.wqkv_t && L.wo_t && L.w1_t && L.w2_t;
+  if (!L.d_out || !L.d_in || (!L.wt_scratch && !pre_t) || !L.ws_e0 || !L.ws_e1 || !L.ws_e2 || !L.ws_f || !L.ws_qkv || !L.delta)
     return set_error("layer_bwd: null scratch pointer");
   if (!L.g_wqkv || !L.g_bqkv || !L.g_wo || !L.g_bo || !L.g_w1 || !L.g_b1 || !L.g_w2 || !L.g_b2 || !L.g_ln1_g ||
       !L.g_ln1_b || !L.g_ln2_g || !L.g_ln2_b)
@@ -96,12 +97,12 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(ln_bwd(b2, s));
   // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
   TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, cu, s));
-  TRY(transpose2d(L.w2, L.wt_scratch, E, F, 1, s));                       // [E,F] -> [F,E]
-  TRY(lin_dgrad(L.ws_e0, L.wt_scratch, L.ws_f, L.hpre, R, E, F, EPI_DGELU, s));
+  if (!pre_t) TRY(transpose2d(L.w2, L.wt_scratch, E, F, 1, s));           // [E,F] -> [F,E]
+  TRY(lin_dgrad(L.ws_e0, pre_t ? L.w2_t : L.wt_scratch, L.ws_f, L.hpre, R, E, F, EPI_DGELU, s));
   // fc1: wgrad, bias, dgrad + residual branch -> d_x1 (ws_e2)
   TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, cu, s));
-  TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));                       // [F,E] -> [E,F]
-  TRY(lin_dgrad(L.ws_f, L.wt_scratch, L.ws_e2, L.ws_e1, R, F, E, EPI_ADD, s));
+  if (!pre_t) TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));           // [F,E] -> [E,F]
+  TRY(lin_dgrad(L.ws_f, pre_t ? L.w1_t : L.wt_scratch, L.ws_e2, L.ws_e1, R, F, E, EPI_ADD, s));
   // LN1 backward: d_a = ds1 o dropmask (ws_e0), d_xin_a = ds1 (ws_e1)
   LnBwdDesc b1{};
   b1.x = L.s1; b1.gamma = L.ln1_g; b1.beta = L.ln1_b; b1.mean = L.mean1; b1.rstd = L.rstd1; b1.dy = L.ws_e2;
@@ -111,8 +112,8 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(ln_bwd(b1, s));
   // out_proj
   TRY(lin_wgrad(L.ws_e0, L.ctx, L.g_wo, L.g_bo, R, E, E, cu, s));
-  TRY(transpose2d(L.wo, L.wt_scratch, E, E, 1, s));
-  TRY(lin_dgrad(L.ws_e0, L.wt_scratch, L.ws_e2, nullptr, R, E, E, EPI_NONE, s));   // d_ctx
+  if (!pre_t) TRY(transpose2d(L.wo, L.wt_scratch, E, E, 1, s));
+  TRY(lin_dgrad(L.ws_e0, pre_t ? L.wo_t : L.wt_scratch, L.ws_e2, nullptr, R, E, E, EPI_NONE, s));   // d_ctx
   // attention
   AttnDesc a{};
   fill_attn(L, a);
@@ -122,8 +123,8 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(attn_bwd(a, s));
   // fused QKV projection
   TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s));
-  TRY(transpose2d(L.wqkv, L.wt_scratch, 3 * E, E, 1, s));                 // [3E,E] -> [E,3E]
-  TRY(lin_dgrad(L.ws_qkv, L.wt_scratch, L.d_in, L.ws_e1, R, 3 * E, E, EPI_ADD, s));
+  if (!pre_t) TRY(transpose2d(L.wqkv, L.wt_scratch, 3 * E, E, 1, s));     // [3E,E] -> [E,3E]
+  TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, L.ws_e1, R, 3 * E, E, EPI_ADD, s));
   return 0;
 }
 

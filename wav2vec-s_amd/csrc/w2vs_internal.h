@@ -54,6 +54,7 @@ int nce_bwd(const NceDesc& d, hipStream_t st);
 int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hipStream_t st);
 int gather_rows(const void* src, const int* idx, void* dst, long R, int C, int scatter, hipStream_t st);
 int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t st);
+int transpose_multi(const w2vs_transpose_item* items, int n, hipStream_t st);
 int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st);
 int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream_t st);
 int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n, float lr, float b1, float b2, float eps,

@@ -525,6 +525,18 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
             alt = ops.empty((R, E), BF16, dev)
             d_in_bufs[1] = alt.data_ptr()
             cur = dx
+            # every layer's four weights are transposed for the dgrad GEMMs in ONE launch (was 4 launches per layer)
+            per_t = 3 * E * E + E * E + 2 * E * F
+            wt_all = ops.empty((len(st.layers) * per_t,), BF16, dev)
+            items = []
+            for j_, rec in enumerate(st.layers):
+                d = rec["desc"]
+                base = wt_all.data_ptr() + 2 * j_ * per_t
+                d.wqkv_t, d.wo_t = base, base + 2 * 3 * E * E
+                d.w1_t, d.w2_t = base + 2 * 4 * E * E, base + 2 * (4 * E * E + E * F)
+                items += [(d.wqkv, d.wqkv_t, 3 * E, E), (d.wo, d.wo_t, E, E), (d.w1, d.w1_t, F, E), (d.w2, d.w2_t, E, F)]
+            ops.transpose_multi(items)
+            st._wt_all = wt_all
             for jj, rec in enumerate(reversed(st.layers)):
                 li = rec["li"]
                 pre = f"encoder.layers.{li}."

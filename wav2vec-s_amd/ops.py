@@ -212,6 +212,19 @@ def colsum(x, out_f32):
     _lib.call("w2vs_colsum", _p(x), _p(out_f32), M, N, N, _stream())
 
 
+
+def transpose_multi(items):
+    """items: (in_ptr, out_ptr, R, C) tuples (device addresses of bf16 matrices); out[C, R] = in[R, C]^T for all
+    of them in one launch per 64 items."""
+    from ._lib import TransposeItem
+    for i in range(0, len(items), 64):
+        chunk = items[i:i + 64]
+        arr = (TransposeItem * len(chunk))()
+        for a, (pi, po, r, c) in zip(arr, chunk):
+            a.inp, a.out, a.R, a.C = pi, po, r, c
+        _lib.call("w2vs_transpose_multi", arr, len(chunk), _stream())
+
+
 def transpose2d(x, batch=1):
     """[batch, R, C] -> [batch, C, R] (bf16)."""
     _chk(x, BF16, "x")
