@@ -61,6 +61,22 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
   return r;
 }
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+// Scaled + masked scores of one 32-key sub-tile, branch free: the 16 key biases of this lane's accumulator rows
+// come in as four 16-byte LDS reads, the mask compares compile-time row offsets against lane-relative limits.
+// (A per-element `ok ? S*c + kb[kl] : -inf` made the compiler branch around sixteen dependent ds_read_b32.)
+__device__ __forceinline__ void masked_scores(f32x16& S, float c, const float* kb32, int hh, int lim_r, int clo_r, int chi_r) {
+  f32x4 kbv[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(kb32 + 8 * g4 + 4 * hh);
+  lim_r -= 4 * hh; clo_r -= 4 * hh; chi_r -= 4 * hh;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rc = (i & 3) + 8 * (i >> 2);
+    const bool ok = (rc < lim_r) | ((rc >= clo_r) & (rc < chi_r));
+    const float sv = fmaf(S[i], c, kbv[i >> 2][i & 3]);
+    S[i] = ok ? sv : -INFINITY;
+  }
+}
 
 struct QLimits { int lim, clo, chi; };
 __device__ __forceinline__ QLimits q_limits(int q, int Tp, int m, int r, int N) {
@@ -231,14 +247,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { S[i] *= c; mloc = fmaxf(mloc, S[i]); }
       } else {
+        masked_scores(S, c, kb + sub * 32, hh, L.lim - k0, L.clo - k0, L.chi - k0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
-          bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
-          float sv = ok ? S[i] * c + kb[kl] : -INFINITY;
-          S[i] = sv;
-          mloc = fmaxf(mloc, sv);
-        }
+        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, S[i]);
       }
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       // Lazy rescale: keep exponentiating against the reference max `mrun` while no row's maximum grew by
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
   int mlim, bclo, bchi;
   tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
-  const int wmlim = wave_max_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
+  const int wmlim = wave_max_i(L.lim), wfull = wave_min_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
   const float c = p.scale * LOG2E;
   const uint32_t thr = drop_threshold(p.p_drop) >> 16;
   const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
@@ -435,6 +446,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     const bf16* Ktb = Kt[buf];
     const bf16* Vb = Vs[buf];
     const float* kb = kbias[buf];
+    const bool tile_clean = !__any(kb[lane] != 0.f);  // no padded / out-of-range key in this tile
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int k0 = kt0 + sub * 32;
@@ -457,12 +469,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
           dP[i + 1] *= (hw >> 16) >= thr ? inv_keep : 0.f;
         }
       }
+      if (tile_clean && (k0 + 32 <= wfull)) {   // every query of the wave sees all 32 keys, none padded
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] *= c;
+      } else {
+        masked_scores(S, c, kb + sub * 32, hh, L.lim - k0, L.clo - k0, L.chi - k0);
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        int kl = sub * 32 + acc_row(i, hh), key = kt0 + kl;
-        bool ok = (key < L.lim) || (key >= L.clo && key < L.chi);
-        float sv = ok ? S[i] * c + kb[kl] : -INFINITY;
-        float pe = fast_exp2(sv - lse2);
+        float pe = fast_exp2(S[i] - lse2);
         S[i] = pe * (dP[i] - delta) * p.scale;
       }
 #pragma unroll
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
   __shared__ __attribute__((aligned(16))) bf16 Dt[2][QT * HD];   // dO tr reads
   __shared__ __attribute__((aligned(16))) float lse_s[2][QT];
   __shared__ __attribute__((aligned(16))) float del_s[2][QT];
-  __shared__ int qlim_s[2][QT], qclo_s[2][QT], qchi_s[2][QT];
+  __shared__ __attribute__((aligned(16))) int qlim_s[2][QT], qclo_s[2][QT], qchi_s[2][QT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r32 = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -540,6 +555,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
   const uint32_t khalf = (uint32_t)min(key, N - 1) >> 1, kodd = (uint32_t)min(key, N - 1) & 1u;
   const int klo = kblk0, khi = min(kblk0 + QB, N);  // this block's keys [klo, khi)
   const int wk0 = kblk0 + wid * 32, wk1 = min(wk0 + 32, N);  // this wave's keys [wk0, wk1)
+  const bool wave_keys_ok = __all(key_ok);                     // none of them padded or past the end
   f32x16 dV0, dV1, dK0, dK1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
@@ -602,12 +618,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
     const int* qlim_b = qlim_s[buf]; const int* qclo_b = qclo_s[buf]; const int* qchi_b = qchi_s[buf];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      bool sub_full = false;
       {  // can any query of this 32-row sub-tile see any key of this wave?  (wave-uniform)
         const int qs0 = q0 + sub * 32;
         if (qs0 >= N || wk0 >= N) continue;
+        const int qs1 = min(qs0 + 32, N) - 1;
         int smlim, sclo, schi;
-        tile_ranges(qs0, min(qs0 + 32, N) - 1, p.Tp, p.m, p.r, N, smlim, sclo, schi);
+        tile_ranges(qs0, qs1, p.Tp, p.m, p.r, N, smlim, sclo, schi);
         if (!((wk0 < smlim) || (wk0 < schi && wk1 > sclo))) continue;
+        // smallest main-key limit over the sub-tile's queries (both query kinds are ordered by block)
+        int minlim = 0;
+        if (qs1 < p.Tp) minlim = min((qs0 / p.m + 1) * p.m, p.Tp);
+        else if (qs0 >= p.Tp && p.r > 0) minlim = min(((qs0 - p.Tp) / p.r + 1) * p.m, p.Tp);
+        sub_full = wave_keys_ok && qs0 + 32 <= N && wk0 + 32 <= minlim;
       }
       f32x16 S, dP;
 #pragma unroll
@@ -619,20 +642,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
         bf16x8 ad = *(const bf16x8*)(Db + kswz(sub * 32 + r32, 2 * s + hh));
         dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[s], dP, 0, 0, 0);
       }
+      // per-query scalars of this lane's accumulator rows come as 16-byte LDS reads, four consecutive rows each
+      // (the per-element form branched around five dependent ds_read_b32 per score)
+      typedef __attribute__((ext_vector_type(4))) int i32x4;
       f32x16 Pd;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        int ql = sub * 32 + acc_row(i, hh), qq = q0 + ql;
-        bool ok = key_ok && ((key < qlim_b[ql]) || (key >= qclo_b[ql] && key < qchi_b[ql]));
-        float sv = ok ? S[i] * c : -INFINITY;
-        float pe = fast_exp2(sv - lse_b[ql]);
-        float ks = 1.f;
-        if (thr > 0) {
-          const uint32_t hw = pair_hash(s0, s1, (dbase + (uint32_t)min(qq, N - 1)) * Nh + khalf);
-          ks = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? inv_keep : 0.f;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int rb = sub * 32 + 8 * g4 + 4 * hh;
+        const f32x4 lse4 = *(const f32x4*)(lse_b + rb);
+        const f32x4 del4 = *(const f32x4*)(del_b + rb);
+        float pe[4];
+        if (sub_full) {   // every query of the sub-tile sees every key of this wave, no padded key: no mask at all
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pe[e] = fast_exp2(fmaf(S[4 * g4 + e], c, -lse4[e]));
+        } else {
+          const i32x4 lim4 = *(const i32x4*)(qlim_b + rb), clo4 = *(const i32x4*)(qclo_b + rb), chi4 = *(const i32x4*)(qchi_b + rb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = key_ok & ((key < lim4[e]) | ((key >= clo4[e]) & (key < chi4[e])));
+            const float v = fast_exp2(fmaf(S[4 * g4 + e], c, -lse4[e]));
+            pe[e] = ok ? v : 0.f;
+          }
         }
-        Pd[i] = pe * ks;
-        S[i] = pe * (dP[i] * ks - del_b[ql]) * p.scale;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g4 + e;
+          float ks = 1.f;
+          if (thr > 0) {
+            const int qq = q0 + rb + e;
+            const uint32_t hw = pair_hash(s0, s1, (dbase + (uint32_t)min(qq, N - 1)) * Nh + khalf);
+            ks = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? inv_keep : 0.f;
+          }
+          Pd[i] = pe[e] * ks;
+          S[i] = pe[e] * (dP[i] * ks - del4[e]) * p.scale;
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
