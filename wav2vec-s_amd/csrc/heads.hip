@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256) void quant_kernel(QuantP p) {
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   const int V = p.V, G = p.G, D = p.D;
   const long rows = (long)p.R * G;
+  // forward: softmax probabilities are summed per code.  When every wave keeps one group (nwaves % G == 0) the sums
+  // stay in registers over the wave's rows and reach memory once per block; per-row atomics put 2000 adders on
+  // each of the 640 words.
+  const bool keep = !BWD && (nwaves % G) == 0;
+  float pacc[QV_MAX];
+#pragma unroll
+  for (int j = 0; j < QV_MAX; ++j) pacc[j] = 0.f;
   for (long rg = wave_id; rg < rows; rg += nwaves) {
     const long row = rg / G;
     const int g = (int)(rg % G);
@@ -98,7 +105,8 @@ __global__ __launch_bounds__(256) void quant_kernel(QuantP p) {
 #pragma unroll
       for (int j = 0; j < QV_MAX; ++j) {
         int v = lane + 64 * j;
-        if (v < V) atomicAdd(&p.prob_sum[g * V + v], ps[j] * inv_se);
+        if (keep) pacc[j] += ps[j] * inv_se;
+        else if (v < V) atomicAdd(&p.prob_sum[g * V + v], ps[j] * inv_se);
       }
       if (lane == 0) {
         atomicAdd(&p.hard_cnt[g * V + xarg], 1.0f);
@@ -140,6 +148,27 @@ __global__ __launch_bounds__(256) void quant_kernel(QuantP p) {
       const bf16* dqp = p.dq + row * (long)(G * D) + (long)g * D;
       float* dv = p.dvars + ((long)g * V + sel) * D;
       for (int e = lane; e < D; e += 64) atomicAdd(&dv[e], bf2f(dqp[e]));
+    }
+  }
+  if (keep) {   // block-uniform
+    __shared__ float pred[4][QV_MAX * 64];
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < QV_MAX; ++j) pred[w][lane + 64 * j] = pacc[j];
+    __syncthreads();
+    // waves w and w' of a block share a group iff (w - w') % G == 0; the first wave of each group folds and flushes
+    const int g = (int)(wave_id % G);
+    bool first = true;
+    for (int w2 = 0; w2 < w; ++w2) first = first && (((blockIdx.x * 4 + w2) % G) != g);
+    if (first && wave_id < rows) {
+#pragma unroll
+      for (int j = 0; j < QV_MAX; ++j) {
+        const int v = lane + 64 * j;
+        float sum = 0.f;
+        for (int w2 = w; w2 < 4; ++w2)
+          if (((blockIdx.x * 4 + w2) % G) == g) sum += pred[w2][v];
+        if (v < V) atomicAdd(&p.prob_sum[g * V + v], sum);
+      }
     }
   }
 }
@@ -196,7 +225,7 @@ int quant_fwd(const QuantDesc& d, hipStream_t st) {
   if (int e = hip_check(hipMemsetAsync(p.hard_cnt, 0, sizeof(float) * p.G * p.V, st), "memset")) return e;
   if (int e = hip_check(hipMemsetAsync(p.prob_sum, 0, sizeof(float) * p.G * p.V, st), "memset")) return e;
   long rows = (long)p.R * p.G;
-  int grid = (int)std::min<long>((rows + 3) / 4, 2048);
+  int grid = (int)std::min<long>((rows + 3) / 4, 256);   // few blocks: the probability sums flush once per block
   hipLaunchKernelGGL(quant_kernel<false>, dim3(grid), dim3(256), 0, st, p);
   hipLaunchKernelGGL(quant_finalize_kernel, dim3(1), dim3(256), 0, st, p.hard_cnt, p.prob_sum, p.R, p.G, p.V, d.ppl_out,
                      d.cvec_out);
@@ -480,18 +509,19 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* logits, long R, in
       if (amx == 0) { max0 += 1.f; if (amn == 0) both0 += 1.f; }
     }
   }
-  if (lane == 0) {
-    atomicAdd(&out[0], loss_acc);
-    atomicAdd(&out[1], max0);
-    atomicAdd(&out[2], both0);
-  }
+  // one atomic triple per BLOCK: thousands of waves adding into the same three words serialise at the memory
+  // side (this tail was 60 of the kernel's 78 us)
+  __shared__ float red[4][3];
+  if (lane == 0) { red[threadIdx.x >> 6][0] = loss_acc; red[threadIdx.x >> 6][1] = max0; red[threadIdx.x >> 6][2] = both0; }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(&out[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hipStream_t st) {
   if (!logits || !out3) return set_error("ce_rows: null pointer");
   if (R <= 0 || W <= 0) return set_error("ce_rows: bad shape");
   if (int e = hip_check(hipMemsetAsync(out3, 0, 3 * sizeof(float), st), "memset")) return e;
-  int grid = (int)std::min<long>((R + 3) / 4, 1024);
+  int grid = (int)std::min<long>((R + 3) / 4, 256);
   hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, st, logits, R, W, out3, dlogits);
   return hip_check(hipGetLastError(), "ce_rows");
 }
@@ -675,11 +705,14 @@ __global__ void sumsq_kernel(const float* x, long n, float* out) {
   float s = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));   // one same-address atomic per block
 }
 int sumsq(const float* x, long n, float* out, hipStream_t st) {
   if (!x || !out || n <= 0) return set_error("sumsq: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, st, x, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, st, x, n, out);
   return hip_check(hipGetLastError(), "sumsq");
 }
 

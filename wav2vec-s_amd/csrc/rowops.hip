@@ -483,9 +483,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
       store_row(p.y + row * C, C, lane, x);
     }
   }
-  if (p.sumsq) {
+  if (p.sumsq) {   // one same-address atomic per block, not per wave
+    __shared__ float sred[4];
     sq = wave_sum(sq);
-    if (lane == 0) atomicAdd(p.sumsq, sq);
+    if (lane == 0) sred[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(p.sumsq, (sred[0] + sred[1]) + (sred[2] + sred[3]));
   }
 }
 
