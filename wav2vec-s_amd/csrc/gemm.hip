@@ -308,6 +308,183 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT with dedicated loader waves: 256 x 128 x 64 tiles, 12 waves per workgroup = 8 consumers (64x64 each, the
+// fragment code of the kernel above) + 4 loaders that do nothing but issue LDS-DMA, one workgroup per CU,
+// three LDS stages.  Measured on the 4-wave kernel and on an 8-wave variant without loaders: the MFMAs of a K
+// tile take 0.25 / 0.5 us, its LDS-DMA alone 0.46 / 0.7 us (~70 GB/s per CU, the issue rate of
+// buffer_load...lds: the issuing wave is stuck ~100+ cycles per 1-KiB piece), and the two hardly overlap while
+// the SAME waves do both.  A loader wave can sit in the issue queue all the time; the consumers never do.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int NLOAD>
+__global__ __launch_bounds__((8 + NLOAD) * 64) void gemm_nt_lc_kernel(GemmP p) {
+  constexpr int TBM = 256, TBN = 128, NST = 3;
+  constexpr int A_EL = TBM * BK, B_EL = TBN * BK, STAGE_EL = A_EL + B_EL;   // 48 KiB per stage
+  constexpr int NTHR = (8 + NLOAD) * 64;
+  constexpr int LP = 48 / NLOAD;                                            // pieces per loader wave and stage
+  __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];         // 144 KiB; the epilogue reuses it
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool loader = wid >= 8;
+  const int wm = (wid >> 1) & 3, wn = wid & 1;
+  int tm_, tn_;
+  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, 4, tm_, tn_);
+  const int m0 = tm_ * TBM, n0 = tn_ * TBN;
+  const int bz = blockIdx.z;
+  const int nk = (p.K + BK - 1) / BK;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+
+  if (loader) {
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long)bz * p.sA, p.a_bytes);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
+    // the stage image is 48 pieces of 8 rows x 128 B (A rows 0..255, then B rows 0..127); loader l takes pieces
+    // l, l+NLOAD, ...  Linear LDS image, XOR swizzle on the SOURCE chunk as in the 4-wave kernel.
+    const int lw = wid - 8;
+    uint32_t d_off[LP];
+    int d_c8[LP];
+    bool d_ok[LP];
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const int piece = lw + NLOAD * j;              // 0..47
+      const bool isA = piece < 32;
+      const int row = (isA ? piece : piece - 32) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      d_c8[j] = c * 8;
+      if (isA) {
+        d_ok[j] = m0 + row < p.M;
+        d_off[j] = (uint32_t)((p.a_off + (long)(m0 + row) * p.lda + c * 8) * 2);
+      } else {
+        d_ok[j] = n0 + row < p.N;
+        d_off[j] = (uint32_t)(((long)(n0 + row) * p.ldb + c * 8) * 2);
+      }
+    }
+    auto dma_issue = [&](int kt, int stage) {   // kt >= nk: out-of-range fetches (zeros), same instruction count
+      bf16* sbase = lds + stage * STAGE_EL;
+#pragma unroll
+      for (int j = 0; j < LP; ++j) {
+        const int piece = lw + NLOAD * j;
+        const bool kok = kt < nk && (kt * BK + d_c8[j]) < p.K;
+        const uint32_t o = (kok && d_ok[j]) ? d_off[j] + (uint32_t)(kt * BK * 2) : 0xFFFFFFF0u;
+        bf16* dst = sbase + piece * 8 * 64;          // A pieces 0..31 fill [0, A_EL), B pieces follow
+        if (piece < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+      }
+    };
+    dma_issue(0, 0);
+    dma_issue(1, 1);
+    if (LP == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int pre = stage == 0 ? 2 : stage - 1;        // (stage + 2) % 3: free since the last barrier
+      dma_issue(kt + 2, pre);
+      if (LP == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt+1 landed; kt+2 in flight
+      __builtin_amdgcn_s_barrier();
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing zero-fill prefetches still target the LDS
+  } else {
+    __builtin_amdgcn_s_barrier();                         // tile 0 is in
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bf16* sa = lds + stage * STAGE_EL;
+      const bf16* sb = sa + A_EL;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + swz(wm * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + swz(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_barrier();                       // done reading `stage`; the next tile is in
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+  }
+  __builtin_amdgcn_s_barrier();                           // every DMA has landed, every read is done
+
+  // ---- epilogue (consumer waves): registers -> (fp32 math) -> LDS bf16 tile(s) [256][136] -> 16-B row stores ----
+  bf16* Cb = p.C + (long)bz * p.sC;
+  if (EPI == EPI_F32) {
+    if (loader) return;
+    float* Cf = p.Cf + (long)bz * p.sC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
+          if (row < p.M && col < p.N) Cf[(long)row * p.ldc + col] = acc[i][j][r] * p.alpha;
+        }
+    return;
+  }
+  constexpr int CP = 136;
+  bf16* st = lds;                 // 256*136*2 = 69632 B
+  bf16* st2 = lds + TBM * CP;     // pre-activation tile
+  if (!loader) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int col = n0 + wn * 64 + j * 16 + fr;
+      float bv = 0.f;
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE)
+        if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int lr = wm * 64 + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
+          float v = acc[i][j][r] + bv;
+          if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+            if (EPI == EPI_BIAS_GELU_SAVE) {
+              bf16 pre = f2bf(v);
+              st2[lr * CP + lc] = pre;
+              v = bf2f(pre);  // the activation is taken of the value that is actually saved
+            }
+            v = gelu_exact(v);
+          }
+          st[lr * CP + lc] = f2bf(v);
+        }
+    }
+  }
+  __syncthreads();
+  // 256 rows x 16 chunks of 16 B = 4096 chunks over all threads
+  for (int c = tid; c < TBM * 16; c += NTHR) {
+    int lr = c >> 4, cc = c & 15;
+    int row = m0 + lr, col = n0 + cc * 8;
+    long o = (long)row * p.ldc + col;
+    if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
+      if (EPI == EPI_DGELU) {
+        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+        bf16x8 outv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * gelu_grad(bf2f(a[e])));
+        *(bf16x8*)(Cb + o) = outv;
+      } else if (EPI == EPI_ADD) {
+        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+        bf16x8 outv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) + bf2f(a[e]));
+        *(bf16x8*)(Cb + o) = outv;
+      } else {
+        *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
+        if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN: C[M,N] += alpha * sum_k A[k,M] * B[k,N];  A,B row-major with the contraction index as the
 // ROW index (tokens).  grid.z splits K; partial sums are combined with fp32 atomics into Cf
 // (which the caller zeroes), so a step's dW for every layer lands in one fp32 gradient arena.
@@ -534,10 +711,24 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   const long ntiles = (long)grid.x * grid.y * grid.z;
   // measured on MI355X: LDS-DMA staging wins on encoder-sized grids (+8..15 % on the N=768 and QKV shapes),
   // the register-staged 3-blocks-per-CU form on the very large conv grids (+5..8 %)
-  const int mode = mode_env >= 0 ? mode_env : (ntiles >= 1500 ? 1 : 2);
+  int mode = ntiles >= 1500 ? 1 : 2;
+  const dim3 grid8((d.N + 127) / 128, (d.M + 255) / 256, d.batch > 0 ? d.batch : 1);
+  if (mode == 2) {
+    // loader/consumer 256x128 kernel (one workgroup per CU) against the 128x128 kernel (two per CU): time =
+    // rounds x (K tiles x time per K tile + fixed), constants fitted to rocprofv3 timings of the encoder shapes
+    // (0.47 us and 2.8 us for 128^2, 0.72 us and 7.5 us for 256x128).  It wins where the 128^2 grid leaves a ragged
+    // second round and K is long: fc2 forward, fc1 / QKV dgrad (-15..20 %).
+    const double nkt = (d.K + BK - 1) / BK;
+    const double t2 = (double)((ntiles + 255) / 256) * (nkt * 0.47 + 2.8);
+    const long tiles8 = (long)grid8.x * grid8.y * grid8.z;
+    const double t3 = (double)((tiles8 + 255) / 256) * (nkt * 0.72 + 7.5 + (d.epi == EPI_BIAS_GELU_SAVE ? 4.0 : 0.0));
+    if (t3 < 0.95 * t2) mode = 3;
+  }
+  if (mode_env >= 0) mode = mode_env;
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
-    if (mode == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, s, p);          \
+    if (mode == 3) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4>), grid8, dim3(768), 0, s, p); \
+    else if (mode == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, s, p);     \
     else if (mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, s, p);     \
     else hipLaunchKernelGGL((gemm_nt_kernel<E, 0>), grid, block, 0, s, p);                    \
   } while (0)
