@@ -635,6 +635,144 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// TN with dedicated loader waves (weight gradients): 256(m) x 128(n) output tile, K tiles of 64 token rows,
+// 8 consumer waves (64x64 each, operands through ds_read_b64_tr_b16 as above) + 4 loader waves, three LDS
+// stages, one workgroup per CU.  A stage is three [64 k][128] bf16 images (A columns 0..127, A columns
+// 128..255, B), each with the tswz swizzle applied on the DMA source side.  grid.z splits K; partial sums are
+// added with fp32 atomics.  The optional column sum of A (bias gradient) rides on the matrix cores: consumers
+// with wn == 0 of the tn == 0 blocks multiply their A fragments with an all-ones B fragment.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
+  constexpr int IMG = TK * TP;                       // one [64][128] image, 16 KiB
+  constexpr int STAGE_EL = 3 * IMG, NST = 3, LP = 12;
+  __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];   // 144 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool loader = wid >= 8;
+  const int wm = (wid >> 1) & 3, wn = wid & 1;
+  int tm_, tn_;
+  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, 4, tm_, tn_);
+  const int m0 = tm_ * 256, n0 = tn_ * 128;
+  const int bz = blockIdx.z / p.n_split, sp = blockIdx.z % p.n_split;
+  const int k_begin = sp * p.k_split;
+  const int k_end = min(p.K, k_begin + p.k_split);
+  if (k_begin >= k_end) return;                       // block-uniform
+  const int nk = (k_end - k_begin + TK - 1) / TK;
+  const bool do_colsum = p.colsum != nullptr && tn_ == 0 && wn == 0 && !loader;
+  f32x4 acc[4][4], cs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (loader) {
+    __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long)bz * p.sA, p.a_bytes);
+    __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
+    // 48 pieces per stage: 16 per image, a piece = 4 k-rows x 256 B; loader l takes pieces l, l+4, ...
+    const int lw = wid - 8;
+    uint32_t d_col[LP];     // byte offset of this lane's 16-B chunk inside its row, or ~0 if the column is out of range
+    int d_row[LP];          // k row inside the tile
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const int piece = lw + 4 * j, img = piece >> 4, r = (piece & 15) * 4 + (lane >> 4);
+      const int wsw = (r & 3) | (((r >> 3) & 1) << 2);
+      const int lc = (lane & 15) ^ (wsw << 1);          // logical 16-B chunk stored at physical chunk lane&15
+      d_row[j] = r;
+      if (img < 2) d_col[j] = (m0 + img * 128 + lc * 8 < p.M) ? (uint32_t)((m0 + img * 128 + lc * 8) * 2) : 0xFFFFFFF0u;
+      else d_col[j] = (n0 + lc * 8 < p.N) ? (uint32_t)((n0 + lc * 8) * 2) : 0xFFFFFFF0u;
+    }
+    auto dma_issue = [&](int kt, int stage) {
+      bf16* sbase = lds + stage * STAGE_EL;
+#pragma unroll
+      for (int j = 0; j < LP; ++j) {
+        const int piece = lw + 4 * j, img = piece >> 4;
+        const int k = k_begin + kt * TK + d_row[j];
+        const bool ok = kt < nk && k < k_end && d_col[j] != 0xFFFFFFF0u;
+        bf16* dst = sbase + piece * 4 * TP;              // pieces are consecutive 1-KiB blocks of the stage
+        if (img < 2) {
+          const uint32_t o = ok ? (uint32_t)(((long)p.a_off + (long)k * p.lda) * 2) + d_col[j] : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+        } else {
+          const uint32_t o = ok ? (uint32_t)((long)k * p.ldb * 2) + d_col[j] : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+        }
+      }
+    };
+    dma_issue(0, 0);
+    dma_issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int pre = stage == 0 ? 2 : stage - 1;
+      dma_issue(kt + 2, pre);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;                                              // no barrier follows for the consumers either
+  }
+  // ---- consumers
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  union { bf16x8 v; uint32_t u[4]; } ones;
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3F803F80u;
+  __builtin_amdgcn_s_barrier();
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bf16* sa = lds + stage * STAGE_EL + (wm >> 1) * IMG;
+    const bf16* sb = lds + stage * STAGE_EL + 2 * IMG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+      const int kr = ks * 32 + g * 8 + q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = (wm & 1) * 64 + i * 16 + pp * 4;
+        s16x4 lo = ds_tr(sa + tswz(kr, col)), hi = ds_tr(sa + tswz(kr + 4, col));
+        union { bf16x8 v; s16x4 h[2]; } u; u.h[0] = lo; u.h[1] = hi; af[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + pp * 4;
+        s16x4 lo = ds_tr(sb + tswz(kr, col)), hi = ds_tr(sb + tswz(kr + 4, col));
+        union { bf16x8 v; s16x4 h[2]; } u; u.h[0] = lo; u.h[1] = hi; bfr[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones.v, cs[i], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
+        if (row < p.M && col < p.N) atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
+      }
+  if (do_colsum && fr == 0) {   // every column of cs holds the same row sums
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
+        if (row < p.M) atomicAdd(&p.colsum[row], cs[i][r] * p.alpha);
+      }
+  }
+}
+
 // Launch-level profiling hooks (bench.py "roofline"): every stride-th GEMM launch is bracketed by a
 // pair of HIP events ON THE STREAM IT IS LAUNCHED ON; totals are read back after the timed region.
 struct ProfSample { hipEvent_t e0, e1; int id; double flops; };
@@ -761,6 +899,29 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   p.a_bytes = (uint32_t)a_ext; p.b_bytes = (uint32_t)b_ext;
   const int nb = d.batch > 0 ? d.batch : 1;
   p.sA = d.sA; p.sB = d.sB;
+  // loader/consumer form (256x128 tiles, one workgroup per CU) when its grid can fill the chip with at most ~1
+  // workgroup per CU and each keeps a long K loop; small outputs (out_proj) stay on the 128x128 kernel
+  static const int tn_lc_env = [] { const char* e = getenv("W2VS_TN_LC"); return e ? atoi(e) : -1; }();
+  {
+    const int tiles8 = ((d.N + 127) / 128) * ((d.M + 255) / 256) * nb;
+    const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
+    bool use_lc = tiles8 >= 24 && tiles8 <= ncu;
+    if (tn_lc_env >= 0) use_lc = tn_lc_env != 0;
+    if (use_lc) {
+      int splits = std::max(1, ncu / tiles8);
+      const int max_splits = (d.K + TK - 1) / TK;
+      splits = std::min(splits, max_splits);
+      int ks = (d.K + splits - 1) / splits;
+      ks = ((ks + TK - 1) / TK) * TK;
+      splits = (d.K + ks - 1) / ks;
+      p.k_split = ks; p.n_split = splits;
+      dim3 grid((d.N + 127) / 128, (d.M + 255) / 256, splits * nb);
+      hipEvent_t pe = prof_begin(s);
+      hipLaunchKernelGGL(gemm_tn_lc_kernel, grid, dim3(768), 0, s, p);
+      prof_end(pe, 7, 2.0 * d.M * d.N * d.K * nb, s);
+      return hip_check(hipGetLastError(), "gemm_tn launch");
+    }
+  }
   int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * nb;
   static const int tn_target = [] { const char* e = getenv("W2VS_TN_TARGET"); return e ? atoi(e) : 0; }();
   int target = tn_target > 0 ? tn_target : (num_cu_hint > 0 ? num_cu_hint : 256) * 3 / 2;  // 1.5 blocks per CU: measured best trade between fill and atomic traffic
