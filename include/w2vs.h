@@ -62,6 +62,8 @@ typedef struct w2vs_gemm_desc {
   int64_t c_elems;         /* valid output elements per batch (0 = derive)            */
   int32_t epi; float alpha;
   float* colsum;           /* TN only, optional: colsum[m] += alpha * sum_k A[k, m] (bias gradient fused in) */
+  void* ws; int64_t ws_bytes; /* TN only, optional scratch (36 MB always suffices): split-K partial tiles are stored
+                                 there and summed by a second launch instead of fp32 atomics into Cf */
 } w2vs_gemm_desc;
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
 /* Measurement hooks: bracket every stride-th GEMM launch with HIP events on its own stream (0 = off).
@@ -171,6 +173,7 @@ typedef struct w2vs_layer_desc {
   /* optional: the four weights already transposed ([E,3E], [E,E], [E,F], [F,E]), e.g. by ONE w2vs_transpose_multi
    * for every layer of the step; layer_bwd then skips its own four transposes (wt_scratch may be NULL) */
   const void *wqkv_t, *wo_t, *w1_t, *w2_t;
+  void* tn_ws; int64_t tn_ws_bytes;   /* optional scratch handed to the weight-gradient GEMMs (w2vs_gemm_desc.ws) */
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

@@ -16,7 +16,7 @@ class GemmDesc(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
                 ("lda", i64), ("ldb", i64), ("ldc", i64), ("a_off", i64),
                 ("sA", i64), ("sB", i64), ("sC", i64), ("a_bytes", i64), ("b_bytes", i64), ("c_elems", i64),
-                ("epi", i32), ("alpha", f32), ("colsum", vp)]
+                ("epi", i32), ("alpha", f32), ("colsum", vp), ("ws", vp), ("ws_bytes", i64)]
 
 
 class LnFwdDesc(C.Structure):
@@ -75,7 +75,7 @@ class LayerDesc(C.Structure):
                     "x_out", "tmp", "d_out", "d_in",
                     "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_ln1_g", "g_ln1_b", "g_w1", "g_b1", "g_w2", "g_b2",
                     "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta",
-                    "wqkv_t", "wo_t", "w1_t", "w2_t")])
+                    "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64)])
 
 
 _DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc]

@@ -54,6 +54,7 @@ struct GemmP {
   long c_elems;               // valid output elements per batch
   int k_split, n_split;       // TN only: K range per split, splits per batch
   float* colsum;              // TN only: optional out[m] += sum_k A[k, m]  (bias gradient)
+  float* slab;                // TN loader/consumer: partial tiles [grid.z][M][N] instead of atomics into Cf
   float alpha;
 };
 
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
 // added with fp32 atomics.  The optional column sum of A (bias gradient) rides on the matrix cores: consumers
 // with wn == 0 of the tn == 0 blocks multiply their A fragments with an all-ones B fragment.
 // ---------------------------------------------------------------------------------------------
+template <bool SLAB>
 __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
   constexpr int IMG = TK * TP;                       // one [64][128] image, 16 KiB
   constexpr int STAGE_EL = 3 * IMG, NST = 3, LP = 12;
@@ -656,8 +658,8 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
   const int bz = blockIdx.z / p.n_split, sp = blockIdx.z % p.n_split;
   const int k_begin = sp * p.k_split;
   const int k_end = min(p.K, k_begin + p.k_split);
-  if (k_begin >= k_end) return;                       // block-uniform
-  const int nk = (k_end - k_begin + TK - 1) / TK;
+  if (!SLAB && k_begin >= k_end) return;             // block-uniform (the host sizes splits so that none is empty)
+  const int nk = k_end > k_begin ? (k_end - k_begin + TK - 1) / TK : 0;
   const bool do_colsum = p.colsum != nullptr && tn_ == 0 && wn == 0 && !loader;
   f32x4 acc[4][4], cs[4];
 #pragma unroll
@@ -760,7 +762,12 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
-        if (row < p.M && col < p.N) atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
+        if (row < p.M && col < p.N) {
+          // a workgroup's 128 KiB of atomics drain at ~one wave-instruction per 50 ns per CU (25 us, as long as the
+          // whole K loop of an encoder wgrad); plain stores of the partial tile + a summing launch cost a third
+          if (SLAB) p.slab[((long)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r] * p.alpha;
+          else atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
+        }
       }
   if (do_colsum && fr == 0) {   // every column of cs holds the same row sums
 #pragma unroll
@@ -771,6 +778,24 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
         if (row < p.M) atomicAdd(&p.colsum[row], cs[i][r] * p.alpha);
       }
   }
+}
+
+// Cf[m][n] += sum over parts of slab[part][m][n]   (M x N fp32, N % 4 == 0; Cf rows are ldc apart)
+__global__ __launch_bounds__(256) void tn_slab_reduce_kernel(const float* slab, int parts, int M, int N, long ldc, float* Cf) {
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;      // one float4 per thread
+  const long total4 = (long)M * N / 4;
+  if (i4 >= total4) return;
+  const long MN = (long)M * N;
+  f32x4 s4 = *(const f32x4*)(slab + i4 * 4);
+  for (int q = 1; q < parts; ++q) {
+    const f32x4 v = *(const f32x4*)(slab + q * MN + i4 * 4);
+    s4[0] += v[0]; s4[1] += v[1]; s4[2] += v[2]; s4[3] += v[3];
+  }
+  const long e = i4 * 4, row = e / N, col = e - row * N;
+  float* dst = Cf + row * ldc + col;
+  f32x4 o = *(f32x4*)dst;
+  o[0] += s4[0]; o[1] += s4[1]; o[2] += s4[2]; o[3] += s4[3];
+  *(f32x4*)dst = o;
 }
 
 // Launch-level profiling hooks (bench.py "roofline"): every stride-th GEMM launch is bracketed by a
@@ -916,8 +941,19 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
       splits = (d.K + ks - 1) / ks;
       p.k_split = ks; p.n_split = splits;
       dim3 grid((d.N + 127) / 128, (d.M + 255) / 256, splits * nb);
+      const int parts = splits * nb;
+      const bool slab = d.ws && d.ws_bytes >= (int64_t)parts * d.M * d.N * 4 && parts > 1 && (d.ldc % 4) == 0 &&
+                        ((uintptr_t)d.ws % 16) == 0 && ((uintptr_t)d.Cf % 16) == 0;
       hipEvent_t pe = prof_begin(s);
-      hipLaunchKernelGGL(gemm_tn_lc_kernel, grid, dim3(768), 0, s, p);
+      if (slab) {
+        p.slab = (float*)d.ws;
+        hipLaunchKernelGGL(gemm_tn_lc_kernel<true>, grid, dim3(768), 0, s, p);
+        const long total4 = (long)d.M * d.N / 4;
+        hipLaunchKernelGGL(tn_slab_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, p.slab, parts, d.M,
+                           d.N, (long)d.ldc, d.Cf);
+      } else {
+        hipLaunchKernelGGL(gemm_tn_lc_kernel<false>, grid, dim3(768), 0, s, p);
+      }
       prof_end(pe, 7, 2.0 * d.M * d.N * d.K * nb, s);
       return hip_check(hipGetLastError(), "gemm_tn launch");
     }

@@ -26,8 +26,10 @@ static int lin_dgrad(const void* dy, const void* wt, void* dx, const void* aux, 
   return gemm_nt(d, s);
 }
 // dw[N,K] += dy[R,N]^T x[R,K] ; db[N] += colsum(dy)
-static int lin_wgrad(const void* dy, const void* x, float* dw, float* db, int R, int N, int K, int num_cu, hipStream_t s) {
+static int lin_wgrad(const void* dy, const void* x, float* dw, float* db, int R, int N, int K, int num_cu, hipStream_t s,
+                     void* ws, int64_t ws_bytes) {
   GemmDesc d{};
+  d.ws = ws; d.ws_bytes = ws_bytes;
   d.A = dy; d.B = x; d.Cf = dw;
   d.M = N; d.N = K; d.K = R; d.batch = 1; d.lda = N; d.ldb = K; d.ldc = K; d.alpha = 1.f;
   d.colsum = db;  // bias gradient rides along in the wgrad GEMM's A-tile staging
@@ -96,11 +98,11 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   b2.ws = L.ws_f; b2.ws_bytes = (int64_t)R * F * 2;   // ws_f is not live yet: dgamma/dbeta partial slab
   TRY(ln_bwd(b2, s));
   // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
-  TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, cu, s));
+  TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w2, L.wt_scratch, E, F, 1, s));           // [E,F] -> [F,E]
   TRY(lin_dgrad(L.ws_e0, pre_t ? L.w2_t : L.wt_scratch, L.ws_f, L.hpre, R, E, F, EPI_DGELU, s));
   // fc1: wgrad, bias, dgrad + residual branch -> d_x1 (ws_e2)
-  TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, cu, s));
+  TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));           // [F,E] -> [E,F]
   TRY(lin_dgrad(L.ws_f, pre_t ? L.w1_t : L.wt_scratch, L.ws_e2, L.ws_e1, R, F, E, EPI_ADD, s));
   // LN1 backward: d_a = ds1 o dropmask (ws_e0), d_xin_a = ds1 (ws_e1)
@@ -111,7 +113,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   b1.ws = L.ws_f; b1.ws_bytes = (int64_t)R * F * 2;   // fc1's wgrad/dgrad (enqueued above) were its last readers
   TRY(ln_bwd(b1, s));
   // out_proj
-  TRY(lin_wgrad(L.ws_e0, L.ctx, L.g_wo, L.g_bo, R, E, E, cu, s));
+  TRY(lin_wgrad(L.ws_e0, L.ctx, L.g_wo, L.g_bo, R, E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wo, L.wt_scratch, E, E, 1, s));
   TRY(lin_dgrad(L.ws_e0, pre_t ? L.wo_t : L.wt_scratch, L.ws_e2, nullptr, R, E, E, EPI_NONE, s));   // d_ctx
   // attention
@@ -122,7 +124,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   a.dq = L.ws_qkv; a.dk = (char*)L.ws_qkv + E2; a.dv = (char*)L.ws_qkv + 2 * E2;
   TRY(attn_bwd(a, s));
   // fused QKV projection
-  TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s));
+  TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wqkv, L.wt_scratch, 3 * E, E, 1, s));     // [3E,E] -> [E,3E]
   TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, L.ws_e1, R, 3 * E, E, EPI_ADD, s));
   return 0;

@@ -537,6 +537,9 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 items += [(d.wqkv, d.wqkv_t, 3 * E, E), (d.wo, d.wo_t, E, E), (d.w1, d.w1_t, F, E), (d.w2, d.w2_t, E, F)]
             ops.transpose_multi(items)
             st._wt_all = wt_all
+            tn_ws = ops.tn_workspace(dev)
+            for rec in st.layers:
+                rec["desc"].tn_ws, rec["desc"].tn_ws_bytes = tn_ws.data_ptr(), tn_ws.numel() * 4
             for jj, rec in enumerate(reversed(st.layers)):
                 li = rec["li"]
                 pre = f"encoder.layers.{li}."

@@ -156,6 +156,18 @@ def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, 
     GEMM_TIMER.end(ev, epi, 2.0 * M * N * K * batch)
 
 
+_TN_WS = {}
+
+
+def tn_workspace(device):
+    """One persistent 36 MB scratch per device for the split-K partial tiles of the weight-gradient GEMMs (launches
+    on a stream are ordered, so every wgrad of a step can share it)."""
+    key = str(device)
+    if key not in _TN_WS:
+        _TN_WS[key] = torch.empty(9 * 1024 * 1024, dtype=torch.float32, device=device)
+    return _TN_WS[key]
+
+
 def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB=0, a_bytes=0, b_bytes=0,
             alpha=1.0, num_cu=256, colsum_out=None):
     d = GemmDesc()
@@ -166,6 +178,8 @@ def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB
     d.a_bytes, d.b_bytes = a_bytes, b_bytes
     d.alpha = alpha
     d.colsum = _p(colsum_out)
+    ws = tn_workspace(a.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     ev = GEMM_TIMER.begin()
     _lib.call("w2vs_gemm_tn", C.byref(d), num_cu, _stream())
     GEMM_TIMER.end(ev, "tn", 2.0 * M * N * K * batch)
