@@ -308,6 +308,13 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
   }
 }
 
+template <int N> __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcnt(N) needs an immediate
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // ---------------------------------------------------------------------------------------------
 // NT with dedicated loader waves: 256 x 128 x 64 tiles, 12 waves per workgroup = 8 consumers (64x64 each, the
 // fragment code of the kernel above) + 4 loaders that do nothing but issue LDS-DMA, one workgroup per CU,
@@ -316,24 +323,26 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
 // buffer_load...lds: the issuing wave is stuck ~100+ cycles per 1-KiB piece), and the two hardly overlap while
 // the SAME waves do both.  A loader wave can sit in the issue queue all the time; the consumers never do.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int NLOAD>
-__global__ __launch_bounds__((8 + NLOAD) * 64) void gemm_nt_lc_kernel(GemmP p) {
-  constexpr int TBM = 256, TBN = 128, NST = 3;
+template <int EPI, int WM, int MI>   // consumers: WM x 2 waves of (16 MI) x 64; tile (WM * MI * 16) x 128
+__global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) {
+  constexpr int NLOAD = 4, NC = 2 * WM;
+  constexpr int TBM = WM * MI * 16, TBN = 128, NST = 3;
   constexpr int A_EL = TBM * BK, B_EL = TBN * BK, STAGE_EL = A_EL + B_EL;   // 48 KiB per stage
-  constexpr int NTHR = (8 + NLOAD) * 64;
-  constexpr int LP = 48 / NLOAD;                                            // pieces per loader wave and stage
+  constexpr int NTHR = (NC + NLOAD) * 64;
+  constexpr int APIECES = TBM / 8, LP = (APIECES + 16) / NLOAD;            // pieces per loader wave and stage
+  static_assert((APIECES + 16) % NLOAD == 0, "pieces must divide over the loaders");
   __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];         // 144 KiB; the epilogue reuses it
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const bool loader = wid >= 8;
-  const int wm = (wid >> 1) & 3, wn = wid & 1;
+  const bool loader = wid >= NC;
+  const int wm = (wid >> 1) % WM, wn = wid & 1;
   int tm_, tn_;
   tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, 4, tm_, tn_);
   const int m0 = tm_ * TBM, n0 = tn_ * TBN;
   const int bz = blockIdx.z;
   const int nk = (p.K + BK - 1) / BK;
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
@@ -343,15 +352,15 @@ __global__ __launch_bounds__((8 + NLOAD) * 64) void gemm_nt_lc_kernel(GemmP p) {
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
     // the stage image is 48 pieces of 8 rows x 128 B (A rows 0..255, then B rows 0..127); loader l takes pieces
     // l, l+NLOAD, ...  Linear LDS image, XOR swizzle on the SOURCE chunk as in the 4-wave kernel.
-    const int lw = wid - 8;
+    const int lw = wid - NC;
     uint32_t d_off[LP];
     int d_c8[LP];
     bool d_ok[LP];
 #pragma unroll
     for (int j = 0; j < LP; ++j) {
       const int piece = lw + NLOAD * j;              // 0..47
-      const bool isA = piece < 32;
-      const int row = (isA ? piece : piece - 32) * 8 + (lane >> 3);
+      const bool isA = piece < APIECES;
+      const int row = (isA ? piece : piece - APIECES) * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
       d_c8[j] = c * 8;
       if (isA) {
@@ -369,20 +378,20 @@ __global__ __launch_bounds__((8 + NLOAD) * 64) void gemm_nt_lc_kernel(GemmP p) {
         const int piece = lw + NLOAD * j;
         const bool kok = kt < nk && (kt * BK + d_c8[j]) < p.K;
         const uint32_t o = (kok && d_ok[j]) ? d_off[j] + (uint32_t)(kt * BK * 2) : 0xFFFFFFF0u;
-        bf16* dst = sbase + piece * 8 * 64;          // A pieces 0..31 fill [0, A_EL), B pieces follow
-        if (piece < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+        bf16* dst = sbase + piece * 8 * 64;          // the A pieces fill [0, A_EL), the B pieces follow
+        if (piece < APIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
       }
     };
     dma_issue(0, 0);
     dma_issue(1, 1);
-    if (LP == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile 0 landed
+    wait_vm<LP>();   // tile 0 landed
     __builtin_amdgcn_s_barrier();
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
       const int pre = stage == 0 ? 2 : stage - 1;        // (stage + 2) % 3: free since the last barrier
       dma_issue(kt + 2, pre);
-      if (LP == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt+1 landed; kt+2 in flight
+      wait_vm<LP>();  // tile kt+1 landed; kt+2 in flight
       __builtin_amdgcn_s_barrier();
       stage = stage == 2 ? 0 : stage + 1;
     }
@@ -395,13 +404,13 @@ __global__ __launch_bounds__((8 + NLOAD) * 64) void gemm_nt_lc_kernel(GemmP p) {
       const bf16* sb = sa + A_EL;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[4], bfr[4];
+        bf16x8 af[MI], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + swz(wm * 64 + i * 16 + fr, ks * 4 + fq));
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + swz(wm * (MI * 16) + i * 16 + fr, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + swz(wn * 64 + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
@@ -418,18 +427,18 @@ __global__ __launch_bounds__((8 + NLOAD) * 64) void gemm_nt_lc_kernel(GemmP p) {
     if (loader) return;
     float* Cf = p.Cf + (long)bz * p.sC;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
+          int row = m0 + wm * (MI * 16) + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
           if (row < p.M && col < p.N) Cf[(long)row * p.ldc + col] = acc[i][j][r] * p.alpha;
         }
     return;
   }
   constexpr int CP = 136;
-  bf16* st = lds;                 // 256*136*2 = 69632 B
+  bf16* st = lds;                 // TBM * 136 * 2 bytes (69632 for 256 rows)
   bf16* st2 = lds + TBM * CP;     // pre-activation tile
   if (!loader) {
 #pragma unroll
@@ -439,10 +448,10 @@ __global__ __launch_bounds__((8 + NLOAD) * 64) void gemm_nt_lc_kernel(GemmP p) {
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE)
         if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int lr = wm * 64 + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
+          int lr = wm * (MI * 16) + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
           float v = acc[i][j][r] + bv;
           if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
             if (EPI == EPI_BIAS_GELU_SAVE) {
@@ -875,22 +884,34 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   // measured on MI355X: LDS-DMA staging wins on encoder-sized grids (+8..15 % on the N=768 and QKV shapes),
   // the register-staged 3-blocks-per-CU form on the very large conv grids (+5..8 %)
   int mode = ntiles >= 1500 ? 1 : 2;
-  const dim3 grid8((d.N + 127) / 128, (d.M + 255) / 256, d.batch > 0 ? d.batch : 1);
+  // loader/consumer kernel (one workgroup per CU, tile height 256 / 192 / 160) against the 128x128 kernel (two per
+  // CU): time = rounds x (K tiles x time per K tile + fixed), constants fitted to rocprofv3 timings of the encoder
+  // shapes: 0.47 us + 2.8 us for 128^2; for the loader/consumer form the K tile is LDS-DMA bound at ~70 GB/s per
+  // CU (0.74 / 0.71 / 0.62 us per K tile) with 7.5 us fixed.  It wins where the 128^2 grid
+  // leaves a ragged second round and K is long (fc2 forward, fc1 / QKV dgrad: -15..25 %); the lower heights put
+  // 210 / 246 instead of 156 workgroups on the 256 CUs for the N = 768 outputs.
+  int lc_h = 256;
   if (mode == 2) {
-    // loader/consumer 256x128 kernel (one workgroup per CU) against the 128x128 kernel (two per CU): time =
-    // rounds x (K tiles x time per K tile + fixed), constants fitted to rocprofv3 timings of the encoder shapes
-    // (0.47 us and 2.8 us for 128^2, 0.72 us and 7.5 us for 256x128).  It wins where the 128^2 grid leaves a ragged
-    // second round and K is long: fc2 forward, fc1 / QKV dgrad (-15..20 %).
     const double nkt = (d.K + BK - 1) / BK;
-    const double t2 = (double)((ntiles + 255) / 256) * (nkt * 0.47 + 2.8);
-    const long tiles8 = (long)grid8.x * grid8.y * grid8.z;
-    const double t3 = (double)((tiles8 + 255) / 256) * (nkt * 0.72 + 7.5 + (d.epi == EPI_BIAS_GELU_SAVE ? 4.0 : 0.0));
-    if (t3 < 0.95 * t2) mode = 3;
+    const long nbz = d.batch > 0 ? d.batch : 1;
+    double best = 0.95 * (double)((ntiles + 255) / 256) * (nkt * 0.47 + 2.8);
+    const int hs[3] = {256, 192, 160};
+    const double tk[3] = {0.74, 0.71, 0.62};   // measured: not proportional to the bytes - with more CUs busy the shared L2 paces them
+    for (int c = 0; c < 3; ++c) {
+      const long t8 = (long)((d.N + 127) / 128) * ((d.M + hs[c] - 1) / hs[c]) * nbz;
+      const double t = (double)((t8 + 255) / 256) * (nkt * tk[c] + 7.5 + (d.epi == EPI_BIAS_GELU_SAVE ? 4.0 : 0.0));
+      if (t < best) { best = t; mode = 3; lc_h = hs[c]; }
+    }
   }
   if (mode_env >= 0) mode = mode_env;
+  static const int lc_env = [] { const char* e = getenv("W2VS_LC_H"); return e ? atoi(e) : 0; }();
+  if (lc_env > 0) lc_h = lc_env;
+  const dim3 grid8((d.N + 127) / 128, (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
-    if (mode == 3) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4>), grid8, dim3(768), 0, s, p); \
+    if (mode == 3 && lc_h == 256) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4, 4>), grid8, dim3(768), 0, s, p); \
+    else if (mode == 3 && lc_h == 192) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 3, 4>), grid8, dim3(640), 0, s, p); \
+    else if (mode == 3) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 2, 5>), grid8, dim3(512), 0, s, p); \
     else if (mode == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, s, p);     \
     else if (mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, s, p);     \
     else hipLaunchKernelGGL((gemm_nt_kernel<E, 0>), grid, block, 0, s, p);                    \
