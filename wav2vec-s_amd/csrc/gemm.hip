@@ -661,10 +661,26 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool loader = wid >= 8;
   const int wm = (wid >> 1) & 3, wn = wid & 1;
-  int tm_, tn_;
-  tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, 4, tm_, tn_);
+  // XCD-aware order over the WHOLE 3-D grid: workgroups are dealt to the 8 XCDs round-robin in dispatch order
+  // (x fastest, then y, then z); every XCD gets one contiguous run of (K-split, tile) pairs, K-split major and
+  // tiles in group-M order, i.e. a few M tiles x all N tiles of one token range.  With the per-plane order the
+  // three planes of an encoder wgrad put three different token ranges on every XCD and the kernel fetched 3.2x
+  // its algorithmic bytes (rocprofv3 FETCH_SIZE: 199 MB per launch, ~5 TB/s of fabric traffic).
+  int tm_, tn_, zz;
+  {
+    const int plane = gridDim.x * gridDim.y, nwg = plane * gridDim.z;
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = lin & 7;
+    const int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (lin >> 3);
+    zz = id / plane;
+    const int t = id - zz * plane, ntm = gridDim.y, ntn = gridDim.x, GM = 4;
+    const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
+    const int gsz = min(ntm - first_m, GM), in_group = t - group * per_group;
+    tm_ = first_m + in_group % gsz;
+    tn_ = in_group / gsz;
+  }
   const int m0 = tm_ * 256, n0 = tn_ * 128;
-  const int bz = blockIdx.z / p.n_split, sp = blockIdx.z % p.n_split;
+  const int bz = zz / p.n_split, sp = zz % p.n_split;
   const int k_begin = sp * p.k_split;
   const int k_end = min(p.K, k_begin + p.k_split);
   if (!SLAB && k_begin >= k_end) return;             // block-uniform (the host sizes splits so that none is empty)
@@ -774,7 +790,7 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
         if (row < p.M && col < p.N) {
           // a workgroup's 128 KiB of atomics drain at ~one wave-instruction per 50 ns per CU (25 us, as long as the
           // whole K loop of an encoder wgrad); plain stores of the partial tile + a summing launch cost a third
-          if (SLAB) p.slab[((long)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r] * p.alpha;
+          if (SLAB) p.slab[((long)zz * p.M + row) * p.N + col] = acc[i][j][r] * p.alpha;
           else atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
         }
       }
