@@ -991,7 +991,7 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
       } else {
         hipLaunchKernelGGL(gemm_tn_lc_kernel<false>, grid, dim3(768), 0, s, p);
       }
-      prof_end(pe, 7, 2.0 * d.M * d.N * d.K * nb, s);
+      prof_end(pe, 8, 2.0 * d.M * d.N * d.K * nb, s);   // id 8: loader/consumer form (+ its summing launch)
       return hip_check(hipGetLastError(), "gemm_tn launch");
     }
   }

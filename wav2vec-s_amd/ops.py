@@ -116,7 +116,8 @@ class _GemmTimer:
         torch.cuda.synchronize()
         names = {0: "gemm_nt_kernel<none>", 1: "gemm_nt_kernel<bias>", 2: "gemm_nt_kernel<bias_gelu>",
                  3: "gemm_nt_kernel<bias_gelu_save>", 4: "gemm_nt_kernel<dgelu>", 5: "gemm_nt_kernel<f32>",
-                 6: "gemm_nt_kernel<add>", 7: "gemm_tn_kernel"}
+                 6: "gemm_nt_kernel<add>", 7: "gemm_tn_kernel",
+                 8: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)"}
         groups = {}
         for k in names:
             ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
@@ -131,11 +132,12 @@ class _GemmTimer:
         out = {"bound": "mfma", "kernel": names[k], "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s",
                "frac": round(ach / peak_tflops, 4), "traffic": None, "launches_timed": n,
                "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": round(fl / n / 1e9, 3)}
-        nt = [g for kk, g in groups.items() if kk != 7]
+        nt = [g for kk, g in groups.items() if kk < 7]
         if nt:
             out["all_gemm_nt_tflops"] = round(sum(g[1] for g in nt) / sum(g[0] for g in nt) / 1e12, 1)
-        if 7 in groups:
-            out["gemm_tn_tflops"] = round(groups[7][1] / groups[7][0] / 1e12, 1)
+        tn = [g for kk, g in groups.items() if kk >= 7]
+        if tn:
+            out["all_gemm_tn_tflops"] = round(sum(g[1] for g in tn) / sum(g[0] for g in tn) / 1e12, 1)
         return out
 
 
