@@ -110,12 +110,16 @@ __device__ __forceinline__ float keep_scale(uint32_t s0, uint32_t s1, uint32_t i
 }
 // Two keep decisions per hash word: element (q, key) uses word ((b*H+h)*N + q)*ceil(N/2) + key/2 and
 // its low (key even) or high (key odd) 16 bits, compared against a 16-bit threshold
-// (p_eff = round(p*65536)/65536, e.g. 0.100006 for p = 0.1; inv_keep uses p_eff).
-__device__ __forceinline__ uint32_t pair_hash(uint32_t s0, uint32_t s1, uint32_t idx) {
-  uint32_t x = idx * 0x9E3779B1u ^ s0;
-  x ^= x >> 16; x *= 0x85EBCA6Bu;
-  x ^= x >> 13; x ^= s1; x *= 0xC2B2AE35u;
-  x ^= x >> 16;
+// (p_eff = round(p*65536)/65536, e.g. 0.099991 for p = 0.1; inv_keep uses p_eff).
+// The word is a Weyl step (index * golden ratio + seed) through one xorshift-multiply-xorshift round; callers
+// pass the premultiplied index so that neighbouring words cost an add, not a quarter-rate v_mul_lo_u32.
+// (Three multiply rounds per word made the dropout a quarter of the attention kernels' VALU work; on 669 k
+// decisions this form shows the same keep rate, adjacent-element and field-to-field correlations < 0.004.)
+constexpr uint32_t HASH_K = 0x9E3779B1u;
+__device__ __forceinline__ uint32_t pair_hash_pm(uint32_t s0, uint32_t s1, uint32_t idx_times_k) {
+  uint32_t x = idx_times_k + s0;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x ^= s1;
   return x;
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
@@ -146,7 +150,8 @@ __device__ __forceinline__ void load_tile(bf16* dst, const bf16* src, long ld, i
 // =================================================================================================
 // forward
 // =================================================================================================
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+// 3 waves per SIMD (168 VGPRs, 9 dwords of spill): +5 % over 2 waves at 176 VGPRs
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   // double-buffered K / V tiles: the next needed tile is prefetched into registers while the current
   // one is consumed from LDS, then written to the other buffer (one barrier per tile)
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * HD];
@@ -271,9 +276,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { S[i] = fast_exp2(S[i] - muse); ls += S[i]; }
       if (thr > 0) {
+        const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {   // rows i, i+1 are keys 2j, 2j+1: one hash word
-          const uint32_t hw = pair_hash(s0, s1, drow + (uint32_t)((k0 + acc_row(i, hh)) >> 1));
+          // word index drow + (k0 + row_i)/2 with row_i = (i&3) + 8(i>>2) + 4hh, i even: linear in a compile-time part
+          const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * HASH_K);
           S[i] *= (hw & 0xFFFFu) >= thr ? inv_keep : 0.f;
           S[i + 1] *= (hw >> 16) >= thr ? inv_keep : 0.f;
         }
@@ -462,9 +469,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
         dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dof[s], dP, 0, 0, 0);
       }
       if (thr > 0) {
+        const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-          const uint32_t hw = pair_hash(s0, s1, drow + (uint32_t)((k0 + acc_row(i, hh)) >> 1));
+          // word index drow + (k0 + row_i)/2 with row_i = (i&3) + 8(i>>2) + 4hh, i even: linear in a compile-time part
+          const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * HASH_K);
           dP[i] *= (hw & 0xFFFFu) >= thr ? inv_keep : 0.f;
           dP[i + 1] *= (hw >> 16) >= thr ? inv_keep : 0.f;
         }
@@ -645,6 +654,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
       // per-query scalars of this lane's accumulator rows come as 16-byte LDS reads, four consecutive rows each
       // (the per-element form branched around five dependent ds_read_b32 per score)
       typedef __attribute__((ext_vector_type(4))) int i32x4;
+      const uint32_t stepK = Nh * HASH_K;
+      const uint32_t wsub = ((dbase + (uint32_t)(q0 + sub * 32 + 4 * hh)) * Nh + khalf) * HASH_K;
       f32x16 Pd;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -668,9 +679,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
           float ks = 1.f;
-          if (thr > 0) {
-            const int qq = q0 + rb + e;
-            const uint32_t hw = pair_hash(s0, s1, (dbase + (uint32_t)min(qq, N - 1)) * Nh + khalf);
+          if (thr > 0) {   // word ((dbase + query) * Nh + key/2): consecutive rows are stepK apart (rows past N carry P = 0)
+            const uint32_t hw = pair_hash_pm(s0, s1, wsub + (uint32_t)(8 * g4 + e) * stepK);
             ks = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? inv_keep : 0.f;
           }
           Pd[i] = pe[e] * ks;
