@@ -209,6 +209,8 @@ typedef struct w2vs_nce_desc {
   const float* dlogits; void* dx; void* dy;   /* bwd: dx, dy bf16 [B*M, C] */
   float* dy_ws;                      /* optional fp32 [B*M, C] scratch: lets bwd split rows over more blocks */
   int32_t B, M, K, C; float temp;
+  void* ws; int64_t ws_bytes;        /* optional scratch, >= 4*B*Mp*(Mp + 2*C + 2) bytes with Mp = M rounded up to 64: bwd then
+                                        runs as two small matrix products per utterance instead of an LDS-atomic scatter */
 } w2vs_nce_desc;
 int w2vs_nce_fwd(const w2vs_nce_desc* d, void* stream);
 int w2vs_nce_bwd(const w2vs_nce_desc* d, void* stream);

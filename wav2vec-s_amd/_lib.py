@@ -59,7 +59,7 @@ class QuantDesc(C.Structure):
 class NceDesc(C.Structure):
     _fields_ = [("x", vp), ("y", vp), ("neg_idx", vp), ("logits", vp), ("xn", vp), ("yn", vp), ("dlogits", vp),
                 ("dx", vp), ("dy", vp), ("dy_ws", vp),
-                ("B", i32), ("M", i32), ("K", i32), ("C", i32), ("temp", f32)]
+                ("B", i32), ("M", i32), ("K", i32), ("C", i32), ("temp", f32), ("ws", vp), ("ws_bytes", i64)]
 
 
 class TransposeItem(C.Structure):

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
-        if (row < p.M && col < p.N) atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
+        if (row < p.M && col < p.N) atomicAdd(&p.Cf[(long)bz * p.sC + (long)row * p.ldc + col], acc[i][j][r] * p.alpha);
       }
   if (do_colsum) {
     // 16 threads (tid>>4) share a column chunk cc = tid&15: each parks its 8 sums in its own LDS row, 128 threads
@@ -960,14 +960,14 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_tn: operand extent must be < 2 GiB per batch");
   p.a_bytes = (uint32_t)a_ext; p.b_bytes = (uint32_t)b_ext;
   const int nb = d.batch > 0 ? d.batch : 1;
-  p.sA = d.sA; p.sB = d.sB;
+  p.sA = d.sA; p.sB = d.sB; p.sC = d.sC;   // sC: batch stride of Cf (0 = every batch adds into the same matrix)
   // loader/consumer form (256x128 tiles, one workgroup per CU) when its grid can fill the chip with at most ~1
   // workgroup per CU and each keeps a long K loop; small outputs (out_proj) stay on the 128x128 kernel
   static const int tn_lc_env = [] { const char* e = getenv("W2VS_TN_LC"); return e ? atoi(e) : -1; }();
   {
     const int tiles8 = ((d.N + 127) / 128) * ((d.M + 255) / 256) * nb;
     const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
-    bool use_lc = tiles8 >= 24 && tiles8 <= ncu;
+    bool use_lc = tiles8 >= 24 && tiles8 <= ncu && d.sC == 0;
     if (tn_lc_env >= 0) use_lc = tn_lc_env != 0;
     if (use_lc) {
       int splits = std::max(1, ncu / tiles8);

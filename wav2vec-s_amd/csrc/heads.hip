@@ -4,6 +4,7 @@
 //   gumbel_quantize   a14  fs/modules/gumbel_vector_quantizer.py:141-202
 //   infonce_logits    a16 gather + a17 compute_preds   fs/models/wav2vec/wav2vec2.py:521-542
 //   ce_rows           a19  fs/criterions/wav2vec_criterion.py:64-68, 133-155
+#include <stdlib.h>
 #include "common.h"
 #include "w2vs_internal.h"
 
@@ -435,10 +436,126 @@ int nce_fwd(const NceDesc& d, hipStream_t st) {
   return hip_check(hipGetLastError(), "infonce_fwd");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense form of the backward (used when the caller hands over a workspace).  Per utterance the targets of all
+// (query i, slot k) pairs are folded into a coefficient matrix A[i][t] = sum of g/(|x_i||y_t|) over the slots of i
+// that point at t (negatives are sampled with replacement: ~20 repeats per row), and
+//     dX = A . Y - diag(sbx) X          dY = A^T . X - diag(Bv) Y
+// are two small matrix products per utterance on the existing TN GEMM (A and A^T are both written, bf16, so each
+// product finds its contraction index on the rows).  The scatter form below issues 820 k LDS float atomics
+// (~130 cycles each on gfx950): 264 us; this form: a 2-atomics-per-row build + two batched GEMMs + a finish pass.
+// ---------------------------------------------------------------------------------------------
+struct NceDenseP {
+  NceP n;
+  bf16* A; bf16* AT;          // [B][Mp][Mp]
+  float* Bv; float* sbx;      // [B][Mp]
+  float* dxw; float* dyw;     // [B][Mp][C]
+  int Mp;
+};
+
+// grid (Mp/16, B), 1024 threads: wave w owns query row i = 16*blockIdx.x + w
+__global__ __launch_bounds__(1024) void nce_coef_kernel(NceDenseP q) {
+  extern __shared__ float rowbuf[];                 // [16][Mp + 1]
+  const NceP& p = q.n;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.y, i0 = blockIdx.x * 16, i = i0 + w;
+  const int M = p.M, K = p.K, Mp = q.Mp, pitch = Mp + 1;
+  const float temp = 1.f / p.inv_temp;
+  for (int j = threadIdx.x; j < 16 * pitch; j += 1024) rowbuf[j] = 0.f;
+  __syncthreads();
+  if (i < M) {
+    const long row = (long)b * M + i;
+    const float xn = p.xn[row];
+    const float* lg = p.logits + row * (K + 1);
+    const float* dl = p.dlogits + row * (K + 1);
+    const long long* ng = p.neg + (long)b * K * M + (long)i * K;
+    float sbx = 0.f;
+    for (int k = lane; k <= K; k += 64) {
+      const float lv = lg[k];
+      const float g = (lv == -INFINITY) ? 0.f : dl[k] * p.inv_temp;
+      if (g != 0.f) {
+        const int t = (k == 0) ? i : (int)(ng[k - 1] - (long long)b * M);
+        const float cosv = lv * temp, tn = p.yn[(long)b * M + t];
+        atomicAdd(&rowbuf[w * pitch + t], g / (xn * tn));          // repeats of t inside this row fold here
+        atomicAdd(&q.Bv[(long)b * Mp + t], g * cosv / (tn * tn));
+        sbx += g * cosv / (xn * xn);
+      }
+    }
+    sbx = wave_sum(sbx);
+    if (lane == 0) q.sbx[(long)b * Mp + i] = sbx;
+  }
+  __syncthreads();
+  // A rows (zero rows past M keep the padded products clean) and the 16-column strip of A^T
+  bf16* Ar = q.A + ((long)b * Mp + i) * Mp;
+  for (int t = lane; t < Mp; t += 64) Ar[t] = f2bf(rowbuf[w * pitch + t]);
+  for (int j = threadIdx.x; j < 16 * Mp; j += 1024) {
+    const int w2 = j & 15, t = j >> 4;
+    q.AT[((long)b * Mp + t) * Mp + i0 + w2] = f2bf(rowbuf[w2 * pitch + t]);
+  }
+}
+
+// dx = bf16(dxw - sbx * x), dy = bf16(dyw - Bv * y); one thread per 8 channels
+__global__ __launch_bounds__(256) void nce_finish_kernel(NceDenseP q) {
+  const NceP& p = q.n;
+  const int C8 = p.C >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.B * p.M * C8;
+  if (idx >= total) return;
+  const int c8 = (int)(idx % C8);
+  const long row = idx / C8;
+  const int b = (int)(row / p.M), i = (int)(row - (long)b * p.M);
+  const float sb = q.sbx[(long)b * q.Mp + i], bv = q.Bv[(long)b * q.Mp + i];
+  const float* dxw = q.dxw + ((long)b * q.Mp + i) * p.C + c8 * 8;
+  const float* dyw = q.dyw + ((long)b * q.Mp + i) * p.C + c8 * 8;
+  const bf16x8 xv = *(const bf16x8*)(p.x + row * p.C + c8 * 8), yv = *(const bf16x8*)(p.y + row * p.C + c8 * 8);
+  bf16x8 ox, oy;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ox[e] = f2bf(dxw[e] - sb * bf2f(xv[e]));
+    oy[e] = f2bf(dyw[e] - bv * bf2f(yv[e]));
+  }
+  *(bf16x8*)(p.dx + row * p.C + c8 * 8) = ox;
+  *(bf16x8*)(p.dy + row * p.C + c8 * 8) = oy;
+}
+
+static int nce_bwd_dense(const NceDesc& d, const NceP& p, hipStream_t st) {
+  NceDenseP q{};
+  q.n = p;
+  const int Mp = (p.M + 63) / 64 * 64;
+  q.Mp = Mp;
+  const long nA = (long)p.B * Mp * Mp, nW = (long)p.B * Mp * p.C, nV = (long)p.B * Mp;
+  char* w = (char*)d.ws;
+  q.dxw = (float*)w; q.dyw = q.dxw + nW; q.Bv = q.dyw + nW; q.sbx = q.Bv + nV;     // fp32 part first (one memset)
+  q.A = (bf16*)(q.sbx + nV); q.AT = q.A + nA;
+  if (int e = hip_check(hipMemsetAsync(q.dxw, 0, sizeof(float) * (2 * nW + nV), st), "memset")) return e;
+  const size_t lds = (size_t)16 * (Mp + 1) * sizeof(float);
+  hipLaunchKernelGGL(nce_coef_kernel, dim3(Mp / 16, p.B), dim3(1024), lds, st, q);
+  if (int e = hip_check(hipGetLastError(), "infonce_bwd coef")) return e;
+  GemmDesc g{};
+  g.M = Mp; g.N = p.C; g.K = p.M; g.batch = p.B; g.lda = Mp; g.ldb = p.C; g.ldc = p.C; g.alpha = 1.f;
+  g.sA = (long)Mp * Mp; g.sB = (long)p.M * p.C; g.sC = (long)Mp * p.C;
+  g.a_bytes = (long)Mp * Mp * 2; g.b_bytes = (long)p.M * p.C * 2;
+  g.A = q.A; g.B = p.x; g.Cf = q.dyw;                      // dY = A^T X : contraction over query rows i
+  if (int e = gemm_tn(g, 0, st)) return e;
+  g.A = q.AT; g.B = p.y; g.Cf = q.dxw;                     // dX = A Y   : contraction over target rows t
+  if (int e = gemm_tn(g, 0, st)) return e;
+  const long total = (long)p.B * p.M * (p.C / 8);
+  hipLaunchKernelGGL(nce_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, q);
+  return hip_check(hipGetLastError(), "infonce_bwd finish");
+}
+
 int nce_bwd(const NceDesc& d, hipStream_t st) {
   NceP p{};
   if (int e = nce_fill(d, p)) return e;
   if (!p.dlogits || !p.dx || !p.dy || !p.logits) return set_error("infonce_bwd: null pointer");
+  {
+    const long Mp = (p.M + 63) / 64 * 64;
+    const long need = 4L * p.B * Mp * (2L * p.C + 2) + 2L * 2 * p.B * Mp * Mp;
+    static const int dense_env = [] { const char* e = getenv("W2VS_NCE_DENSE"); return e ? atoi(e) : -1; }();
+    bool dense = d.ws && d.ws_bytes >= need && ((uintptr_t)d.ws % 16) == 0 && Mp <= 1024 && (p.C % 8) == 0;
+    if (dense_env == 0) dense = false;
+    if (dense) return nce_bwd_dense(d, p, st);
+  }
   // widest channel slice whose [M][cw] fp32 accumulator fits in LDS (keep 16 KiB headroom)
   int cw = 0;
   for (int c = 64; c >= 64; c -= 64)   // 64-wide slices: C/64 x B blocks keep more CUs busy than wider ones

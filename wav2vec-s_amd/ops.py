@@ -554,6 +554,9 @@ def nce_bwd(dlogits, logits, norms, x, y, neg_idx, B, M, K, temp):
     d.x, d.y, d.neg_idx, d.logits, d.dlogits, d.dx, d.dy = _p(x), _p(y), _p(neg_idx), _p(logits), _p(dlogits), _p(dx), _p(dy)
     ws = empty((B * M, Cc), torch.float32, x.device)
     d.dy_ws = _p(ws)
+    Mp = (M + 63) // 64 * 64
+    ws2 = empty((B * Mp * (Mp + 2 * Cc + 2),), torch.float32, x.device)
+    d.ws, d.ws_bytes = _p(ws2), ws2.numel() * 4
     d.xn, d.yn = _p(norms[0]), _p(norms[1])
     d.B, d.M, d.K, d.C, d.temp = B, M, K, Cc, temp
     _lib.call("w2vs_nce_bwd", C.byref(d), _stream())
