@@ -352,7 +352,7 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) 
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
     // the stage image is 48 pieces of 8 rows x 128 B (A rows 0..255, then B rows 0..127); loader l takes pieces
     // l, l+NLOAD, ...  Linear LDS image, XOR swizzle on the SOURCE chunk as in the 4-wave kernel.
-    const int lw = wid - NC;
+    const int lw = (wid - NC) & 3;   // the mask tells the compiler the range: which pieces are A / B becomes static
     uint32_t d_off[LP];
     int d_c8[LP];
     bool d_ok[LP];
@@ -489,6 +489,198 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) 
       } else {
         *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
         if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT, PERSISTENT loader/consumer: the kernel above as a loop over output tiles.  One workgroup per CU walks
+// tiles g, g+G, g+2G, ...; the LDS-DMA ring simply keeps running across tile boundaries, so while the consumers
+// write a finished tile out the loaders already fetch the first K tiles of the next one, and the per-tile
+// fixed cost (launch, two K tiles of cold-start latency, an LDS-staged epilogue: 7.5 us above) shrinks to the
+// store time of the epilogue.  The epilogue needs no LDS (the loaders own it all the time): the MFMA operands are
+// swapped, acc[i][j] = B_frag x A_frag, so a lane holds FOUR CONSECUTIVE output columns of one row and stores
+// them as 8 bytes; the four j tiles of a wave complete a row's 128-byte line.
+// ---------------------------------------------------------------------------------------------
+struct TileIter {   // tiles of one workgroup, in XCD-aware order: round r covers ids [r*G, (r+1)*G), the 32 workgroups
+  int G, slot, total, ntm, ntn;   // of an XCD take a contiguous chunk of it, ids walk group-M inside a batch plane
+  __device__ __forceinline__ bool get(int r, int& bz, int& tm, int& tn) const {
+    const long id = (long)r * G + slot;
+    if (id >= total) return false;
+    const int plane = ntm * ntn;
+    bz = (int)(id / plane);
+    const int t = (int)(id - (long)bz * plane), GM = 4;
+    const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
+    const int gsz = min(ntm - first_m, GM), in_group = t - group * per_group;
+    // workgroup-uniform by construction; say so, or every LDS-DMA gets a waterfall loop around its descriptor
+    bz = __builtin_amdgcn_readfirstlane(bz);
+    tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsz);
+    tn = __builtin_amdgcn_readfirstlane(in_group / gsz);
+    return true;
+  }
+};
+
+template <int EPI, int WM, int MI>
+__global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, int ntm, int ntn, int total_tiles) {
+  constexpr int NLOAD = 4, NC = 2 * WM;
+  constexpr int TBM = WM * MI * 16, TBN = 128, NST = 3;
+  constexpr int A_EL = TBM * BK, B_EL = TBN * BK, STAGE_EL = A_EL + B_EL;
+  constexpr int APIECES = TBM / 8, LP = (APIECES + 16) / NLOAD;
+  static_assert((APIECES + 16) % NLOAD == 0, "pieces must divide over the loaders");
+  __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool loader = wid >= NC;
+  const int wm = (wid >> 1) % WM, wn = wid & 1;
+  const int nk = (p.K + BK - 1) / BK;
+  TileIter it;
+  it.G = gridDim.x; it.total = total_tiles; it.ntm = ntm; it.ntn = ntn;
+  {
+    const int g = blockIdx.x, G = gridDim.x, qd = G >> 3, rm = G & 7, xcd = g & 7;
+    it.slot = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (g >> 3);
+  }
+  if (loader) {
+    const int lw = (wid - NC) & 3;   // the mask tells the compiler the range: which pieces are A / B becomes static
+    // Issues run two K tiles ahead of the consumers: issue I0, then for every further issue {issue; wait until the
+    // previous one has landed; barrier}.  After the last real K tile two out-of-range issues (zeros) keep the
+    // instruction count per step constant for the counted vmcnt.  Plain nested loops over (tile, K tile): the
+    // compiler must see that descriptors and offsets are wave-uniform, or it wraps every DMA in a waterfall loop.
+    int my_tiles = 0;
+    { int b_, m_, n_; while (it.get(my_tiles, b_, m_, n_)) ++my_tiles; }
+    int stage = 0;
+    bool first = true;
+    for (int r = 0; r <= my_tiles; ++r) {            // r == my_tiles: the two trailing dummy issues
+      int bz = 0, tm = 0, tn = 0;
+      const bool live = r < my_tiles && it.get(r, bz, tm, tn);
+      __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long)bz * p.sA, p.a_bytes);
+      __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
+      const int m0 = tm * TBM, n0 = tn * TBN;
+      uint32_t d_off[LP];
+      int d_c8[LP];
+      bool d_ok[LP];
+#pragma unroll
+      for (int j = 0; j < LP; ++j) {
+        const int piece = lw + NLOAD * j;
+        const bool isA = piece < APIECES;
+        const int row = (isA ? piece : piece - APIECES) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        d_c8[j] = c * 8;
+        if (isA) {
+          d_ok[j] = live && m0 + row < p.M;
+          d_off[j] = (uint32_t)((p.a_off + (long)(m0 + row) * p.lda + c * 8) * 2);
+        } else {
+          // B rows are stored PERMUTED: LDS row (w*64 + jj*16 + f) <- B row w*64 + (jj>>1)*32 + (f>>2)*8 + (jj&1)*4 + (f&3),
+          // so that a consumer lane ends up with 8 consecutive output columns in the accumulators of tiles 2u, 2u+1
+          const int f = row & 15, jj = (row >> 4) & 3;
+          const int srow = (row & 64) + (jj >> 1) * 32 + (f >> 2) * 8 + (jj & 1) * 4 + (f & 3);
+          d_ok[j] = live && n0 + srow < p.N;
+          d_off[j] = (uint32_t)(((long)(n0 + srow) * p.ldb + c * 8) * 2);
+        }
+      }
+      const int kts = live ? nk : 2;
+      for (int kt = 0; kt < kts; ++kt) {
+        bf16* sbase = lds + stage * STAGE_EL;
+#pragma unroll
+        for (int j = 0; j < LP; ++j) {
+          const int piece = lw + NLOAD * j;
+          const bool kok = (kt * BK + d_c8[j]) < p.K;
+          const uint32_t o = (kok && d_ok[j]) ? d_off[j] + (uint32_t)(kt * BK * 2) : 0xFFFFFFF0u;
+          bf16* dst = sbase + piece * 8 * 64;
+          if (piece < APIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+        }
+        if (!first) {
+          wait_vm<LP>();                              // the previous issue has landed, this one stays in flight
+          __builtin_amdgcn_s_barrier();
+        }
+        first = false;
+        stage = stage == 2 ? 0 : stage + 1;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // ---- consumers
+  const int fr = lane & 15, fq = lane >> 4;
+  __builtin_amdgcn_s_barrier();
+  int stage = 0;
+  for (int r = 0;; ++r) {
+    int bz, tm, tn;
+    if (!it.get(r, bz, tm, tn)) break;
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      const bf16* sa = lds + stage * STAGE_EL;
+      const bf16* sb = sa + A_EL;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MI], bfr[4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sa + swz(wm * (MI * 16) + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // LDS row j*16 + fr holds output column (j>>1)*32 + (fr>>2)*8 + (j&1)*4 + (fr&3): the loaders permute
+          bfr[j] = *(const bf16x8*)(sb + swz(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)   // operands swapped: the accumulator holds C^T, i.e. 4 consecutive columns per lane
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_barrier();
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    // ---- epilogue straight from the registers: lane (fr, fq) holds row i*16+fr and, from tiles 2u / 2u+1, the
+    // EIGHT consecutive columns u*32 + fq*8 .. +7 (one 16-byte store; dwordx2 stores are issue-bound)
+    const long cbase = (long)bz * p.sC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + wn * 64 + u * 32 + fq * 8;
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+        if (p.bias != nullptr && col < p.N) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[e] = bf2f(p.bias[col + e]);   // N % 8 == 0 (host check)
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = m0 + wm * (MI * 16) + i * 16 + fr;
+        const long o = (long)row * p.ldc + col;
+        if (row >= p.M || col >= p.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * u][e]; v[4 + e] = acc[i][2 * u + 1][e]; }
+        if (EPI == EPI_F32) {
+          *(f32x4*)(p.Cf + cbase + o) = f32x4{v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha};
+          *(f32x4*)(p.Cf + cbase + o + 4) = f32x4{v[4] * p.alpha, v[5] * p.alpha, v[6] * p.alpha, v[7] * p.alpha};
+          continue;
+        }
+        if (o + 8 > p.c_elems) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        bf16x8 o8;
+        if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+          bf16x8 pre;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { pre[e] = f2bf(v[e]); o8[e] = f2bf(gelu_exact(EPI == EPI_BIAS_GELU_SAVE ? bf2f(pre[e]) : v[e])); }
+          if (EPI == EPI_BIAS_GELU_SAVE) *(bf16x8*)(p.C2 + cbase + o) = pre;
+        } else if (EPI == EPI_DGELU) {
+          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * gelu_grad(bf2f(a[e])));
+        } else if (EPI == EPI_ADD) {
+          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) + bf2f(a[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(v[e]);
+        }
+        *(bf16x8*)(p.C + cbase + o) = o8;
       }
     }
   }
@@ -697,7 +889,7 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
     __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A + (long)bz * p.sA, p.a_bytes);
     __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
     // 48 pieces per stage: 16 per image, a piece = 4 k-rows x 256 B; loader l takes pieces l, l+4, ...
-    const int lw = wid - 8;
+    const int lw = (wid - 8) & 3;
     uint32_t d_col[LP];     // byte offset of this lane's 16-B chunk inside its row, or ~0 if the column is out of range
     int d_row[LP];          // k row inside the tile
 #pragma unroll
@@ -900,19 +1092,25 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   // measured on MI355X: LDS-DMA staging wins on encoder-sized grids (+8..15 % on the N=768 and QKV shapes),
   // the register-staged 3-blocks-per-CU form on the very large conv grids (+5..8 %)
   int mode = ntiles >= 1500 ? 1 : 2;
-  // loader/consumer kernel (one workgroup per CU, tile height 256 / 192 / 160) against the 128x128 kernel (two per
-  // CU): time = rounds x (K tiles x time per K tile + fixed), constants fitted to rocprofv3 timings of the encoder
-  // shapes: 0.47 us + 2.8 us for 128^2; for the loader/consumer form the K tile is LDS-DMA bound at ~70 GB/s per
-  // CU (0.74 / 0.71 / 0.62 us per K tile) with 7.5 us fixed.  It wins where the 128^2 grid
-  // leaves a ragged second round and K is long (fc2 forward, fc1 / QKV dgrad: -15..25 %); the lower heights put
-  // 210 / 246 instead of 156 workgroups on the 256 CUs for the N = 768 outputs.
+  // Loader/consumer kernels (one workgroup per CU) against the 128x128 kernels (two / three per CU); time models
+  // fitted to rocprofv3 timings:  128^2: rounds x (K tiles x 0.47 us + 2.8 us);  loader/consumer, tile height
+  // 256 / 192 / 160: rounds x (K tiles x {0.74, 0.71, 0.62} us + 7.5 us) - the K tile is LDS-DMA bound at ~70 GB/s
+  // per CU, and with more CUs busy the shared L2 paces them, so the time is not proportional to the tile bytes.
+  // The lower heights put 210 / 246 instead of 156 workgroups on the 256 CUs for the N = 768 outputs.  On the
+  // huge conv grids the PERSISTENT form (tile loop inside the kernel, 256-row tiles) replaces the register-staged
+  // 3-per-CU kernel; on the encoder shapes it measured 1 % slower end to end than separate workgroups.
   int lc_h = 256;
-  if (mode == 2) {
+  const bool p_ok = (d.N % 8) == 0 && (d.ldc % 8) == 0 && d.epi != EPI_F32 && ((uintptr_t)d.C % 16) == 0 &&
+                    ((uintptr_t)d.C2 % 16) == 0 && ((uintptr_t)d.aux % 16) == 0 && (d.sC % 8) == 0;
+  static const int conv_p_env = [] { const char* e = getenv("W2VS_CONV_PERSIST"); return e ? atoi(e) : 1; }();
+  if (mode == 1 && p_ok && conv_p_env) {
+    mode = 5;
+  } else if (mode == 2) {
     const double nkt = (d.K + BK - 1) / BK;
     const long nbz = d.batch > 0 ? d.batch : 1;
     double best = 0.95 * (double)((ntiles + 255) / 256) * (nkt * 0.47 + 2.8);
     const int hs[3] = {256, 192, 160};
-    const double tk[3] = {0.74, 0.71, 0.62};   // measured: not proportional to the bytes - with more CUs busy the shared L2 paces them
+    const double tk[3] = {0.74, 0.71, 0.62};
     for (int c = 0; c < 3; ++c) {
       const long t8 = (long)((d.N + 127) / 128) * ((d.M + hs[c] - 1) / hs[c]) * nbz;
       const double t = (double)((t8 + 255) / 256) * (nkt * tk[c] + 7.5 + (d.epi == EPI_BIAS_GELU_SAVE ? 4.0 : 0.0));
@@ -925,7 +1123,13 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   const dim3 grid8((d.N + 127) / 128, (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
-    if (mode == 3 && lc_h == 256) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4, 4>), grid8, dim3(768), 0, s, p); \
+    if (mode == 5) {                                                                          \
+      const int ntm_ = grid8.y, ntn_ = grid8.x, tot_ = ntm_ * ntn_ * (int)grid8.z;            \
+      const dim3 gp(std::min(tot_, 256));                                                     \
+      if (lc_h == 256) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 4, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_);      \
+      else if (lc_h == 192) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 3, 4>), gp, dim3(640), 0, s, p, ntm_, ntn_, tot_); \
+      else hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5>), gp, dim3(512), 0, s, p, ntm_, ntn_, tot_);                  \
+    } else if (mode == 3 && lc_h == 256) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4, 4>), grid8, dim3(768), 0, s, p); \
     else if (mode == 3 && lc_h == 192) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 3, 4>), grid8, dim3(640), 0, s, p); \
     else if (mode == 3) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 2, 5>), grid8, dim3(512), 0, s, p); \
     else if (mode == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, s, p);     \
