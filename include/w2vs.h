@@ -226,7 +226,7 @@ int w2vs_ce_rows(const float* logits, int64_t R, int32_t W, float* out3, float* 
 int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, int32_t C, int32_t scatter, void* stream);
 int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* stream);
 /* many independent 2-D transposes in one launch (n <= 64): out[i] [C_i, R_i] = in[i] [R_i, C_i]^T */
-typedef struct w2vs_transpose_item { const void* in; void* out; int32_t R, C; } w2vs_transpose_item;
+typedef struct w2vs_transpose_item { const void* in; void* out; int32_t R, C; int64_t ld_in, ld_out; /* row strides in elements, 0 = dense (C / R) */ } w2vs_transpose_item;
 int w2vs_transpose_multi(const w2vs_transpose_item* items, int32_t n, void* stream);
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* stream);
 /* out[i] = in[i] * keep(seed, i) / (1 - p) : nn.Dropout (dropout_features, wav2vec2.py:571);

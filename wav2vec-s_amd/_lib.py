@@ -63,7 +63,7 @@ class NceDesc(C.Structure):
 
 
 class TransposeItem(C.Structure):
-    _fields_ = [("inp", vp), ("out", vp), ("R", i32), ("C", i32)]
+    _fields_ = [("inp", vp), ("out", vp), ("R", i32), ("C", i32), ("ld_in", i64), ("ld_out", i64)]
 
 
 class LayerDesc(C.Structure):

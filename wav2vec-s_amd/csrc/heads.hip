@@ -691,6 +691,7 @@ int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t 
 struct TrBatch {
   const bf16* in[64]; bf16* out[64];
   int R[64], C[64], tile0[65], tc[64];
+  long ldi[64], ldo[64];
   int n;
 };
 __global__ __launch_bounds__(256) void transpose_multi_kernel(TrBatch b) {
@@ -702,15 +703,16 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(TrBatch b) {
   const int r0 = (local / b.tc[it]) * 64, c0 = (local % b.tc[it]) * 64;
   const bf16* in = b.in[it];
   bf16* out = b.out[it];
+  const long ldi = b.ldi[it], ldo = b.ldo[it];
   const int tid = threadIdx.x;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {       // 64 rows x 8 chunks of 8 elements
     const int ch = tid + 256 * j, rr = ch >> 3, cc = (ch & 7) * 8;
     bf16x8 v;
-    if (r0 + rr < R && c0 + cc + 8 <= C) v = *(const bf16x8*)(in + (long)(r0 + rr) * C + c0 + cc);
+    if (r0 + rr < R && c0 + cc + 8 <= C && (ldi % 8) == 0) v = *(const bf16x8*)(in + (long)(r0 + rr) * ldi + c0 + cc);
     else
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (r0 + rr < R && c0 + cc + e < C) ? in[(long)(r0 + rr) * C + c0 + cc + e] : f2bf(0.f);
+      for (int e = 0; e < 8; ++e) v[e] = (r0 + rr < R && c0 + cc + e < C) ? in[(long)(r0 + rr) * ldi + c0 + cc + e] : f2bf(0.f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) t[rr][cc + e] = v[e];
   }
@@ -722,8 +724,8 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(TrBatch b) {
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = t[rr + e][oc];
-    bf16* dst = out + (long)(c0 + oc) * R + r0 + rr;
-    if (r0 + rr + 8 <= R && (R % 8) == 0) *(bf16x8*)dst = v;
+    bf16* dst = out + (long)(c0 + oc) * ldo + r0 + rr;
+    if (r0 + rr + 8 <= R && (ldo % 8) == 0) *(bf16x8*)dst = v;
     else
 #pragma unroll
       for (int e = 0; e < 8; ++e) if (r0 + rr + e < R) dst[e] = v[e];
@@ -736,6 +738,8 @@ int transpose_multi(const w2vs_transpose_item* items, int n, hipStream_t st) {
   for (int i = 0; i < n; ++i) {
     if (!items[i].in || !items[i].out || items[i].R <= 0 || items[i].C <= 0) return set_error("transpose_multi: bad item");
     b.in[i] = (const bf16*)items[i].in; b.out[i] = (bf16*)items[i].out; b.R[i] = items[i].R; b.C[i] = items[i].C;
+    b.ldi[i] = items[i].ld_in > 0 ? items[i].ld_in : items[i].C;
+    b.ldo[i] = items[i].ld_out > 0 ? items[i].ld_out : items[i].R;
     b.tile0[i] = tiles;
     b.tc[i] = (items[i].C + 63) / 64;
     tiles += b.tc[i] * ((items[i].R + 63) / 64);

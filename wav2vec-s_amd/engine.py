@@ -535,6 +535,12 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 d.wqkv_t, d.wo_t = base, base + 2 * 3 * E * E
                 d.w1_t, d.w2_t = base + 2 * 4 * E * E, base + 2 * (4 * E * E + E * F)
                 items += [(d.wqkv, d.wqkv_t, 3 * E, E), (d.wo, d.wo_t, E, E), (d.w1, d.w1_t, F, E), (d.w2, d.w2_t, E, F)]
+            st._dgrad_w = {}
+            for ci_ in range(1, len(cfg.conv_layers)):        # conv dgrad operands ride in the same launch
+                _, ck, cs = cfg.conv_layers[ci_]
+                buf, its = ops.conv_dgrad_weight_items((id(A), ci_), st.packed[ci_], ck, cs)
+                st._dgrad_w[ci_] = buf
+                items += its
             ops.transpose_multi(items)
             st._wt_all = wt_all
             tn_ws = ops.tn_workspace(dev)
@@ -647,7 +653,8 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                           db_f32=A.view(_pname(i, "0.bias")) if _pname(i, "0.bias") in A else None)
         prev = st.conv[i - 1]
         prev_aux = prev.get("pre") if (i - 1 >= 1 and not prev["ln"]) else None
-        d_cur = ops.conv_cl_dgrad(d_c, st.packed[i], k, s, x_in.shape[1], dgelu_aux=prev_aux)
+        d_cur = ops.conv_cl_dgrad(d_c, st.packed[i], k, s, x_in.shape[1], dgelu_aux=prev_aux,
+                                  wprep=getattr(st, "_dgrad_w", {}).get(i))
     dim0, k0, s0 = convs[0]
     r0 = st.conv[0]
     if cfg.extractor_mode == "default":

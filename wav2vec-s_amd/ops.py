@@ -230,14 +230,15 @@ def colsum(x, out_f32):
 
 
 def transpose_multi(items):
-    """items: (in_ptr, out_ptr, R, C) tuples (device addresses of bf16 matrices); out[C, R] = in[R, C]^T for all
-    of them in one launch per 64 items."""
+    """items: (in_ptr, out_ptr, R, C[, ld_in, ld_out]) tuples (device addresses of bf16 matrices, row strides in
+    elements, 0 = dense); out[C, R] = in[R, C]^T for all of them in one launch per 64 items."""
     from ._lib import TransposeItem
     for i in range(0, len(items), 64):
         chunk = items[i:i + 64]
         arr = (TransposeItem * len(chunk))()
-        for a, (pi, po, r, c) in zip(arr, chunk):
-            a.inp, a.out, a.R, a.C = pi, po, r, c
+        for a, it in zip(arr, chunk):
+            a.inp, a.out, a.R, a.C = it[0], it[1], it[2], it[3]
+            a.ld_in, a.ld_out = (it[4], it[5]) if len(it) > 4 else (0, 0)
         _lib.call("w2vs_transpose_multi", arr, len(chunk), _stream())
 
 
@@ -282,7 +283,35 @@ def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True):
     return (y, pre) if save_pre else y
 
 
-def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None):
+_DGRAD_W = {}
+
+
+def conv_dgrad_weight_items(key, w2, k, s):
+    """Transpose items that build the B operand of conv_cl_dgrad for one conv layer into a persistent buffer (its
+    structural zeros are written once): returns (buffer, items).  All layers' items go into ONE transpose_multi."""
+    Cout, kc = w2.shape
+    Cin = kc // k
+    if (k, s) == (2, 2):
+        buf = _DGRAD_W.get(key)
+        if buf is None or buf.shape != (2 * Cin, Cout):
+            buf = _DGRAD_W[key] = torch.empty((2 * Cin, Cout), dtype=BF16, device=w2.device)
+        return buf, [(w2.data_ptr(), buf.data_ptr(), Cout, 2 * Cin)]
+    if (k, s) == (3, 2):
+        buf = _DGRAD_W.get(key)
+        if buf is None or buf.shape != (2, Cin, 2, Cout):
+            buf = _DGRAD_W[key] = torch.zeros((2, Cin, 2, Cout), dtype=BF16, device=w2.device)
+        e = 2  # bytes
+        base, src = buf.data_ptr(), w2.data_ptr()
+        # tap j of the packed weight is the [Cout, Cin] block at columns j*Cin (row stride 3*Cin); its transpose lands
+        # at rows (h, ci), column block g of bt[h][ci][g][co] (row stride 2*Cout): (h,g) = (0,0)<-W2, (0,1)<-W0, (1,1)<-W1
+        items = []
+        for j, (h, g) in ((2, (0, 0)), (0, (0, 1)), (1, (1, 1))):
+            items.append((src + e * j * Cin, base + e * ((h * Cin) * 2 * Cout + g * Cout), Cout, Cin, 3 * Cin, 2 * Cout))
+        return buf, items
+    raise W2vsError("conv dgrad is built for (k,s) in {(2,2),(3,2)}; got (%d,%d)" % (k, s))
+
+
+def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None, wprep=None):
     """Gradient wrt the channel-last input of conv_cl_fwd.  dy [B, Lout, Cout]; w2 [Cout, k*Cin] packed.
     (k, s) = (2, 2): non-overlapping windows -> plain GEMM into [B, Lout, 2*Cin].
     (k, s) = (3, 2): input rows pair up, pair p = [dy[p-1] | dy[p]] @ [[W2, 0], [W0, W1]]."""
@@ -291,7 +320,10 @@ def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None):
     Cin = w2.shape[1] // k
     dx = empty((B, Lin, Cin), BF16, dy.device)
     epi = EPI_DGELU if dgelu_aux is not None else EPI_NONE
-    wt = transpose2d(w2)  # [k*Cin, Cout]: row (j*Cin + ci) = w[:, ci, j]
+    if wprep is not None:
+        wt = bt = wprep
+    else:
+        wt = transpose2d(w2)  # [k*Cin, Cout]: row (j*Cin + ci) = w[:, ci, j]
     if (k, s) == (2, 2):
         if Lin > 2 * Lout:
             dx[:, 2 * Lout:].zero_()
@@ -300,11 +332,12 @@ def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None):
     elif (k, s) == (3, 2):
         # B operand [N = 2*Cin, K = 2*Cout]: row-half 0 = [W2^T | W0^T], row-half 1 = [0 | W1^T]
         # (K index 0..Cout-1 multiplies dy[p-1], Cout..2Cout-1 multiplies dy[p])
-        wt3 = wt.view(3, Cin, Cout)
-        bt = zeros((2, Cin, 2, Cout), BF16, dy.device)
-        bt[0, :, 0] = wt3[2]
-        bt[0, :, 1] = wt3[0]
-        bt[1, :, 1] = wt3[1]
+        if wprep is None:
+            wt3 = wt.view(3, Cin, Cout)
+            bt = zeros((2, Cin, 2, Cout), BF16, dy.device)
+            bt[0, :, 0] = wt3[2]
+            bt[0, :, 1] = wt3[0]
+            bt[1, :, 1] = wt3[1]
         P = (Lin + 1) // 2
         gemm_nt(dy, bt, M=P, N=2 * Cin, K=2 * Cout, lda=Cout, ldb=2 * Cout, ldc=2 * Cin, out=dx, aux=dgelu_aux,
                 epi=epi, a_off=-Cout, batch=B, sA=Lout * Cout, sC=Lin * Cin, a_bytes=Lout * Cout * 2,
