@@ -339,28 +339,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
 }
 
 // =================================================================================================
-// delta[b,h,q] = sum_d dO[q,d] * O[q,d]
-// =================================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  long total = (long)p.B * p.H * p.N;
-  if (i >= total) return;
-  int qn = (int)(i % p.N);
-  int h = (int)((i / p.N) % p.H);
-  int b = (int)(i / ((long)p.N * p.H));
-  const bf16* o = p.o + (long)b * p.sbo + (long)qn * p.ldo + h * HD;
-  const bf16* d = p.dout + (long)b * p.sbo + (long)qn * p.ldo + h * HD;
-  float s = 0.f;
-#pragma unroll
-  for (int ch = 0; ch < 8; ++ch) {
-    bf16x8 a = *(const bf16x8*)(o + ch * 8), g = *(const bf16x8*)(d + ch * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(g[e]);
-  }
-  const_cast<float*>(p.delta)[i] = s;
-}
-
-// =================================================================================================
 // backward, pass 1: dQ.  Same loop structure as the forward (one block = 128 queries).
 //   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T o drop - delta)
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -395,7 +373,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   }
   const long sidx = ((long)(b * p.H + h)) * N + qc;
   const float lse2 = p.lse[sidx] * LOG2E;
-  const float delta = p.delta[sidx];
+  // delta[q] = dO[q] . O[q]: the lane already holds half of dO[q] (the other half sits in lane ^ 32); computed
+  // here and written out for the dK/dV pass instead of a separate launch
+  float delta = 0.f;
+  if (q < N) {
+    const bf16* Orow = p.o + (long)b * p.sbo + (long)q * p.ldo + h * HD;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 ov = *(const bf16x8*)(Orow + 16 * s + 8 * hh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta = fmaf(bf2f(ov[e]), bf2f(dof[s][e]), delta);
+    }
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  if (q < N && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
   const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
   int mlim, bclo, bchi;
   tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
@@ -755,8 +746,6 @@ int attn_bwd(const AttnDesc& d, hipStream_t st) {
   AttnP p{};
   if (int e = attn_fill(d, p)) return e;
   if (!p.dout || !p.delta || !p.dq || !p.dk || !p.dv) return set_error("attn_bwd: null pointer");
-  long total = (long)p.B * p.H * p.N;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
   dim3 grid((p.N + QB - 1) / QB, p.H, p.B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, p);
