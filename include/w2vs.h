@@ -66,6 +66,10 @@ typedef struct w2vs_gemm_desc {
                                  there and summed by a second launch instead of fp32 atomics into Cf */
 } w2vs_gemm_desc;
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
+/* Tests / tuning: force a kernel variant process-wide (not thread safe).  nt_mode: -1 auto, 0/1/2 the 128x128 forms
+ * (register double buffer / single buffer / LDS-DMA), 3 loader-consumer, 5 persistent loader-consumer; lc_height: 0 auto or
+ * 256 / 192 / 160; tn_lc: -1 auto, 0 the 128x128 atomics kernel, 1 the loader-consumer kernel.  Returns 0. */
+int w2vs_gemm_tune(int32_t nt_mode, int32_t lc_height, int32_t tn_lc);
 /* Measurement hooks: bracket every stride-th GEMM launch with HIP events on its own stream (0 = off).
  * id = NT epilogue (0..6) or 7 for gemm_tn; read returns summed launch time [ms], algorithmic FLOPs
  * and the number of launches timed since the last enable. */

@@ -511,3 +511,72 @@ def test_transpose_multi(ops):
     torch.cuda.synchronize()
     for x, o in zip(xs, outs):
         assert torch.equal(o, x.t().contiguous())      # bit-exact data movement
+
+
+# ------------------------------------------------------------------------------------------ GEMM kernel variants
+NT_VARIANTS = [(0, 0), (1, 0), (2, 0), (3, 256), (3, 192), (3, 160), (5, 256), (5, 192), (5, 160)]
+
+
+@pytest.mark.parametrize("mode,height", NT_VARIANTS)
+def test_gemm_nt_every_variant(ops, mode, height):
+    """Each NT kernel (128x128 register / single-buffer / LDS-DMA, loader-consumer and persistent at three tile
+    heights) against fp32 torch on ragged shapes with every epilogue, then the conv-as-GEMM form (overlapping A
+    rows, batch, the 'row -1' dgrad operand)."""
+    try:
+        ops.gemm_tune(nt_mode=mode, lc_height=height)
+        for (M, N, K) in [(1000, 392, 200), (257, 128, 64), (6544, 768, 768), (130, 2304, 776)]:
+            x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+            y = ops.linear_fwd(dev(x), dev(w), dev(b))
+            ref = x.float() @ w.float().t() + b.float()
+            assert rel(y, ref) < 5e-3, (M, N, K)
+            h, pre = ops.linear_fwd(dev(x), dev(w), dev(b), gelu=True, save_pre=True)
+            assert rel(pre, ref) < 5e-3
+            assert rel(h, F.gelu(pre.float().cpu())) < 5e-3
+            dy, aux = rnd(M, N, seed=4), rnd(M, K, seed=5)
+            dx = ops.linear_dgrad(dev(dy), dev(w).t().contiguous())
+            assert rel(dx, dy.float() @ w.float()) < 5e-3
+            dx2 = ops.linear_dgrad(dev(dy), dev(w).t().contiguous(), dgelu_aux=dev(aux))
+            a = aux.float().requires_grad_(True)
+            F.gelu(a).backward(dx.float().cpu())
+            assert rel(dx2, a.grad) < 6e-3
+            dx3 = ops.linear_dgrad(dev(dy), dev(w).t().contiguous(), add_aux=dev(aux))
+            assert rel(dx3, dx.float().cpu() + aux.float()) < 5e-3
+        B, Lin, Cin, Cout, k, s = 2, 301, 64, 128, 3, 2
+        xx, ww = rnd(B, Lin, Cin, seed=6), rnd(Cout, Cin, k, seed=7, scale=0.1)
+        w2 = ops.conv_pack_weight(dev(ww))
+        yy, pre = ops.conv_cl_fwd(dev(xx), w2, k, s, None, gelu=True, save_pre=True)
+        ref_pre = F.conv1d(xx.float().transpose(1, 2), ww.float(), stride=s).transpose(1, 2)
+        assert rel(pre, ref_pre) < 5e-3
+        dyy = rnd(*ref_pre.shape, seed=8)
+        dxx = ops.conv_cl_dgrad(dev(dyy), w2, k, s, Lin)
+        xr = xx.float().requires_grad_(True)
+        F.conv1d(xr.transpose(1, 2), ww.float(), stride=s).backward(dyy.float().transpose(1, 2))
+        assert rel(dxx, xr.grad) < 5e-3
+    finally:
+        ops.gemm_tune()
+
+
+@pytest.mark.parametrize("tn_lc", [0, 1])
+def test_gemm_tn_both_kernels(ops, tn_lc):
+    """Weight-gradient kernels (128x128 + atomics, loader-consumer + partial-tile workspace) incl. the fused bias
+    gradient, accumulation into a non-zero target, ragged K, and the batched conv form."""
+    try:
+        ops.gemm_tune(tn_lc=tn_lc)
+        for (R, N, K) in [(1000, 256, 192), (6544, 768, 768), (333, 640, 512), (4097, 3072, 768)]:
+            dy, x = rnd(R, N, seed=1), rnd(R, K, seed=2)
+            dw = torch.full((N, K), 0.5, device="cuda")
+            db = torch.zeros(N, device="cuda")
+            ops.linear_wgrad(dev(dy), dev(x), dw, 1.0, db)
+            assert rel(dw, 0.5 + dy.float().t() @ x.float()) < 3e-3, (R, N, K)
+            assert rel(db, dy.float().sum(0)) < 3e-3
+        B, Lin, Cin, Cout, k, s = 3, 1001, 64, 128, 3, 2
+        xx, ww = rnd(B, Lin, Cin, seed=6), rnd(Cout, Cin, k, seed=7, scale=0.1)
+        xr, wr = xx.float(), ww.float().requires_grad_(True)
+        out = F.conv1d(xr.transpose(1, 2), wr, stride=s)
+        dyy = rnd(B, out.shape[-1], Cout, seed=8)
+        out.backward(dyy.float().transpose(1, 2))
+        dw2 = torch.zeros(Cout, k * Cin, device="cuda")
+        ops.conv_cl_wgrad(dev(dyy), dev(xx), k, s, dw2)
+        assert rel(dw2, wr.grad.permute(0, 2, 1).reshape(Cout, k * Cin)) < 3e-3
+    finally:
+        ops.gemm_tune()

@@ -106,6 +106,7 @@ _SIGS = {
     "w2vs_nce_bwd": [C.POINTER(NceDesc), vp],
     "w2vs_ce_rows": [vp, i64, i32, vp, vp, vp],
     "w2vs_gather_rows": [vp, vp, vp, i64, i32, i32, vp],
+    "w2vs_gemm_tune": [i32, i32, i32],
     "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],
     "w2vs_transpose_multi": [vp, i32, vp],
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],

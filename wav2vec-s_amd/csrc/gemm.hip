@@ -1066,6 +1066,10 @@ static int check_common(const GemmDesc& d) {
   return 0;
 }
 
+// Variant overrides for tests and tuning (process-wide, not thread safe): -1 / 0 = automatic choice.
+static int g_force_nt_mode = -1, g_force_lc_h = 0, g_force_tn_lc = -1;
+void gemm_tune(int nt_mode, int lc_height, int tn_lc) { g_force_nt_mode = nt_mode; g_force_lc_h = lc_height; g_force_tn_lc = tn_lc; }
+
 int gemm_nt(const GemmDesc& d, hipStream_t s) {
   if (int e = check_common(d)) return e;
   if (d.epi == EPI_F32 ? !d.Cf : !d.C) return set_error("gemm_nt: null output");
@@ -1118,8 +1122,12 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     }
   }
   if (mode_env >= 0) mode = mode_env;
+  if (g_force_nt_mode >= 0) mode = g_force_nt_mode;
+  if ((mode == 5) && !p_ok) return set_error("gemm_nt: the persistent kernel needs N % 8 == 0, ldc % 8 == 0, 16-byte aligned outputs");
   static const int lc_env = [] { const char* e = getenv("W2VS_LC_H"); return e ? atoi(e) : 0; }();
   if (lc_env > 0) lc_h = lc_env;
+  if (g_force_lc_h > 0) lc_h = g_force_lc_h;
+  if (lc_h != 256 && lc_h != 192 && lc_h != 160) return set_error("gemm_nt: tile height must be 256, 192 or 160");
   const dim3 grid8((d.N + 127) / 128, (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
@@ -1173,6 +1181,7 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
     const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
     bool use_lc = tiles8 >= 24 && tiles8 <= ncu && d.sC == 0;
     if (tn_lc_env >= 0) use_lc = tn_lc_env != 0;
+    if (g_force_tn_lc >= 0) use_lc = g_force_tn_lc != 0 && d.sC == 0;
     if (use_lc) {
       int splits = std::max(1, ncu / tiles8);
       const int max_splits = (d.K + TK - 1) / TK;

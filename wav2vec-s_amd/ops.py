@@ -158,6 +158,11 @@ def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, 
     GEMM_TIMER.end(ev, epi, 2.0 * M * N * K * batch)
 
 
+def gemm_tune(nt_mode=-1, lc_height=0, tn_lc=-1):
+    """Force a GEMM kernel variant (tests / tuning); defaults restore the automatic choice."""
+    _lib.call("w2vs_gemm_tune", nt_mode, lc_height, tn_lc)
+
+
 _TN_WS = {}
 
 
