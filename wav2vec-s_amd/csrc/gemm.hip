@@ -145,10 +145,15 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
     for (int j = 0; j < 4; ++j) {
       const int row = wid * 32 + j * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
+      // B rows are stored PERMUTED (LDS row w*64 + jj*16 + f <- B row w*64 + (jj>>1)*32 + (f>>2)*8 + (jj&1)*4 + (f&3)):
+      // with the MFMA operands swapped a lane then owns 8 consecutive output columns (tiles 2u, 2u+1) of one row and
+      // the epilogue stores 16 bytes straight from the registers - no LDS staging, no barriers
+      const int f = row & 15, jj = (row >> 4) & 3;
+      const int brow = (row & 64) + (jj >> 1) * 32 + (f >> 2) * 8 + (jj & 1) * 4 + (f & 3);
       da_ok[j] = (m0 + row < p.M) && (c * 8 < p.K);
-      db_ok[j] = (n0 + row < p.N) && (c * 8 < p.K);
+      db_ok[j] = (n0 + brow < p.N) && (c * 8 < p.K);
       da_off[j] = (uint32_t)((p.a_off + (long)(m0 + row) * p.lda + c * 8) * 2);
-      db_off[j] = (uint32_t)(((long)(n0 + row) * p.ldb + c * 8) * 2);
+      db_off[j] = (uint32_t)(((long)(n0 + brow) * p.ldb + c * 8) * 2);
     }
   }
   auto dma_issue = [&](int kt, int buf) {
@@ -192,8 +197,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)   // operands swapped: acc holds C^T (4 consecutive columns per lane)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (this wave's part)
       __builtin_amdgcn_s_barrier();                       // ... everyone's part; and everyone is done reading `buf`
@@ -228,6 +233,59 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
   }
   if (SB) __syncthreads();
 
+  if (DMA) {
+    // ---- epilogue straight from the registers: lane (fr, fq) holds row i*16+fr and, from tiles 2u / 2u+1, the eight
+    // consecutive columns u*32 + fq*8 .. +7 of its wave's 64-column strip
+    const long cbase = (long)bz * p.sC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + wn * 64 + u * 32 + fq * 8;
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+        if (p.bias != nullptr && col < p.N) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[e] = bf2f(p.bias[col + e]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + fr;
+        const long o = (long)row * p.ldc + col;
+        if (row >= p.M || col >= p.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * u][e]; v[4 + e] = acc[i][2 * u + 1][e]; }
+        if (EPI == EPI_F32) {
+          *(f32x4*)(p.Cf + cbase + o) = f32x4{v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha};
+          *(f32x4*)(p.Cf + cbase + o + 4) = f32x4{v[4] * p.alpha, v[5] * p.alpha, v[6] * p.alpha, v[7] * p.alpha};
+          continue;
+        }
+        if (o + 8 > p.c_elems) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        bf16x8 o8;
+        if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+          bf16x8 pre;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { pre[e] = f2bf(v[e]); o8[e] = f2bf(gelu_exact(EPI == EPI_BIAS_GELU_SAVE ? bf2f(pre[e]) : v[e])); }
+          if (EPI == EPI_BIAS_GELU_SAVE) *(bf16x8*)(p.C2 + cbase + o) = pre;
+        } else if (EPI == EPI_DGELU) {
+          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * gelu_grad(bf2f(a[e])));
+        } else if (EPI == EPI_ADD) {
+          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) + bf2f(a[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(v[e]);
+        }
+        *(bf16x8*)(p.C + cbase + o) = o8;
+      }
+    }
+    return;
+  }
   // ---- epilogue: registers -> (fp32 math) -> LDS bf16 tile -> 16-B row-contiguous stores ----
   bf16* Cb = p.C + (long)bz * p.sC;
   if (EPI == EPI_F32) {
