@@ -1181,7 +1181,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   }
   if (mode_env >= 0) mode = mode_env;
   if (g_force_nt_mode >= 0) mode = g_force_nt_mode;
-  if ((mode == 5) && !p_ok) return set_error("gemm_nt: the persistent kernel needs N % 8 == 0, ldc % 8 == 0, 16-byte aligned outputs");
+  if ((mode == 5 || mode == 6) && !p_ok) return set_error("gemm_nt: the persistent kernel needs N % 8 == 0, ldc % 8 == 0, 16-byte aligned outputs");
   static const int lc_env = [] { const char* e = getenv("W2VS_LC_H"); return e ? atoi(e) : 0; }();
   if (lc_env > 0) lc_h = lc_env;
   if (g_force_lc_h > 0) lc_h = g_force_lc_h;
@@ -1189,9 +1189,9 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   const dim3 grid8((d.N + 127) / 128, (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
-    if (mode == 5) {                                                                          \
+    if (mode == 5 || mode == 6) {   /* 6: the same kernel with one workgroup per tile */       \
       const int ntm_ = grid8.y, ntn_ = grid8.x, tot_ = ntm_ * ntn_ * (int)grid8.z;            \
-      const dim3 gp(std::min(tot_, 256));                                                     \
+      const dim3 gp(mode == 6 ? tot_ : std::min(tot_, 256));                                  \
       if (lc_h == 256) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 4, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_);      \
       else if (lc_h == 192) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 3, 4>), gp, dim3(640), 0, s, p, ntm_, ntn_, tot_); \
       else hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5>), gp, dim3(512), 0, s, p, ntm_, ntn_, tot_);                  \
