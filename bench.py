@@ -70,15 +70,6 @@ def cpu_baseline(threads):
             "sample": "oracle fp32, base model, 2 x 80000 samples, fwd+loss+bwd, median of 2 after 1 warm-up, %.2f s/step" % t}
 
 
-def gemm_flops_per_step(cfg, B, T, N, M):
-    """Algorithmic FLOPs of every gemm_nt/gemm_tn launch of one step (fwd + dgrad + wgrad), SURVEY.md 8d."""
-    E, F, C0 = cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim, 512
-    R = B * N
-    lin = lambda rows, k, n: 2.0 * rows * k * n  # noqa: E731
-    per_layer = lin(R, E, 3 * E) + lin(R, E, E) + 2 * lin(R, E, F)
-    return per_layer
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +142,17 @@ def main():
     audio_s = B * L / SR
     value = world * audio_s * args.steps / elapsed
     roof = ops.GEMM_TIMER.report(PEAK_BF16_TFLOPS)
+    # HBM-side bytes per launch of that kernel come from SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    # same command (counters cannot be read in-process); the committed summary is quoted here, null if it is absent
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")))
+        key = {"gemm_tn_lc_kernel": "w2vs::gemm_tn_lc_kernel<true>", "gemm_tn_kernel": "w2vs::gemm_tn_kernel"}.get(
+            roof["kernel"].split(" ")[0])
+        if key in pmc:
+            roof["traffic"] = int((pmc[key]["read_MB_per_launch_corrected"] + pmc[key]["write_MB_per_launch"]) * 1e6)
+            roof["traffic_note"] = "bytes/launch, rocprofv3 --pmc (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/round1_pmc_hbm_traffic.json"
+    except Exception:
+        pass
     st = model._last_state
     out = {
         "metric": "audio-seconds/s/GPU, wav2vec-S base pretrain step, 1/2/4/8 MI355X",
