@@ -1019,39 +1019,40 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)   // operands swapped: acc holds the transposed tile, 4 consecutive output columns per lane
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       if (do_colsum) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones.v, cs[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, af[i], cs[i], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_barrier();
     stage = stage == 2 ? 0 : stage + 1;
   }
+  // lane (fr, fq) of tile (i, j) holds output row i*16 + fr and the four consecutive columns j*16 + fq*4 .. +3
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      const int row = m0 + wm * 64 + i * 16 + fr, col = n0 + wn * 64 + j * 16 + fq * 4;
+      if (row >= p.M || col >= p.N) continue;      // N % 8 == 0: the four columns are in or out together
+      // a workgroup's 128 KiB of atomics drain at ~one wave-instruction per 50 ns per CU (25 us, as long as the
+      // whole K loop of an encoder wgrad); plain 16-byte stores of the partial tile + a summing launch cost a third
+      if (SLAB) {
+        *(f32x4*)(p.slab + ((long)zz * p.M + row) * p.N + col) =
+            f32x4{acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = m0 + wm * 64 + i * 16 + fq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
-        if (row < p.M && col < p.N) {
-          // a workgroup's 128 KiB of atomics drain at ~one wave-instruction per 50 ns per CU (25 us, as long as the
-          // whole K loop of an encoder wgrad); plain stores of the partial tile + a summing launch cost a third
-          if (SLAB) p.slab[((long)zz * p.M + row) * p.N + col] = acc[i][j][r] * p.alpha;
-          else atomicAdd(&p.Cf[(long)row * p.ldc + col], acc[i][j][r] * p.alpha);
-        }
+        for (int r = 0; r < 4; ++r) atomicAdd(&p.Cf[(long)row * p.ldc + col + r], acc[i][j][r] * p.alpha);
       }
-  if (do_colsum && fr == 0) {   // every column of cs holds the same row sums
+    }
+  if (do_colsum && fq == 0) {   // every accumulator row of cs holds the same sums: lane fr owns output row i*16 + fr
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
-        if (row < p.M) atomicAdd(&p.colsum[row], cs[i][r] * p.alpha);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + wm * 64 + i * 16 + fr;
+      if (row < p.M) atomicAdd(&p.colsum[row], cs[i][0] * p.alpha);
+    }
   }
 }
 
@@ -1237,7 +1238,7 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   {
     const int tiles8 = ((d.N + 127) / 128) * ((d.M + 255) / 256) * nb;
     const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
-    bool use_lc = tiles8 >= 24 && tiles8 <= ncu && d.sC == 0;
+    bool use_lc = tiles8 >= 16 && tiles8 <= ncu && d.sC == 0;
     if (tn_lc_env >= 0) use_lc = tn_lc_env != 0;
     if (g_force_tn_lc >= 0) use_lc = g_force_tn_lc != 0 && d.sC == 0;
     if (use_lc) {
