@@ -580,3 +580,31 @@ def test_gemm_tn_both_kernels(ops, tn_lc):
         assert rel(dw2, wr.grad.permute(0, 2, 1).reshape(Cout, k * Cin)) < 3e-3
     finally:
         ops.gemm_tune()
+
+
+def test_conv0_ln_gelu_with_conv_bias(ops):
+    """The matrix-core conv0 carries the conv bias as an extra all-ones tap: forward and every gradient
+    (weight, conv bias, LayerNorm affine) against autograd, frames straddling utterance ends."""
+    B, L, Cc, k, s = 3, 2003, 512, 10, 5
+    wave = rnd(B, L, seed=11)
+    w = rnd(Cc, 1, k, seed=12, scale=0.4)
+    cb = rnd(Cc, seed=13, scale=0.3)
+    g, b = (1 + 0.1 * torch.randn(Cc)).to(BF), (0.1 * torch.randn(Cc)).to(BF)
+    y, mean, rstd = ops.conv0_fwd(dev(wave), dev(w), dev(g), dev(b), k, s, conv_bias=dev(cb))
+    wf, cbf, gf, bf_ = (t.float().requires_grad_(True) for t in (w, cb, g, b))
+    c = F.conv1d(wave.float().unsqueeze(1), wf, cbf, stride=s).transpose(1, 2)          # [B, L0, C]
+    ref = F.gelu(F.layer_norm(c, (Cc,), gf, bf_))
+    assert rel(y, ref) < 5e-3
+    dy = rnd(*y.shape, seed=14)
+    ref.backward(dy.float())
+    dw = torch.zeros(Cc, k, device="cuda")
+    dcb = torch.zeros(Cc, device="cuda")
+    dg = torch.zeros(Cc, device="cuda")
+    db = torch.zeros(Cc, device="cuda")
+    ops.conv0_bwd(dev(wave), dev(w), dev(g), dev(b), mean, rstd, dev(dy), k, s, dw, dg, db, conv_bias=dev(cb),
+                  dconv_bias=dcb)
+    assert rel(dw, wf.grad.view(Cc, k)) < 5e-3
+    assert rel(dg, gf.grad) < 5e-3
+    assert rel(db, bf_.grad) < 5e-3
+    # d(conv bias) is a sum of the LayerNorm-backward output, which is zero-mean per frame: compare with an absolute floor
+    assert float((dcb.cpu() - cbf.grad).abs().max()) < 5e-3 * max(1.0, float(cbf.grad.abs().max())) + 2e-2
