@@ -149,6 +149,8 @@ typedef struct w2vs_attn_desc {
   int64_t ld, ldo, sb, sbo;
   int32_t B, H, N, Tp, m, r, head_dim;
   float scale; float p_drop; uint64_t seed;
+  int32_t Nq;   /* 0 = N.  Otherwise only positions 0..Nq-1 are queries (Nq <= Tp: the main frames); o / lse / dq rows
+                 * past Nq are left untouched - used by the last encoder layer, whose right-context outputs are dead */
 } w2vs_attn_desc;
 int w2vs_attn_fwd(const w2vs_attn_desc* d, void* stream);
 int w2vs_attn_bwd(const w2vs_attn_desc* d, void* stream);
@@ -178,6 +180,11 @@ typedef struct w2vs_layer_desc {
    * for every layer of the step; layer_bwd then skips its own four transposes (wt_scratch may be NULL) */
   const void *wqkv_t, *wo_t, *w1_t, *w2_t;
   void* tn_ws; int64_t tn_ws_bytes;   /* optional scratch handed to the weight-gradient GEMMs (w2vs_gemm_desc.ws) */
+  /* optional "selected rows" mode for the LAST layer of a pre-training step: only the n_sel token rows sel_idx[]
+   * (= the masked frames) of its output are ever read, so everything after the attention runs on those rows only
+   * (s1, x1, hpre, h, s2, x_out, mean/rstd then hold n_sel rows, in sel_idx order) and the attention takes the
+   * n_q = Tp main frames as queries.  ctx_sel / xin_sel: [n_sel, E] scratch kept for the backward. */
+  const int32_t* sel_idx; int32_t n_sel, n_q; void* ctx_sel; void* xin_sel;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

@@ -82,8 +82,12 @@ def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
     rep["conv0"] = rel(st.conv[0]["y"], col["conv0"].transpose(1, 2))
     rep["conv_out"] = rel(st.y_last, col[f"conv{len(ocfg.conv_layers) - 1}"].transpose(1, 2))
     rep["features"] = rel(st.feats, col["features"])
-    enc = st.enc.view(B_, N, -1)[:, :T]
-    rep["enc_out"] = rel(enc, col["enc_out"])
+    if getattr(st, "enc_is_sel", False):     # the last layer ran on the masked frames only: compare those rows
+        msk = torch.from_numpy(mask)
+        rep["enc_out"] = rel(st.enc, col["enc_out"][msk])
+    else:
+        enc = st.enc.view(B_, N, -1)[:, :T]
+        rep["enc_out"] = rel(enc, col["enc_out"])
     rep["q"] = rel(st.q.view(B_, -1, st.q.shape[-1]), col["q"])
     rep["code_idx_equal"] = float((st.qst.idx.cpu().long() == col["q_idx"]).float().mean())
     logits_ref = col["preds"].permute(1, 2, 0).reshape(-1, st.K + 1)
@@ -240,3 +244,38 @@ def test_train_step_flat_storage_learns_and_keeps_checkpoint_layout():
     assert all(np.isfinite(losses))
     changed = sum(int(not torch.equal(model.state_dict()[k].cpu(), before[k].cpu())) for k in before if "pos_conv" not in k)
     assert changed >= len(before) - 8
+
+
+def test_last_layer_selected_rows_equals_full_path():
+    """engine.SELECT_LAST_LAYER (the last encoder layer computes only the masked frames, its attention only the main
+    frames as queries) is an exact dead-code elimination: loss, logits and every gradient match the full path."""
+    from wav2vec_s_amd import engine
+    # attention dropout is keyed by (query position, key): identical in both modes; the row dropout of the last layer is
+    # keyed by the row index of the tensor it runs on, so it is switched off for an exact comparison
+    cfg_kw = dict(BASE, dropout=0.0, attention_dropout=0.1)
+    out = {}
+    for flag in (False, True):
+        w, model, P, ocfg, source, draws, mask, neg, noise = _setup(cfg_kw, B=2, L=24000, seed=3, m_ctx=16, r_ctx=8)
+        model = model.cuda().train()
+        crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0])
+        engine.SELECT_LAST_LAYER = flag
+        try:
+            model.inject_draws(draws)
+            torch.manual_seed(7); torch.cuda.manual_seed(7)
+            loss, _, _ = crit(model, {"net_input": {"source": source.cuda()}})
+            loss.backward()
+            st = model._last_state
+            assert bool(getattr(st, "enc_is_sel", False)) == flag
+            out[flag] = (float(loss), st.logits.float().cpu().clone(),
+                         {n: p.grad.float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            engine.SELECT_LAST_LAYER = True
+    (l0, lg0, g0), (l1, lg1, g1) = out[False], out[True]
+    assert abs(l0 - l1) / abs(l0) < 1e-5, (l0, l1)
+    fin = torch.isfinite(lg0)
+    assert float((lg0[fin] - lg1[fin]).abs().max()) < 1e-3
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        den = float(g0[n].norm())
+        if den > 1e-6:
+            assert float((g0[n] - g1[n]).norm()) / den < 2e-3, n       # wgrad / reduction order differs, nothing else

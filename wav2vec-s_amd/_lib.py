@@ -46,7 +46,7 @@ class AttnDesc(C.Structure):
                 ("dout", vp), ("delta", vp), ("dq", vp), ("dk", vp), ("dv", vp),
                 ("ld", i64), ("ldo", i64), ("sb", i64), ("sbo", i64),
                 ("B", i32), ("H", i32), ("N", i32), ("Tp", i32), ("m", i32), ("r", i32), ("head_dim", i32),
-                ("scale", f32), ("p_drop", f32), ("seed", u64)]
+                ("scale", f32), ("p_drop", f32), ("seed", u64), ("Nq", i32)]
 
 
 class QuantDesc(C.Structure):
@@ -75,7 +75,8 @@ class LayerDesc(C.Structure):
                     "x_out", "tmp", "d_out", "d_in",
                     "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_ln1_g", "g_ln1_b", "g_w1", "g_b1", "g_w2", "g_b2",
                     "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta",
-                    "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64)])
+                    "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64), ("sel_idx", vp), ("n_sel", i32),
+                                                                            ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp)])
 
 
 _DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc]

@@ -36,6 +36,7 @@ struct AttnP {
   bf16* dq; bf16* dk; bf16* dv;                 // [B, N, ld] same layout as q/k/v
   long ld, ldo, sb, sbo;                        // row stride, batch stride (elements)
   int B, H, N, Tp, m, r;
+  int Nq;                                       // queries are positions 0..Nq-1 (Nq == N, or Nq <= Tp: main frames only)
   float scale; float p_drop; uint64_t seed;
 };
 
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int qblk0 = (gridDim.x - 1 - blockIdx.x) * QB;  // longest query tiles first: shorter tail
   const int q = qblk0 + wid * 32 + r32;
-  const int N = p.N;
+  const int N = p.N, Nq = p.Nq;
   const bf16* Q = p.q + (long)b * p.sb + h * HD;
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
@@ -171,14 +172,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    if (q < N) qf[s] = *(const bf16x8*)(Q + (long)q * p.ld + 16 * s + 8 * hh);
+    if (q < Nq) qf[s] = *(const bf16x8*)(Q + (long)q * p.ld + 16 * s + 8 * hh);
     else
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[s][j] = f2bf(0.f);
   }
-  const QLimits L = q_limits(min(q, N - 1), p.Tp, p.m, p.r, N);
+  const QLimits L = q_limits(min(q, Nq - 1), p.Tp, p.m, p.r, N);
   int mlim, bclo, bchi;
-  tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+  tile_ranges(qblk0, min(qblk0 + QB, Nq) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
   // per-wave key ranges: sub-tiles no query of this wave can see are skipped, sub-tiles every
   // query sees completely (and that hold no padded key) skip the mask arithmetic
   const int wmlim = wave_max_i(L.lim), wfull = wave_min_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
-  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)min(q, N - 1)) * Nh;
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)min(q, Nq - 1)) * Nh;
 
   f32x16 O0, O1;
 #pragma unroll
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   }
   const float ltot = lrun + __shfl_xor(lrun, 32, 64);
   const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-  if (q < N) {
+  if (q < Nq) {
     bf16* orow = p.o + (long)b * p.sbo + (long)q * p.ldo + h * HD;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -353,8 +354,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int qblk0 = (gridDim.x - 1 - blockIdx.x) * QB;
   const int q = qblk0 + wid * 32 + r32;
-  const int N = p.N;
-  const int qc = min(q, N - 1);
+  const int N = p.N, Nq = p.Nq;
+  const int qc = min(q, Nq - 1);
   const bf16* Q = p.q + (long)b * p.sb + h * HD;
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   bf16x8 qf[4], dof[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    if (q < N) {
+    if (q < Nq) {
       qf[s] = *(const bf16x8*)(Q + (long)q * p.ld + 16 * s + 8 * hh);
       dof[s] = *(const bf16x8*)(dO + (long)q * p.ldo + 16 * s + 8 * hh);
     } else {
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   // delta[q] = dO[q] . O[q]: the lane already holds half of dO[q] (the other half sits in lane ^ 32); computed
   // here and written out for the dK/dV pass instead of a separate launch
   float delta = 0.f;
-  if (q < N) {
+  if (q < Nq) {
     const bf16* Orow = p.o + (long)b * p.sbo + (long)q * p.ldo + h * HD;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -386,10 +387,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     }
   }
   delta += __shfl_xor(delta, 32, 64);
-  if (q < N && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
+  if (q < Nq && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
   const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
   int mlim, bclo, bchi;
-  tile_ranges(qblk0, min(qblk0 + QB, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+  tile_ranges(qblk0, min(qblk0 + QB, Nq) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
   const int wmlim = wave_max_i(L.lim), wfull = wave_min_i(L.lim), wclo = wave_min_i(L.clo), wchi = wave_max_i(L.chi);
   const float c = p.scale * LOG2E;
   const uint32_t thr = drop_threshold(p.p_drop) >> 16;
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     cur = nxt;
     buf ^= 1;
   }
-  if (q < N) {
+  if (q < Nq) {
     bf16* drow_p = p.dq + (long)b * p.sb + (long)q * p.ld + h * HD;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int kblk0 = blockIdx.x * QB;
   const int key = kblk0 + wid * 32 + r32;
-  const int N = p.N;
+  const int N = p.N, Nq = p.Nq;
   const bf16* Q = p.q + (long)b * p.sb + h * HD;
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
@@ -561,13 +562,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
   for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   auto next_tile = [&](int q0) {  // first query tile at or after q0 that sees any key of this block
-    while (q0 < N) {
+    while (q0 < Nq) {
       int mlim, bclo, bchi;
-      tile_ranges(q0, min(q0 + QT, N) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
+      tile_ranges(q0, min(q0 + QT, Nq) - 1, p.Tp, p.m, p.r, N, mlim, bclo, bchi);
       if ((klo < mlim) || (klo < bchi && khi > bclo)) break;
       q0 += QT;
     }
-    return q0;
+    return min(q0, N) >= Nq ? N : q0;   // past the last query tile: the loops below test against N
   };
   u32x4 rq[2], rd[2];
   float rlse = 0.f, rdel = 0.f;
@@ -578,16 +579,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
       int cidx = tid + 256 * j, row = cidx >> 3, ch = cidx & 7;
       rq[j] = u32x4{0u, 0u, 0u, 0u};
       rd[j] = u32x4{0u, 0u, 0u, 0u};
-      if (q0 + row < N) {
+      if (q0 + row < Nq) {
         rq[j] = *(const u32x4*)(Q + (long)(q0 + row) * p.ld + ch * 8);
         rd[j] = *(const u32x4*)(dO + (long)(q0 + row) * p.ldo + ch * 8);
       }
     }
     if (tid < QT) {
       int qq = q0 + tid;
-      int qcl = min(qq, N - 1);
-      rlse = (qq < N) ? p.lse[(long)(b * p.H + h) * N + qq] * LOG2E : INFINITY;  // +inf -> P = 0
-      rdel = (qq < N) ? p.delta[(long)(b * p.H + h) * N + qq] : 0.f;
+      int qcl = min(qq, Nq - 1);
+      rlse = (qq < Nq) ? p.lse[(long)(b * p.H + h) * N + qq] * LOG2E : INFINITY;  // +inf -> P = 0
+      rdel = (qq < Nq) ? p.delta[(long)(b * p.H + h) * N + qq] : 0.f;
       QLimits L = q_limits(qcl, p.Tp, p.m, p.r, N);
       rlim = L.lim; rclo = L.clo; rchi = L.chi;
     }
@@ -621,8 +622,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
       bool sub_full = false;
       {  // can any query of this 32-row sub-tile see any key of this wave?  (wave-uniform)
         const int qs0 = q0 + sub * 32;
-        if (qs0 >= N || wk0 >= N) continue;
-        const int qs1 = min(qs0 + 32, N) - 1;
+        if (qs0 >= Nq || wk0 >= N) continue;
+        const int qs1 = min(qs0 + 32, Nq) - 1;
         int smlim, sclo, schi;
         tile_ranges(qs0, qs1, p.Tp, p.m, p.r, N, smlim, sclo, schi);
         if (!((wk0 < smlim) || (wk0 < schi && wk1 > sclo))) continue;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
         int minlim = 0;
         if (qs1 < p.Tp) minlim = min((qs0 / p.m + 1) * p.m, p.Tp);
         else if (qs0 >= p.Tp && p.r > 0) minlim = min(((qs0 - p.Tp) / p.r + 1) * p.m, p.Tp);
-        sub_full = wave_keys_ok && qs0 + 32 <= N && wk0 + 32 <= minlim;
+        sub_full = wave_keys_ok && qs0 + 32 <= Nq && wk0 + 32 <= minlim;
       }
       f32x16 S, dP;
 #pragma unroll
@@ -722,12 +723,14 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
   p.q = (const bf16*)d.q; p.k = (const bf16*)d.k; p.v = (const bf16*)d.v; p.o = (bf16*)d.o; p.lse = d.lse; p.kpad = d.kpad;
   p.dout = (const bf16*)d.dout; p.delta = d.delta; p.dq = (bf16*)d.dq; p.dk = (bf16*)d.dk; p.dv = (bf16*)d.dv;
   p.ld = d.ld; p.ldo = d.ldo; p.sb = d.sb; p.sbo = d.sbo; p.B = d.B; p.H = d.H; p.N = d.N; p.Tp = d.Tp; p.m = d.m; p.r = d.r;
+  p.Nq = d.Nq > 0 ? d.Nq : d.N;
   p.scale = d.scale; p.p_drop = d.p_drop; p.seed = d.seed;
   if (!p.q || !p.k || !p.v || !p.o || !p.lse) return set_error("attention: null pointer");
   if (d.head_dim != HD) return set_error("attention: only head_dim 64 is built");
   if (p.B <= 0 || p.H <= 0 || p.N <= 0) return set_error("attention: bad B/H/N");
   if (p.m <= 0 || p.r < 0 || p.Tp <= 0 || p.Tp > p.N) return set_error("attention: bad block structure (m>0, r>=0, 0<Tp<=N)");
   if (p.N != p.Tp + (p.Tp / p.m) * p.r) return set_error("attention: N must equal Tp + (Tp/m)*r");
+  if (p.Nq != p.N && p.Nq > p.Tp) return set_error("attention: Nq must be N (all queries) or <= Tp (main frames only)");
   if ((p.ld % 8) || (p.ldo % 8) || (p.sb % 8) || (p.sbo % 8)) return set_error("attention: strides must be multiples of 8 elements");
   if (p.p_drop < 0.f || p.p_drop >= 1.f) return set_error("attention: dropout must be in [0,1)");
   if ((long)p.B * p.H * p.N * (long)((p.N + 1) / 2) >= (1L << 32)) return set_error("attention: B*H*N*N/2 must be < 2^32 (dropout index)");
@@ -737,7 +740,7 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
 int attn_fwd(const AttnDesc& d, hipStream_t st) {
   AttnP p{};
   if (int e = attn_fill(d, p)) return e;
-  dim3 grid((p.N + QB - 1) / QB, p.H, p.B);
+  dim3 grid((p.Nq + QB - 1) / QB, p.H, p.B);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "attn_fwd");
 }
@@ -746,9 +749,9 @@ int attn_bwd(const AttnDesc& d, hipStream_t st) {
   AttnP p{};
   if (int e = attn_fill(d, p)) return e;
   if (!p.dout || !p.delta || !p.dq || !p.dk || !p.dv) return set_error("attn_bwd: null pointer");
-  dim3 grid((p.N + QB - 1) / QB, p.H, p.B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, p);
+  dim3 gridq((p.Nq + QB - 1) / QB, p.H, p.B), gridk((p.N + QB - 1) / QB, p.H, p.B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, gridq, dim3(256), 0, st, p);     // dq rows >= Nq are not written
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, gridk, dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "attn_bwd");
 }
 

@@ -60,29 +60,48 @@ static void fill_attn(const w2vs_layer_desc& L, AttnDesc& a) {
   a.scale = 0.125f; a.p_drop = L.p_attn; a.seed = L.seed_attn;
 }
 
+static int sel_check(const w2vs_layer_desc& L) {
+  if (!L.sel_idx) return 0;
+  if (L.n_sel <= 0 || L.n_sel > L.B * L.N || !L.ctx_sel || !L.xin_sel) return set_error("layer: selected-rows mode needs n_sel, ctx_sel, xin_sel");
+  if (L.n_q <= 0 || (L.n_q != L.N && L.n_q > L.Tp)) return set_error("layer: n_q must be N or <= Tp");
+  return 0;
+}
+
 int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(layer_check(L));
+  TRY(sel_check(L));
   const int R = L.B * L.N, E = L.E, F = L.F;
+  const bool sel = L.sel_idx != nullptr;
+  const int Rt = sel ? L.n_sel : R;      // rows of everything behind the attention
   TRY(lin_fwd(L.x_in, L.wqkv, L.bqkv, L.qkv, nullptr, R, 3 * E, E, EPI_BIAS, s));
   AttnDesc a{};
   fill_attn(L, a);
+  if (sel) a.Nq = L.n_q;
   TRY(attn_fwd(a, s));
-  TRY(lin_fwd(L.ctx, L.wo, L.bo, L.tmp, nullptr, R, E, E, EPI_BIAS, s));
+  const void* ctx = L.ctx;
+  const void* xin = L.x_in;
+  if (sel) {   // only these token rows of the layer output are read downstream (the masked frames)
+    TRY(gather_rows(L.ctx, L.sel_idx, L.ctx_sel, Rt, E, 0, s));
+    TRY(gather_rows(L.x_in, L.sel_idx, L.xin_sel, Rt, E, 0, s));
+    ctx = L.ctx_sel; xin = L.xin_sel;
+  }
+  TRY(lin_fwd(ctx, L.wo, L.bo, L.tmp, nullptr, Rt, E, E, EPI_BIAS, s));
   LnFwdDesc n1{};
-  n1.x = L.tmp; n1.res = L.x_in; n1.gamma = L.ln1_g; n1.beta = L.ln1_b; n1.y = L.x1; n1.sum_out = L.s1;
-  n1.mean = L.mean1; n1.rstd = L.rstd1; n1.rows = R; n1.C = E; n1.p_drop = L.p_drop; n1.seed = L.seed_drop1;
+  n1.x = L.tmp; n1.res = xin; n1.gamma = L.ln1_g; n1.beta = L.ln1_b; n1.y = L.x1; n1.sum_out = L.s1;
+  n1.mean = L.mean1; n1.rstd = L.rstd1; n1.rows = Rt; n1.C = E; n1.p_drop = L.p_drop; n1.seed = L.seed_drop1;
   TRY(ln_fwd(n1, s));
-  TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, R, F, E, EPI_BIAS_GELU_SAVE, s));
-  TRY(lin_fwd(L.h, L.w2, L.b2, L.tmp, nullptr, R, E, F, EPI_BIAS, s));
+  TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, Rt, F, E, EPI_BIAS_GELU_SAVE, s));
+  TRY(lin_fwd(L.h, L.w2, L.b2, L.tmp, nullptr, Rt, E, F, EPI_BIAS, s));
   LnFwdDesc n2{};
   n2.x = L.tmp; n2.res = L.x1; n2.gamma = L.ln2_g; n2.beta = L.ln2_b; n2.y = L.x_out; n2.sum_out = L.s2;
-  n2.mean = L.mean2; n2.rstd = L.rstd2; n2.rows = R; n2.C = E; n2.p_drop = L.p_drop; n2.seed = L.seed_drop2;
+  n2.mean = L.mean2; n2.rstd = L.rstd2; n2.rows = Rt; n2.C = E; n2.p_drop = L.p_drop; n2.seed = L.seed_drop2;
   TRY(ln_fwd(n2, s));
   return 0;
 }
 
 int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(layer_check(L));
+  TRY(sel_check(L));
   const bool pre_t = L.wqkv_t && L.wo_t && L.w1_t && L.w2_t;
   if (!L.d_out || !L.d_in || (!L.wt_scratch && !pre_t) || !L.ws_e0 || !L.ws_e1 || !L.ws_e2 || !L.ws_f || !L.ws_qkv || !L.delta)
     return set_error("layer_bwd: null scratch pointer");
@@ -90,43 +109,60 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
       !L.g_ln1_b || !L.g_ln2_g || !L.g_ln2_b)
     return set_error("layer_bwd: null gradient pointer");
   const int R = L.B * L.N, E = L.E, F = L.F, cu = L.num_cu > 0 ? L.num_cu : 256;
+  const bool sel = L.sel_idx != nullptr;
+  const int Rt = sel ? L.n_sel : R;      // d_out, and everything down to d_ctx, has Rt rows
+  const void* ctx = sel ? L.ctx_sel : L.ctx;
   // LN2 backward: d_f = ds2 o dropmask (ws_e0), d_x1a = ds2 (ws_e1)
   LnBwdDesc b2{};
   b2.x = L.s2; b2.gamma = L.ln2_g; b2.beta = L.ln2_b; b2.mean = L.mean2; b2.rstd = L.rstd2; b2.dy = L.d_out;
-  b2.dx = L.ws_e0; b2.dres = L.ws_e1; b2.dgamma = L.g_ln2_g; b2.dbeta = L.g_ln2_b; b2.rows = R; b2.C = E;
+  b2.dx = L.ws_e0; b2.dres = L.ws_e1; b2.dgamma = L.g_ln2_g; b2.dbeta = L.g_ln2_b; b2.rows = Rt; b2.C = E;
   b2.p_drop = L.p_drop; b2.seed = L.seed_drop2; b2.out_scale = 1.f;
   b2.ws = L.ws_f; b2.ws_bytes = (int64_t)R * F * 2;   // ws_f is not live yet: dgamma/dbeta partial slab
   TRY(ln_bwd(b2, s));
   // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
-  TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, cu, s, L.tn_ws, L.tn_ws_bytes));
+  TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, Rt, E, F, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w2, L.wt_scratch, E, F, 1, s));           // [E,F] -> [F,E]
-  TRY(lin_dgrad(L.ws_e0, pre_t ? L.w2_t : L.wt_scratch, L.ws_f, L.hpre, R, E, F, EPI_DGELU, s));
+  TRY(lin_dgrad(L.ws_e0, pre_t ? L.w2_t : L.wt_scratch, L.ws_f, L.hpre, Rt, E, F, EPI_DGELU, s));
   // fc1: wgrad, bias, dgrad + residual branch -> d_x1 (ws_e2)
-  TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, cu, s, L.tn_ws, L.tn_ws_bytes));
+  TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, Rt, F, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));           // [F,E] -> [E,F]
-  TRY(lin_dgrad(L.ws_f, pre_t ? L.w1_t : L.wt_scratch, L.ws_e2, L.ws_e1, R, F, E, EPI_ADD, s));
+  TRY(lin_dgrad(L.ws_f, pre_t ? L.w1_t : L.wt_scratch, L.ws_e2, L.ws_e1, Rt, F, E, EPI_ADD, s));
   // LN1 backward: d_a = ds1 o dropmask (ws_e0), d_xin_a = ds1 (ws_e1)
   LnBwdDesc b1{};
   b1.x = L.s1; b1.gamma = L.ln1_g; b1.beta = L.ln1_b; b1.mean = L.mean1; b1.rstd = L.rstd1; b1.dy = L.ws_e2;
-  b1.dx = L.ws_e0; b1.dres = L.ws_e1; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = R; b1.C = E;
+  b1.dx = L.ws_e0; b1.dres = L.ws_e1; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = Rt; b1.C = E;
   b1.p_drop = L.p_drop; b1.seed = L.seed_drop1; b1.out_scale = 1.f;
   b1.ws = L.ws_f; b1.ws_bytes = (int64_t)R * F * 2;   // fc1's wgrad/dgrad (enqueued above) were its last readers
   TRY(ln_bwd(b1, s));
   // out_proj
-  TRY(lin_wgrad(L.ws_e0, L.ctx, L.g_wo, L.g_bo, R, E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
+  TRY(lin_wgrad(L.ws_e0, ctx, L.g_wo, L.g_bo, Rt, E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wo, L.wt_scratch, E, E, 1, s));
-  TRY(lin_dgrad(L.ws_e0, pre_t ? L.wo_t : L.wt_scratch, L.ws_e2, nullptr, R, E, E, EPI_NONE, s));   // d_ctx
+  TRY(lin_dgrad(L.ws_e0, pre_t ? L.wo_t : L.wt_scratch, L.ws_e2, nullptr, Rt, E, E, EPI_NONE, s));   // d_ctx
+  const void* d_ctx = L.ws_e2;
+  const void* d_res = L.ws_e1;
+  if (sel) {
+    // back to token rows: d_ctx and the residual-branch gradient are zero outside the selected rows
+    const size_t bytes = (size_t)R * E * 2;
+    if (hipMemsetAsync(L.ws_e0, 0, bytes, s) != hipSuccess || hipMemsetAsync(L.ws_f, 0, bytes, s) != hipSuccess)
+      return set_error("layer_bwd: memset failed");
+    TRY(gather_rows(L.ws_e2, L.sel_idx, L.ws_e0, Rt, E, 1, s));     // ws_e0 (d_a) is dead after the out_proj pair
+    TRY(gather_rows(L.ws_e1, L.sel_idx, L.ws_f, Rt, E, 1, s));      // ws_f  (d_hpre, LN slab) is dead too
+    d_ctx = L.ws_e0; d_res = L.ws_f;
+    // dq rows past n_q are not written by the attention backward: the QKV GEMMs read them
+    if (hipMemsetAsync(L.ws_qkv, 0, (size_t)R * 3 * E * 2, s) != hipSuccess) return set_error("layer_bwd: memset failed");
+  }
   // attention
   AttnDesc a{};
   fill_attn(L, a);
+  if (sel) a.Nq = L.n_q;
   const long E2 = 2L * E;
-  a.dout = L.ws_e2; a.delta = L.delta;
+  a.dout = d_ctx; a.delta = L.delta;
   a.dq = L.ws_qkv; a.dk = (char*)L.ws_qkv + E2; a.dv = (char*)L.ws_qkv + 2 * E2;
   TRY(attn_bwd(a, s));
   // fused QKV projection
   TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wqkv, L.wt_scratch, 3 * E, E, 1, s));     // [3E,E] -> [E,3E]
-  TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, L.ws_e1, R, 3 * E, E, EPI_ADD, s));
+  TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, d_res, R, 3 * E, E, EPI_ADD, s));
   return 0;
 }
 

@@ -275,6 +275,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         st.tmp = slab16[max(nk, 1) * per16:]
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         kpad_ptr = st.kpad.data_ptr() if st.kpad is not None else None
+        use_sel = SELECT_LAST_LAYER and not features_only and "token_idx" in st.up and nk > 0
         for j, li in enumerate(st.kept):
             pre = f"encoder.layers.{li}."
             d = LayerDesc()
@@ -301,11 +302,21 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
             d.mean2, d.rstd2 = base32 + 4 * (B * H * N + 2 * R), base32 + 4 * (B * H * N + 3 * R)
             d.x_in = x.data_ptr()
             d.tmp = st.tmp.data_ptr()
+            sel_last = use_sel and j == nk - 1
+            if sel_last:
+                # only the masked frames of the LAST layer's output are ever read (x[mask_indices], wav2vec2.py:590):
+                # everything behind its attention runs on those B*M rows, the attention on the T' main frames
+                RMs = st.up["token_idx"].numel()
+                rec["sel_bufs"] = (ops.empty((RMs, E), BF16, dev), ops.empty((RMs, E), BF16, dev))
+                d.sel_idx, d.n_sel, d.n_q = st.up["token_idx"].data_ptr(), RMs, Tp
+                d.ctx_sel, d.xin_sel = rec["sel_bufs"][0].data_ptr(), rec["sel_bufs"][1].data_ptr()
             _lib.call("w2vs_layer_fwd", C.byref(d), stream)
             rec["desc"] = d
             st.layers.append(rec)
-            x = slab16[j * per16 + R * (7 * E + 2 * F): j * per16 + R * (8 * E + 2 * F)].view(R, E)
+            x_off = j * per16 + R * (7 * E + 2 * F)
+            x = slab16[x_off: x_off + (RMs if sel_last else R) * E].view(-1, E)
         st.slabs = (slab16, slab32)
+        st.enc_is_sel = bool(st.layers) and use_sel
         enc = x
     else:
         # pre-LN: stream s; every "residual add + next LayerNorm" pair is one fused kernel
@@ -367,7 +378,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     q, st.qst = ops.quant_fwd(st.q_logits, vars2d, G, V, tau, training, noise=noise, seed=seed(4))
     st.q = q
     yq = ops.linear_fwd(q, W["project_q.weight"], W["project_q.bias"])
-    xm = ops.gather_rows(enc, token_idx, RM)
+    xm = enc if getattr(st, "enc_is_sel", False) else ops.gather_rows(enc, token_idx, RM)
     xf = ops.linear_fwd(xm, W["final_proj.weight"], W["final_proj.bias"])
     st.yq, st.xm, st.xf = yq, xm, xf
     if not st.neg.is_cuda:
@@ -375,6 +386,10 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     st.logits, st.nce_norms = ops.nce_fwd(xf, yq, st.neg, B, M, K, cfg.logit_temp)   # [B*M, K+1] rows (b, m)
     return st
 
+
+# The last encoder layer of a pre-training step computes only what the loss reads (masked frames); tests switch it off
+# to compare the full encoder output.
+SELECT_LAST_LAYER = True
 
 _POS_TABLES = {}
 
@@ -477,7 +492,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
     p_in, p_feat, p_enc, p_att = st.p
     seed = st.seed
     R = B * N
-    d_enc = ops.zeros((R, E), BF16, dev)
+    d_enc = None if getattr(st, "enc_is_sel", False) else ops.zeros((R, E), BF16, dev)
     d_feats_unmasked = None
 
     if st.features_only:
@@ -488,7 +503,10 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         dxf, dyq = ops.nce_bwd(d_logits, st.logits, st.nce_norms, st.xf, st.yq, st.neg, B, M, K, cfg.logit_temp)
         # final_proj
         dxm = _linear_bwd(dxf, st.xm, "final_proj.weight", "final_proj.bias", W, A)
-        ops.gather_rows(dxm, st.token_idx, RM, scatter=True, out=d_enc)
+        if getattr(st, "enc_is_sel", False):
+            d_enc = dxm                    # the last layer ran on exactly these rows
+        else:
+            ops.gather_rows(dxm, st.token_idx, RM, scatter=True, out=d_enc)
         # project_q
         dq = _linear_bwd(dyq, st.q, "project_q.weight", "project_q.bias", W, A)
         # quantizer
