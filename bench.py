@@ -161,7 +161,7 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "wav2vec-S base (12L d768, 90.3M params) pretrain step: fwd + InfoNCE/diversity/penalty loss + "
                                "bwd%s%s; %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, LayerDrop 0.05, sampled "
-                               "block contexts; random-init weights" % (
+                               "block contexts; random-init weights; unread rows of the last encoder layer pruned (exact)" % (
                                    " + RCCL grad all-reduce" if world > 1 else "",
                                    "" if args.no_optimizer else " + fused Adam", B, L, audio_s),
                    "global_batch_samples": world * B * L, "per_gpu_audio_s_per_s": round(value / world, 2),
