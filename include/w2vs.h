@@ -48,7 +48,9 @@ enum {
   W2VS_EPI_BIAS_GELU_SAVE = 3, /* C2 = acc + bias (pre-activation), C = gelu(C2)     */
   W2VS_EPI_DGELU = 4,          /* C = acc * gelu'(aux[m,n])                          */
   W2VS_EPI_F32 = 5,            /* Cf = alpha * acc (fp32 output)                     */
-  W2VS_EPI_ADD = 6             /* C = acc + aux[m,n]                                 */
+  W2VS_EPI_ADD = 6,            /* C = acc + aux[m,n]                                 */
+  W2VS_EPI_BIAS_GELU_SAVEG = 7,/* C = gelu(pre), C2 = gelu'(pre), pre = bf16(acc + bias): what the backward needs     */
+  W2VS_EPI_MUL = 8             /* C = acc * aux[m,n]              (aux = the saved gelu')                              */
 };
 typedef struct w2vs_gemm_desc {
   const void* A; const void* B;

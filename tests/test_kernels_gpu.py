@@ -541,6 +541,14 @@ def test_gemm_nt_every_variant(ops, mode, height):
             assert rel(dx2, a.grad) < 6e-3
             dx3 = ops.linear_dgrad(dev(dy), dev(w).t().contiguous(), add_aux=dev(aux))
             assert rel(dx3, dx.float().cpu() + aux.float()) < 5e-3
+            # the pair the training step uses: forward saves gelu'(pre), backward multiplies with it
+            h2, gp = ops.linear_fwd(dev(x), dev(w), dev(b), gelu=True, save_pre=True, save_grad=True)
+            assert torch.equal(h2, h)
+            pr = pre.float().cpu().requires_grad_(True)
+            F.gelu(pr).sum().backward()
+            assert rel(gp, pr.grad) < 5e-3
+            dx4 = ops.linear_dgrad(dev(dy), dev(w).t().contiguous(), mul_aux=dev(aux))
+            assert rel(dx4, dx.float().cpu() * aux.float()) < 5e-3
         B, Lin, Cin, Cout, k, s = 2, 301, 64, 128, 3, 2
         xx, ww = rnd(B, Lin, Cin, seed=6), rnd(Cout, Cin, k, seed=7, scale=0.1)
         w2 = ops.conv_pack_weight(dev(ww))

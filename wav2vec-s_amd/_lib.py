@@ -81,7 +81,7 @@ class LayerDesc(C.Structure):
 
 _DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc]
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_ADD = range(7)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_ADD, EPI_BIAS_GELU_SAVEG, EPI_MUL = range(9)
 
 # name -> argtypes ; every entry returns int
 _SIGS = {

@@ -58,7 +58,21 @@ struct GemmP {
   float alpha;
 };
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6,
+       EPI_BIAS_GELU_SAVEG = 7,   // C = gelu(pre), C2 = gelu'(pre): the backward then needs one multiply, not an erf
+       EPI_MUL = 8 };             // C = acc * aux (aux = the saved gelu')
+constexpr bool epi_has_bias(int e) { return e == EPI_BIAS || e == EPI_BIAS_GELU || e == EPI_BIAS_GELU_SAVE || e == EPI_BIAS_GELU_SAVEG; }
+constexpr bool epi_is_gelu(int e) { return e == EPI_BIAS_GELU || e == EPI_BIAS_GELU_SAVE || e == EPI_BIAS_GELU_SAVEG; }
+constexpr bool epi_is_save(int e) { return e == EPI_BIAS_GELU_SAVE || e == EPI_BIAS_GELU_SAVEG; }
+constexpr bool epi_is_dact(int e) { return e == EPI_DGELU || e == EPI_MUL; }
+// gelu(x) and gelu'(x) from one erf / exp
+__device__ __forceinline__ void gelu_pair(float x, float& gv, float& dv) {
+  float e;
+  const float er = fast_erf(x * 0.70710678118654752440f, e);
+  const float cdf = 0.5f * (1.0f + er);
+  gv = x * cdf;
+  dv = cdf + x * 0.3989422804014327f * e;
+}
 
 // SB = single LDS buffer: 34 KiB per block instead of 68, which lets THREE blocks share a CU (12 waves);
 // the tile for step kt+1 waits in registers while step kt computes, at the price of a second barrier.
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
     for (int u = 0; u < 2; ++u) {
       const int col = n0 + wn * 64 + u * 32 + fq * 8;
       float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+      if (epi_has_bias(EPI)) {
         if (p.bias != nullptr && col < p.N) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) bv[e] = bf2f(p.bias[col + e]);
@@ -264,15 +278,21 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bv[e];
         bf16x8 o8;
-        if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+        if (epi_is_gelu(EPI)) {
           bf16x8 pre;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { pre[e] = f2bf(v[e]); o8[e] = f2bf(gelu_exact(EPI == EPI_BIAS_GELU_SAVE ? bf2f(pre[e]) : v[e])); }
-          if (EPI == EPI_BIAS_GELU_SAVE) *(bf16x8*)(p.C2 + cbase + o) = pre;
-        } else if (EPI == EPI_DGELU) {
+          for (int e = 0; e < 8; ++e) {
+            pre[e] = f2bf(v[e]);
+            float gv, dv;
+            gelu_pair(epi_is_save(EPI) ? bf2f(pre[e]) : v[e], gv, dv);   // the activation of the value that is saved
+            o8[e] = f2bf(gv);
+            if (EPI == EPI_BIAS_GELU_SAVEG) pre[e] = f2bf(dv);
+          }
+          if (epi_is_save(EPI)) *(bf16x8*)(p.C2 + cbase + o) = pre;
+        } else if (epi_is_dact(EPI)) {
           const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * gelu_grad(bf2f(a[e])));
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
         } else if (EPI == EPI_ADD) {
           const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
 #pragma unroll
@@ -305,14 +325,14 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
   constexpr int CP = 136;
   bf16* st = lds;                          // 128*136*2 = 34816 B
   bf16* st2 = (SB || DMA) ? lds : lds + 128 * CP;   // pre-activation tile (SB/DMA: same buffer, emitted in a first pass)
-  constexpr bool TWO_PASS = (SB || DMA) && EPI == EPI_BIAS_GELU_SAVE;
+  constexpr bool TWO_PASS = (SB || DMA) && epi_is_save(EPI);
 #pragma unroll
   for (int pass = 0; pass < (TWO_PASS ? 2 : 1); ++pass) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int col = n0 + wn * 64 + j * 16 + fr;
       float bv = 0.f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE)
+      if (epi_has_bias(EPI))
         if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -320,13 +340,14 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
         for (int r = 0; r < 4; ++r) {
           int lr = wm * 64 + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
           float v = acc[i][j][r] + bv;
-          if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
-            if (EPI == EPI_BIAS_GELU_SAVE) {
-              bf16 pre = f2bf(v);
-              if (!TWO_PASS || pass == 0) st2[lr * CP + lc] = pre;
-              v = bf2f(pre);  // the activation is taken of the value that is actually saved
-            }
-            v = gelu_exact(v);
+          if (epi_is_gelu(EPI)) {
+            bf16 pre = f2bf(v);
+            if (epi_is_save(EPI)) v = bf2f(pre);  // the activation is taken of the value that is actually saved
+            float gv, dv;
+            gelu_pair(v, gv, dv);
+            if (EPI == EPI_BIAS_GELU_SAVEG) pre = f2bf(dv);
+            if (epi_is_save(EPI) && (!TWO_PASS || pass == 0)) st2[lr * CP + lc] = pre;
+            v = gv;
           }
           if (!TWO_PASS || pass == 1) st[lr * CP + lc] = f2bf(v);
         }
@@ -339,12 +360,12 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
       int row = m0 + lr, col = n0 + cc * 8;
       long o = (long)row * p.ldc + col;
       if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
-        if (EPI == EPI_DGELU) {
+        if (epi_is_dact(EPI)) {
           bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
           bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
           bf16x8 outv;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * gelu_grad(bf2f(a[e])));
+          for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
           *(bf16x8*)(Cb + o) = outv;
         } else if (EPI == EPI_ADD) {
           bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
           else *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
         } else {
           *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
-          if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+          if (epi_is_save(EPI)) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
         }
       }
     }
@@ -503,7 +524,7 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) 
     for (int j = 0; j < 4; ++j) {
       int col = n0 + wn * 64 + j * 16 + fr;
       float bv = 0.f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE)
+      if (epi_has_bias(EPI))
         if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -511,13 +532,14 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) 
         for (int r = 0; r < 4; ++r) {
           int lr = wm * (MI * 16) + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
           float v = acc[i][j][r] + bv;
-          if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
-            if (EPI == EPI_BIAS_GELU_SAVE) {
-              bf16 pre = f2bf(v);
-              st2[lr * CP + lc] = pre;
-              v = bf2f(pre);  // the activation is taken of the value that is actually saved
-            }
-            v = gelu_exact(v);
+          if (epi_is_gelu(EPI)) {
+            bf16 pre = f2bf(v);
+            if (epi_is_save(EPI)) v = bf2f(pre);  // the activation is taken of the value that is actually saved
+            float gv, dv;
+            gelu_pair(v, gv, dv);
+            if (EPI == EPI_BIAS_GELU_SAVEG) pre = f2bf(dv);
+            if (epi_is_save(EPI)) st2[lr * CP + lc] = pre;
+            v = gv;
           }
           st[lr * CP + lc] = f2bf(v);
         }
@@ -530,12 +552,12 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) 
     int row = m0 + lr, col = n0 + cc * 8;
     long o = (long)row * p.ldc + col;
     if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
-      if (EPI == EPI_DGELU) {
+      if (epi_is_dact(EPI)) {
         bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
         bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
         bf16x8 outv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * gelu_grad(bf2f(a[e])));
+        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
         *(bf16x8*)(Cb + o) = outv;
       } else if (EPI == EPI_ADD) {
         bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
@@ -546,7 +568,7 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) 
         *(bf16x8*)(Cb + o) = outv;
       } else {
         *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
-        if (EPI == EPI_BIAS_GELU_SAVE) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+        if (epi_is_save(EPI)) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
       }
     }
   }
@@ -698,7 +720,7 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, i
     for (int u = 0; u < 2; ++u) {
       const int col = n0 + wn * 64 + u * 32 + fq * 8;
       float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+      if (epi_has_bias(EPI)) {
         if (p.bias != nullptr && col < p.N) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) bv[e] = bf2f(p.bias[col + e]);   // N % 8 == 0 (host check)
@@ -721,15 +743,21 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bv[e];
         bf16x8 o8;
-        if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_SAVE) {
+        if (epi_is_gelu(EPI)) {
           bf16x8 pre;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { pre[e] = f2bf(v[e]); o8[e] = f2bf(gelu_exact(EPI == EPI_BIAS_GELU_SAVE ? bf2f(pre[e]) : v[e])); }
-          if (EPI == EPI_BIAS_GELU_SAVE) *(bf16x8*)(p.C2 + cbase + o) = pre;
-        } else if (EPI == EPI_DGELU) {
+          for (int e = 0; e < 8; ++e) {
+            pre[e] = f2bf(v[e]);
+            float gv, dv;
+            gelu_pair(epi_is_save(EPI) ? bf2f(pre[e]) : v[e], gv, dv);   // the activation of the value that is saved
+            o8[e] = f2bf(gv);
+            if (EPI == EPI_BIAS_GELU_SAVEG) pre[e] = f2bf(dv);
+          }
+          if (epi_is_save(EPI)) *(bf16x8*)(p.C2 + cbase + o) = pre;
+        } else if (epi_is_dact(EPI)) {
           const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * gelu_grad(bf2f(a[e])));
+          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
         } else if (EPI == EPI_ADD) {
           const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
 #pragma unroll
@@ -1134,8 +1162,8 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   if (d.epi == EPI_F32 ? !d.Cf : !d.C) return set_error("gemm_nt: null output");
   if ((d.ldc % 8) || (d.N % 8)) return set_error("gemm_nt: N and ldc must be multiples of 8");
   if (d.K % 8) return set_error("gemm_nt: K must be a multiple of 8");
-  if ((d.epi == EPI_DGELU || d.epi == EPI_ADD) && !d.aux) return set_error("gemm_nt: DGELU/ADD need aux");
-  if (d.epi == EPI_BIAS_GELU_SAVE && !d.C2) return set_error("gemm_nt: GELU_SAVE needs C2");
+  if ((epi_is_dact(d.epi) || d.epi == EPI_ADD) && !d.aux) return set_error("gemm_nt: DGELU/MUL/ADD need aux");
+  if (epi_is_save(d.epi) && !d.C2) return set_error("gemm_nt: GELU_SAVE / GELU_SAVEG need C2");
   GemmP p{};
   p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.C = (bf16*)d.C; p.C2 = (bf16*)d.C2; p.Cf = d.Cf;
   p.bias = (const bf16*)d.bias; p.aux = (const bf16*)d.aux;
@@ -1176,7 +1204,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     const double tk[3] = {0.74, 0.71, 0.62};
     for (int c = 0; c < 3; ++c) {
       const long t8 = (long)((d.N + 127) / 128) * ((d.M + hs[c] - 1) / hs[c]) * nbz;
-      const double t = (double)((t8 + 255) / 256) * (nkt * tk[c] + 7.5 + (d.epi == EPI_BIAS_GELU_SAVE ? 4.0 : 0.0));
+      const double t = (double)((t8 + 255) / 256) * (nkt * tk[c] + 7.5 + (epi_is_save(d.epi) ? 4.0 : 0.0));
       if (t < best) { best = t; mode = 3; lc_h = hs[c]; }
     }
   }
@@ -1211,6 +1239,8 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     case EPI_DGELU: NT_LAUNCH(EPI_DGELU); break;
     case EPI_F32: NT_LAUNCH(EPI_F32); break;
     case EPI_ADD: NT_LAUNCH(EPI_ADD); break;
+    case EPI_BIAS_GELU_SAVEG: NT_LAUNCH(EPI_BIAS_GELU_SAVEG); break;
+    case EPI_MUL: NT_LAUNCH(EPI_MUL); break;
     default: return set_error("gemm_nt: unknown epilogue");
   }
 #undef NT_LAUNCH

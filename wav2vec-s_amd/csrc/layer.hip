@@ -6,11 +6,13 @@
 // Post-LN layer (wav2vec-S base), fs/models/wav2vec/wav2vec2.py:955-976:
 //     a  = out_proj(attn(qkv(x)))            s1 = x + drop(a)      x1 = LN1(s1)
 //     f  = fc2(gelu(fc1(x1)))                s2 = x1 + drop(f)     y  = LN2(s2)
+// (the buffer called hpre holds gelu'(fc1 pre-activation), written by the forward's own erf evaluation)
 #include "w2vs_internal.h"
 
 namespace w2vs {
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6,
+       EPI_BIAS_GELU_SAVEG = 7, EPI_MUL = 8 };
 
 static int lin_fwd(const void* x, const void* w, const void* b, void* y, void* pre, int R, int N, int K, int epi, hipStream_t s) {
   GemmDesc d{};
@@ -90,7 +92,7 @@ int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
   n1.x = L.tmp; n1.res = xin; n1.gamma = L.ln1_g; n1.beta = L.ln1_b; n1.y = L.x1; n1.sum_out = L.s1;
   n1.mean = L.mean1; n1.rstd = L.rstd1; n1.rows = Rt; n1.C = E; n1.p_drop = L.p_drop; n1.seed = L.seed_drop1;
   TRY(ln_fwd(n1, s));
-  TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, Rt, F, E, EPI_BIAS_GELU_SAVE, s));
+  TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, Rt, F, E, EPI_BIAS_GELU_SAVEG, s));   // hpre <- gelu'(pre)
   TRY(lin_fwd(L.h, L.w2, L.b2, L.tmp, nullptr, Rt, E, F, EPI_BIAS, s));
   LnFwdDesc n2{};
   n2.x = L.tmp; n2.res = L.x1; n2.gamma = L.ln2_g; n2.beta = L.ln2_b; n2.y = L.x_out; n2.sum_out = L.s2;
@@ -122,7 +124,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
   TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, Rt, E, F, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w2, L.wt_scratch, E, F, 1, s));           // [E,F] -> [F,E]
-  TRY(lin_dgrad(L.ws_e0, pre_t ? L.w2_t : L.wt_scratch, L.ws_f, L.hpre, Rt, E, F, EPI_DGELU, s));
+  TRY(lin_dgrad(L.ws_e0, pre_t ? L.w2_t : L.wt_scratch, L.ws_f, L.hpre, Rt, E, F, EPI_MUL, s));
   // fc1: wgrad, bias, dgrad + residual branch -> d_x1 (ws_e2)
   TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, Rt, F, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));           // [F,E] -> [E,F]

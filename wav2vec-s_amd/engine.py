@@ -230,7 +230,9 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
             y, _, mean, rstd = ops.ln_fwd(c, W[_pname(i, "2.1.weight")], W[_pname(i, "2.1.bias")], gelu=True)
             rec.update(c=c, mean=mean, rstd=rstd)
         else:
-            y, pre = ops.conv_cl_fwd(x, w2, k, s, bias, gelu=True, save_pre=True)
+            # layers below the last save gelu'(pre) (the next layer's dgrad multiplies with it); the last one saves
+            # pre itself, which the feature LayerNorm backward differentiates through
+            y, pre = ops.conv_cl_fwd(x, w2, k, s, bias, gelu=True, save_pre=True, save_grad=(i < len(convs) - 1))
             rec.update(pre=pre)
         st.conv.append(rec)
         x = y
@@ -671,7 +673,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                           db_f32=A.view(_pname(i, "0.bias")) if _pname(i, "0.bias") in A else None)
         prev = st.conv[i - 1]
         prev_aux = prev.get("pre") if (i - 1 >= 1 and not prev["ln"]) else None
-        d_cur = ops.conv_cl_dgrad(d_c, st.packed[i], k, s, x_in.shape[1], dgelu_aux=prev_aux,
+        d_cur = ops.conv_cl_dgrad(d_c, st.packed[i], k, s, x_in.shape[1], mul_aux=prev_aux,
                                   wprep=getattr(st, "_dgrad_w", {}).get(i))
     dim0, k0, s0 = convs[0]
     r0 = st.conv[0]

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_NONE, AttnDesc,
+from ._lib import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_BIAS_GELU_SAVEG, EPI_DGELU, EPI_F32, EPI_MUL, EPI_NONE, AttnDesc,
                    EncPrologueDesc, GemmDesc, LnBwdDesc, LnFwdDesc, NceDesc, QuantDesc, W2vsError)
 
 BF16 = torch.bfloat16
@@ -192,21 +192,24 @@ def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB
     GEMM_TIMER.end(ev, "tn", 2.0 * M * N * K * batch)
 
 
-def linear_fwd(x, w, bias=None, *, gelu=False, save_pre=False):
-    """y = x @ w.T (+ bias) [gelu].  x [R, K] bf16, w [N, K] bf16.  Returns y (and pre if save_pre)."""
+def linear_fwd(x, w, bias=None, *, gelu=False, save_pre=False, save_grad=False):
+    """y = x @ w.T (+ bias) [gelu].  x [R, K] bf16, w [N, K] bf16.  Returns y (and pre if save_pre; with save_grad the
+    second tensor is gelu'(pre) instead, what a backward pass multiplies with)."""
     _chk(x, BF16, "x"); _chk(w, BF16, "w"); _chk(bias, BF16, "bias")
     R, K = x.shape
     N = w.shape[0]
     y = empty((R, N), BF16, x.device)
     pre = empty(y.shape, y.dtype, y.device) if save_pre else None
     epi = EPI_BIAS if not gelu else (EPI_BIAS_GELU_SAVE if save_pre else EPI_BIAS_GELU)
+    if gelu and save_pre and save_grad:
+        epi = EPI_BIAS_GELU_SAVEG
     gemm_nt(x, w, M=R, N=N, K=K, lda=K, ldb=K, ldc=N, out=y, out2=pre, bias=bias, epi=epi)
     return (y, pre) if save_pre else y
 
 
-def linear_dgrad(dy, w_t, *, dgelu_aux=None, add_aux=None):
-    """dx = dy @ w  given w_t = w.T contiguous ([K, N]).  Optionally dx *= gelu'(aux) or dx += add_aux."""
-    _chk(dy, BF16, "dy"); _chk(w_t, BF16, "w_t"); _chk(dgelu_aux, BF16, "aux"); _chk(add_aux, BF16, "aux")
+def linear_dgrad(dy, w_t, *, dgelu_aux=None, add_aux=None, mul_aux=None):
+    """dx = dy @ w  given w_t = w.T contiguous ([K, N]).  Optionally dx *= gelu'(aux), dx *= mul_aux or dx += add_aux."""
+    _chk(dy, BF16, "dy"); _chk(w_t, BF16, "w_t"); _chk(dgelu_aux, BF16, "aux"); _chk(add_aux, BF16, "aux"); _chk(mul_aux, BF16, "aux")
     R, N = dy.shape
     K = w_t.shape[0]
     dx = empty((R, K), BF16, dy.device)
@@ -215,6 +218,8 @@ def linear_dgrad(dy, w_t, *, dgelu_aux=None, add_aux=None):
         epi, aux = EPI_DGELU, dgelu_aux
     elif add_aux is not None:
         epi, aux = EPI_ADD, add_aux
+    elif mul_aux is not None:
+        epi, aux = EPI_MUL, mul_aux
     gemm_nt(dy, w_t, M=R, N=K, K=N, lda=N, ldb=N, ldc=K, out=dx, aux=aux, epi=epi)
     return dx
 
@@ -271,8 +276,9 @@ def conv_pack_weight(w):
     return transpose2d(w.view(Cout, Cin, k), batch=Cout).view(Cout, k * Cin)
 
 
-def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True):
-    """Channel-last Conv1d (no padding): x [B, Lin, Cin], w2 [Cout, k*Cin] -> [B, Lout, Cout]."""
+def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True, save_grad=False):
+    """Channel-last Conv1d (no padding): x [B, Lin, Cin], w2 [Cout, k*Cin] -> [B, Lout, Cout].  save_grad: the second
+    output is gelu'(pre) instead of pre."""
     _chk(x, BF16, "x"); _chk(w2, BF16, "w2")
     B, Lin, Cin = x.shape
     Cout = w2.shape[0]
@@ -280,7 +286,7 @@ def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True):
     y = empty((B, Lout, Cout), BF16, x.device)
     pre = empty(y.shape, y.dtype, y.device) if save_pre else None
     if gelu:
-        epi = EPI_BIAS_GELU_SAVE if save_pre else EPI_BIAS_GELU
+        epi = (EPI_BIAS_GELU_SAVEG if save_grad else EPI_BIAS_GELU_SAVE) if save_pre else EPI_BIAS_GELU
     else:
         epi = EPI_BIAS
     gemm_nt(x, w2, M=Lout, N=Cout, K=k * Cin, lda=s * Cin, ldb=k * Cin, ldc=Cout, out=y, out2=pre, bias=bias,
@@ -316,7 +322,7 @@ def conv_dgrad_weight_items(key, w2, k, s):
     raise W2vsError("conv dgrad is built for (k,s) in {(2,2),(3,2)}; got (%d,%d)" % (k, s))
 
 
-def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None, wprep=None):
+def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None, mul_aux=None, wprep=None):
     """Gradient wrt the channel-last input of conv_cl_fwd.  dy [B, Lout, Cout]; w2 [Cout, k*Cin] packed.
     (k, s) = (2, 2): non-overlapping windows -> plain GEMM into [B, Lout, 2*Cin].
     (k, s) = (3, 2): input rows pair up, pair p = [dy[p-1] | dy[p]] @ [[W2, 0], [W0, W1]]."""
@@ -325,6 +331,8 @@ def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None, wprep=None):
     Cin = w2.shape[1] // k
     dx = empty((B, Lin, Cin), BF16, dy.device)
     epi = EPI_DGELU if dgelu_aux is not None else EPI_NONE
+    if mul_aux is not None:          # mul_aux = gelu'(pre) saved by the producing layer's forward
+        epi, dgelu_aux = EPI_MUL, mul_aux
     if wprep is not None:
         wt = bt = wprep
     else:
