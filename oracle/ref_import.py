@@ -148,6 +148,42 @@ def load():
     return ns
 
 
+_RAIN = None
+
+
+def load_rain():
+    """The reference's streaming / fine-tune twin:
+    ``rain/layers/unidirect_w2v2_encoder.py`` imported unchanged from where it lies.  ``rain`` and
+    ``rain.layers`` are registered path-only (their ``__init__`` pulls in the transducer loss and
+    SimulEval agents); ``fairseq.options`` / ``fairseq.checkpoint_utils`` need omegaconf and are
+    imported-but-unused by that file, so two empty modules stand in for them."""
+    global _RAIN
+    if _RAIN is not None:
+        return _RAIN
+    load()
+    fairseq = sys.modules["fairseq"]
+    for n in ["options", "checkpoint_utils"]:
+        if "fairseq." + n not in sys.modules:
+            m = types.ModuleType("fairseq." + n)
+            sys.modules["fairseq." + n] = m
+            setattr(fairseq, n, m)
+    d = importlib.import_module("fairseq.data.dictionary")
+    sys.modules["fairseq.data"].Dictionary = d.Dictionary
+    fe = importlib.import_module("fairseq.models.fairseq_encoder")
+    sys.modules["fairseq.models"].FairseqEncoder = fe.FairseqEncoder
+    rain_root = os.path.join(REF_ROOT, "rain")
+    _pkg("rain", rain_root)
+    _pkg("rain.layers", os.path.join(rain_root, "layers"))
+    tw = importlib.import_module("rain.layers.unidirect_w2v2_encoder")
+    _RAIN = types.SimpleNamespace(
+        module=tw,
+        BlockWiseWav2Vec2Model=tw.BlockWiseWav2Vec2Model,
+        OnlineW2V2TransformerEncoder=tw.OnlineW2V2TransformerEncoder,
+        gen_block_atten_mask=tw.gen_block_atten_mask,
+    )
+    return _RAIN
+
+
 def make_cfg(ref, **overrides):
     """Wav2VecSConfig with the base yaml's model overrides
     (fairseq/examples/wav2vec/config/pretraining/wav2vec-S_base_librispeech.yaml:50-77)."""

@@ -420,6 +420,61 @@ def forward_loss(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCf
     return out
 
 
+def frame_padding_mask(padding_mask: torch.Tensor, T: int) -> torch.Tensor:
+    """Sample-level -> frame-level padding mask, fs/models/wav2vec/wav2vec2.py:560-565 and
+    rain/layers/unidirect_w2v2_encoder.py:500-505."""
+    extra = padding_mask.size(1) % T
+    if extra > 0:
+        padding_mask = padding_mask[:, :-extra]
+    return padding_mask.view(padding_mask.size(0), T, -1).all(-1)
+
+
+def streaming_encoder_forward(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCfg, *,
+                              main_context: int, right_context: int, padding_mask: Optional[torch.Tensor] = None,
+                              finished: bool = False, is_infer: bool = False,
+                              layer_keep: Optional[List[bool]] = None):
+    """Row f1: BlockWiseWav2Vec2Model.forward (rain/layers/unidirect_w2v2_encoder.py:485-531) through
+    BlockwiseW2V2TransformerEncoder.forward / extract_features (:245-330): conv extractor, feature
+    LayerNorm, post_extract_proj, block-wise encoder with constant contexts, NO masking and NO
+    quantizer.  Returns (x [T, B, C], padding_mask [B, T] bool); with ``is_infer and not finished``
+    the last ``right_context`` frames are withheld (:326-328).  Dropouts are the identity (eval)."""
+    feats = conv_feature_extractor(source, P, cfg)
+    if cfg.feature_grad_mult != 1.0:                       # :486-489 GradMultiply: identity fwd, grad * scale
+        s = cfg.feature_grad_mult
+        feats = feats * s + (feats * (1.0 - s)).detach()
+    feats = feats.transpose(1, 2)
+    B, T, C0 = feats.shape
+    feats = F.layer_norm(feats, (C0,), P["layer_norm.weight"], P["layer_norm.bias"], 1e-5)
+    pmf = frame_padding_mask(padding_mask, T) if padding_mask is not None else None
+    if "post_extract_proj.weight" in P:
+        x = F.linear(feats, P["post_extract_proj.weight"], P["post_extract_proj.bias"])
+    else:
+        x = feats
+    x = blockwise_encoder(x, P, cfg, main_context, right_context, pmf, layer_keep)   # B x T x C
+    x = x.transpose(0, 1)
+    pad = pmf if pmf is not None else torch.zeros(B, T, dtype=torch.bool)            # :83-84, :319, :324
+    if is_infer and not finished and right_context > 0:
+        x = x[:-right_context]
+        pad = pad[:, :-right_context]
+    return x, pad
+
+
+def online_encoder_forward(P: Dict[str, torch.Tensor], src_tokens: torch.Tensor, src_lengths: torch.Tensor,
+                           cfg: OracleCfg, *, main_context: int, right_context: int, finished: bool = False,
+                           is_infer: bool = False, prefix: str = "w2v2_model."):
+    """OnlineW2V2TransformerEncoder.forward (rain/layers/unidirect_w2v2_encoder.py:587-611): lengths ->
+    padding mask (fs/data/data_utils.py:528-532), the twin, optional ``encoder_proj``.  P holds the
+    module's own state_dict keys (``w2v2_model.*``, ``encoder_proj.*``)."""
+    L = int(src_lengths.max())
+    pm = torch.arange(L).view(1, L).expand(src_lengths.numel(), -1) >= src_lengths.view(-1, 1)
+    Pw = {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
+    x, pad = streaming_encoder_forward(Pw, src_tokens, cfg, main_context=main_context, right_context=right_context,
+                                       padding_mask=pm, finished=finished, is_infer=is_infer)
+    if "encoder_proj.weight" in P:
+        x = F.linear(x, P["encoder_proj.weight"], P["encoder_proj.bias"])
+    return x, pad
+
+
 def init_params(cfg: OracleCfg, seed: int = 1) -> Dict[str, torch.Tensor]:
     """Seeded random parameters with the reference's key names/shapes (SURVEY.md section
     8a 'Parameter inventory') and init distributions (kaiming-normal convs

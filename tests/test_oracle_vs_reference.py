@@ -86,3 +86,32 @@ def test_base_model_matches_reference(train):
             scale = float(want.abs().max())
             err = float((got - want).abs().max())
             assert err <= 2e-3 * scale + 1e-5, (n, err, scale)
+
+
+def test_streaming_twin_matches_reference_full_width():
+    """Row f1: the reference's BlockWiseWav2Vec2Model (rain/layers/unidirect_w2v2_encoder.py) at base width on a
+    padded batch, unfinished streaming call included."""
+    import argparse
+    warnings.simplefilter("ignore")
+    rain = ref_import.load_rain()
+    kw = dict(extractor_mode="layer_norm", encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,
+              encoder_attention_heads=12, final_dim=256, quantize_targets=True, feature_grad_mult=0.1, dropout=0.0,
+              attention_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0,
+              conv_feature_layers="[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 2", main_context=16,
+              right_context=8, pos_type="sin", load_pretrained_model_from=None)
+    torch.manual_seed(3)
+    model = rain.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(**kw)).eval()
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    src = torch.randn(2, 20000)
+    pm = torch.zeros(2, 20000, dtype=torch.bool)
+    pm[1, 13000:] = True
+    src[pm] = 0
+    ocfg = O.OracleCfg(**{k: v for k, v in kw.items() if k in O.OracleCfg.__dataclass_fields__})
+    with torch.no_grad():
+        for finished, is_infer in ((False, False), (False, True)):
+            r = model(src, pm, None, finished, is_infer)
+            x, pad = O.streaming_encoder_forward(P, src, ocfg, main_context=16, right_context=8, padding_mask=pm,
+                                                 finished=finished, is_infer=is_infer)
+            assert torch.equal(pad, r["encoder_padding_mask"][0])
+            valid = ~pad.transpose(0, 1)
+            np.testing.assert_allclose(x[valid].numpy(), r["encoder_out"][0][valid].numpy(), atol=5e-4)

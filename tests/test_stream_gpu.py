@@ -1,0 +1,182 @@
+"""Row f1 on the GPU: the streaming / fine-tune encoder twin (wav2vec_s_amd.streaming, bf16 HIP kernels)
+against (a) the golden vectors recorded from the real reference and (b) the fp32 oracle at full width.
+Needs an MI355X: pytest -m gpu
+
+Tolerances: padding masks / shapes / gradient presence bit-exact; activations within 2e-2 relative
+Frobenius over the valid frames; the linear functional within 1e-2 of its gradient-norm scale."""
+import argparse
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import w2vs_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a = a.detach().float().cpu()
+    b = torch.as_tensor(b).detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _valid(pad):
+    return ~torch.as_tensor(pad).transpose(0, 1)            # T x B
+
+
+def _grad_report(named_params, want_of, has_of):
+    errs = {}
+    for n, p in named_params:
+        want, has = want_of(n), has_of(n)
+        if not has:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        want = torch.as_tensor(want)
+        if "k_proj.bias" in n:      # analytically zero gradient (softmax shift invariance): rounding noise on both sides
+            continue
+        errs[n] = rel(p.grad, want) if float(want.norm()) > 1e-6 else float(p.grad.float().norm())
+    return errs
+
+
+def test_twin_matches_reference_golden(golden_dir):
+    from wav2vec_s_amd import streaming
+    z = np.load(os.path.join(golden_dir, "stream_twin.npz"))
+    over = ast.literal_eval(bytes(z["cfg_json"]).decode())
+    model = streaming.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(**over))
+    sd = {k[len("param."):]: torch.tensor(z[k]) for k in z.files if k.startswith("param.")}
+    assert set(sd) == set(model.state_dict())               # checkpoint interchange: identical keys
+    model.load_state_dict(sd)
+    model = model.cuda().train()                            # fp32 parameters, bf16 compute
+    src, pm = torch.tensor(z["source"]).cuda(), torch.tensor(z["padding_mask"]).cuda()
+    res = model(src, pm)
+    x, pad = res["encoder_out"][0], res["encoder_padding_mask"][0]
+    assert sorted(res) == sorted(["encoder_out", "encoder_padding_mask", "encoder_embedding", "encoder_states",
+                                  "src_tokens", "src_lengths", "dec1_state", "dec1_padding_mask"])
+    assert tuple(x.shape) == z["x_full"].shape and np.array_equal(pad.cpu().numpy(), z["pad_full"])
+    v = _valid(z["pad_full"])
+    assert rel(x[v.cuda()], z["x_full"][v.numpy()]) < 2e-2
+    valid = (~pad).transpose(0, 1).unsqueeze(-1).to(x.dtype)
+    loss = (x * torch.tensor(z["w"]).cuda().to(x.dtype) * valid).sum()
+    loss.backward()
+    errs = _grad_report(model.named_parameters(), lambda n: z["grad." + n], lambda n: bool(z["hasgrad." + n][0]))
+    assert len(errs) > 50
+    assert float(np.median(list(errs.values()))) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert max(errs.values()) < 0.15, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # streaming calls: unfinished (right context withheld), finished, un-padded prefix with odd T
+    model.eval()
+    with torch.no_grad():
+        for tag, args in (("infer", (src, pm, None, False, True)), ("finished", (src, pm, None, True, True)),
+                          ("prefix", (src[:, :9000],)), ("prefix_infer", (src[:, :9000], None, None, False, True))):
+            r = model(*args)
+            xx, pp = r["encoder_out"][0], r["encoder_padding_mask"][0]
+            assert tuple(xx.shape) == z["x_" + tag].shape, tag
+            assert pp.dtype == torch.bool and np.array_equal(pp.cpu().numpy(), z["pad_" + tag]), tag
+            v = _valid(z["pad_" + tag])
+            assert rel(xx[v.cuda()], z["x_" + tag][v.numpy()]) < 2e-2, tag
+
+
+def _online_from_golden(z, tmp_path):
+    from wav2vec_s_amd import streaming
+    over = ast.literal_eval(bytes(z["cfg_json"]).decode())
+    args = ast.literal_eval(bytes(z["args_json"]).decode())
+    sd = {k[len("param."):]: torch.tensor(z[k]) for k in z.files if k.startswith("param.")}
+    w2v = {k[len("w2v2_model."):]: v for k, v in sd.items() if k.startswith("w2v2_model.")}
+    path = os.path.join(tmp_path, "ckpt.pt")
+    torch.save({"args": None, "cfg": {"model": dict(over)}, "model": w2v}, path)     # a fairseq-style checkpoint
+    enc = streaming.OnlineW2V2TransformerEncoder(argparse.Namespace(w2v2_model_path=path, **args))
+    assert set(enc.state_dict()) == set(sd)
+    with torch.no_grad():
+        enc.encoder_proj.weight.copy_(sd["encoder_proj.weight"])
+        enc.encoder_proj.bias.copy_(sd["encoder_proj.bias"])
+    for k, v in enc.w2v2_model.state_dict().items():
+        assert torch.equal(v, w2v[k]), k                    # the checkpoint was really loaded
+    return enc.cuda(), over, args
+
+
+def test_online_encoder_from_checkpoint_freeze_and_proj(golden_dir, tmp_path):
+    z = np.load(os.path.join(golden_dir, "stream_online.npz"))
+    enc, over, args = _online_from_golden(z, str(tmp_path))
+    assert enc.init_frames == int(z["init_frames"][0]) and enc.step_frames == int(z["step_frames"][0])
+    assert enc.w2v2_model.cfg.main_context == args["main_context"]        # the caller's contexts win over the checkpoint's
+    src, lens = torch.tensor(z["source"]).cuda(), torch.tensor(z["src_lengths"]).cuda()
+    enc.train()
+    for tag, upd in (("frozen", 0), ("tuned", 5)):
+        enc.set_num_updates(upd)
+        enc.zero_grad()
+        res = enc(src, lens)
+        x, pad = res["encoder_out"][0], res["encoder_padding_mask"][0]
+        assert tuple(x.shape) == z[tag + ".x"].shape and np.array_equal(pad.cpu().numpy(), z[tag + ".pad"])
+        v = _valid(z[tag + ".pad"])
+        assert rel(x[v.cuda()], z[tag + ".x"][v.numpy()]) < 2e-2
+        valid = (~pad).transpose(0, 1).unsqueeze(-1).to(x.dtype)
+        loss = (x * torch.tensor(z["w"]).cuda().to(x.dtype) * valid).sum()
+        loss.backward()
+        errs = _grad_report(enc.named_parameters(), lambda n: z[f"{tag}.grad.{n}"],
+                            lambda n: bool(z[f"{tag}.hasgrad.{n}"][0]))
+        if tag == "frozen":
+            assert sorted(errs) == ["encoder_proj.bias", "encoder_proj.weight"]
+        else:
+            assert len(errs) > 40
+        assert float(np.median(list(errs.values()))) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+        assert max(errs.values()) < 0.15, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    enc.eval()
+    with torch.no_grad():
+        r = enc(src, lens, None, False, True)
+        order = torch.tensor(z["reorder.order"]).cuda()
+        ro = enc.reorder_encoder_out(r, order)
+    assert np.array_equal(r["encoder_padding_mask"][0].cpu().numpy(), z["infer.pad"])
+    v = _valid(z["infer.pad"])
+    assert rel(r["encoder_out"][0][v.cuda()], z["infer.x"][v.numpy()]) < 2e-2
+    assert tuple(ro["encoder_out"][0].shape) == z["reorder.x"].shape
+    assert np.array_equal(ro["encoder_padding_mask"][0].cpu().numpy(), z["reorder.pad"])
+    assert torch.equal(ro["encoder_out"][0], r["encoder_out"][0].index_select(1, order))
+
+
+def test_twin_full_width_padded_batch_matches_oracle():
+    """Base width (12 x 768, 12 heads, conv 512), padded batch of 3, m=16 / r=8: forward + backward against the fp32
+    oracle on the bf16-rounded parameters."""
+    from wav2vec_s_amd import streaming
+    kw = dict(extractor_mode="layer_norm", encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,
+              encoder_attention_heads=12, final_dim=256, quantize_targets=True, feature_grad_mult=0.1,
+              dropout=0.0, attention_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0,
+              conv_feature_layers="[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 2", main_context=16,
+              right_context=8, pos_type="sin", load_pretrained_model_from=None)
+    torch.manual_seed(5)
+    model = streaming.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(**kw)).to(BF)
+    P = {k: v.float().clone().requires_grad_(v.dtype == BF) for k, v in model.state_dict().items()}
+    B, L = 3, 48000
+    g = torch.Generator().manual_seed(6)
+    src = torch.randn(B, L, generator=g).to(BF)
+    pm = torch.zeros(B, L, dtype=torch.bool)
+    pm[1, 40000:] = True
+    pm[2, 23456:] = True
+    src[pm] = 0
+    ocfg = O.OracleCfg(**{k: v for k, v in kw.items() if k in O.OracleCfg.__dataclass_fields__})
+    xr, padr = O.streaming_encoder_forward(P, src.float(), ocfg, main_context=16, right_context=8, padding_mask=pm)
+    w = torch.randn(xr.shape, generator=g)
+    validr = (~padr).transpose(0, 1).unsqueeze(-1).float()
+    (xr * w * validr).sum().backward()
+    model = model.cuda().train()
+    res = model(src.cuda(), pm.cuda())
+    x, pad = res["encoder_out"][0], res["encoder_padding_mask"][0]
+    assert torch.equal(pad.cpu(), padr) and tuple(x.shape) == tuple(xr.shape)
+    v = _valid(padr)
+    assert rel(x[v.cuda()], xr.detach()[v]) < 2e-2
+    (x * w.cuda().to(BF) * validr.cuda().to(BF)).sum().backward()
+    errs = _grad_report(model.named_parameters(), lambda n: P[n].grad, lambda n: P[n].grad is not None)
+    assert float(np.median(list(errs.values()))) < 4e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert max(errs.values()) < 0.2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # a growing prefix, as the SimulEval agent feeds it: frames emitted for a prefix never change afterwards
+    # (their whole receptive field - own block, all earlier blocks, own right context - is inside the prefix)
+    model.eval()
+    with torch.no_grad():
+        full = model(src[:1].cuda(), None, None, True, True)["encoder_out"][0]
+        part = model(src[:1, :24000].cuda(), None, None, False, True)["encoder_out"][0]
+    n_blocks = part.shape[0] // 16
+    assert n_blocks >= 3
+    assert rel(part[:n_blocks * 16], full[:n_blocks * 16]) < 1e-2

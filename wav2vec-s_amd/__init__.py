@@ -11,6 +11,9 @@ def __getattr__(name):  # lazy: model/criterion import torch + the HIP library
                 "EXTRACTOR_MODE_CHOICES", "MASKING_DISTRIBUTION_CHOICES", "LAYER_TYPE_CHOICES"):
         from . import model
         return getattr(model, name)
+    if name in ("BlockWiseWav2Vec2Model", "OnlineW2V2TransformerEncoder", "gen_block_atten_mask", "HipLinear"):
+        from . import streaming      # row f1: rain/layers/unidirect_w2v2_encoder.py
+        return getattr(streaming, name)
     if name == "Wav2vecCriterion":
         from .criterion import Wav2vecCriterion
         return Wav2vecCriterion
