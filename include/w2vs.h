@@ -31,7 +31,7 @@ extern "C" {
 int w2vs_abi_version(void);
 const char* w2vs_last_error(void);
 /* sizeof() of the descriptor structs as compiled, so a binding can verify its mirror:
- * which = 0 gemm, 1 ln_fwd, 2 ln_bwd, 3 enc_prologue, 4 attn, 5 quant, 6 nce, 7 layer */
+ * which = 0 gemm, 1 ln_fwd, 2 ln_bwd, 3 enc_prologue, 4 attn, 5 quant, 6 nce, 7 layer, 8 collate */
 int w2vs_sizeof(int which);
 
 /* ---- GEMM family ----------------------------------------------------------------------------
@@ -255,6 +255,32 @@ int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, in
 int w2vs_sumsq(const float* x, int64_t n, float* out, void* stream);
 /* out[n] += sum_m in[m, n] : bias gradients */
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* stream);
+
+/* ---- input side --------------------------------------------------
+ * w2vs_batch_by_size: HOST function, no GPU work.  fs/data/data_utils_fast.pyx:19-98 batch_by_size_vec
+ * (the Cython batcher behind fs/data/data_utils.py:281-355 and FairseqDataset.batch_by_size,
+ * fs/data/fairseq_dataset.py:104-153).  num_tokens[n] (host) = the sizes of the ordered indices; batch_ends[n]
+ * (host, out) receives the exclusive end position of every batch, *n_batches their count; the batches are
+ * indices[0:e0], indices[e0:e1], ...  max_tokens / max_sentences <= 0 = unlimited; bsz_mult >= 1.
+ * Returns W2VS_ERR_INVALID when a single sample exceeds max_tokens (the reference asserts, :30-32).   */
+int w2vs_batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens, int64_t max_sentences,
+                       int32_t bsz_mult, int32_t* batch_ends, int32_t* n_batches);
+
+/* w2vs_collate: RawAudioDataset.collater (fs/data/audio/raw_audio_dataset.py:123-192) for one batch, with
+ * postprocess's per-utterance normalisation (:60-72: F.layer_norm(feats, feats.shape), eps 1e-5, over the WHOLE
+ * utterance, before any crop) folded in.  flat = the batch's utterances back to back as read from disk (fp32);
+ * row b of out is utterance b cropped to [crop_start[b], crop_start[b] + target) when it is longer than target
+ * (crop_to_max_size :73-81; the start is the caller's np.random.randint draw), copied when equal, and zero-padded
+ * with padding_mask = 1 when shorter (pad=True datasets).  Rows are `width` >= target long; columns past target are
+ * padding too (bucketed batch shapes, :157-167).  out: bf16 [B, width] (out_f32 = 0) or fp32 (1); padding_mask: uint8
+ * [B, width] or NULL; partial: scratch, >= B * w2vs_collate_chunks(max_size) * 2 doubles (normalize only).        */
+typedef struct w2vs_collate_desc {
+  const float* flat; const int64_t* offset; const int32_t* size; const int32_t* crop_start;
+  void* out; uint8_t* padding_mask; double* partial;
+  int32_t B, target, width, max_size, normalize, out_f32;
+} w2vs_collate_desc;
+int32_t w2vs_collate_chunks(int32_t max_size);
+int w2vs_collate(const w2vs_collate_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -184,6 +184,42 @@ def load_rain():
     return _RAIN
 
 
+_DATA = None
+
+
+def load_data():
+    """The reference's input side: ``fs/data/audio/raw_audio_dataset.py`` imported
+    unchanged, plus - when ``oracle/_ref`` holds it (``make -C oracle ref``) - the reference's own Cython batcher
+    ``data_utils_fast`` compiled from ``fs/data/data_utils_fast.pyx``."""
+    global _DATA
+    if _DATA is not None:
+        return _DATA
+    load()
+    data = sys.modules["fairseq.data"]
+    fd = importlib.import_module("fairseq.data.fairseq_dataset")
+    data.FairseqDataset = fd.FairseqDataset
+    bw = importlib.import_module("fairseq.data.base_wrapper_dataset")
+    data.BaseWrapperDataset = bw.BaseWrapperDataset
+    _pkg("fairseq.data.audio", os.path.join(FS, "data", "audio"))
+    rad = importlib.import_module("fairseq.data.audio.raw_audio_dataset")
+    fast = None
+    ref_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+    if os.path.isdir(ref_dir):
+        sys.path.insert(0, ref_dir)
+        try:
+            fast = importlib.import_module("data_utils_fast")
+        except ImportError:
+            fast = None
+        finally:
+            sys.path.remove(ref_dir)
+    if fast is not None:
+        sys.modules["fairseq.data.data_utils_fast"] = fast     # what fs/data/data_utils.py:311-315 imports
+    _DATA = types.SimpleNamespace(raw_audio_dataset=rad, RawAudioDataset=rad.RawAudioDataset,
+                                  FileAudioDataset=rad.FileAudioDataset, data_utils=sys.modules["fairseq.data.data_utils"],
+                                  data_utils_fast=fast)
+    return _DATA
+
+
 def make_cfg(ref, **overrides):
     """Wav2VecSConfig with the base yaml's model overrides
     (fairseq/examples/wav2vec/config/pretraining/wav2vec-S_base_librispeech.yaml:50-77)."""

@@ -475,6 +475,86 @@ def online_encoder_forward(P: Dict[str, torch.Tensor], src_tokens: torch.Tensor,
     return x, pad
 
 
+# ----------------------------------------------------------------------------------
+# input side
+# ----------------------------------------------------------------------------------
+def batch_by_size_vec(indices: np.ndarray, num_tokens_vec: np.ndarray, max_tokens: int, max_sentences: int,
+                      bsz_mult: int) -> List[np.ndarray]:
+    """fs/data/data_utils_fast.pyx:19-98 restated as a plain Python loop (small cases only).
+    Pinned against the reference's own compiled Cython (oracle/_ref, ``make -C oracle ref``) and the
+    vectors recorded from it (tests/golden/data_side.npz)."""
+    n = len(indices)
+    if n == 0:
+        return []
+    assert max_tokens <= 0 or int(np.max(num_tokens_vec)) <= max_tokens, \
+        f"Sentences lengths should not exceed max_tokens={max_tokens}"
+    ends = [0] * (n + 1)
+    count = 0            # index of the running batch
+    start = 0            # where the running batch begins
+    tail_max = 0         # longest sample in the not-yet-committed tail
+    batch_max = 0        # longest sample in the committed part of the running batch
+    for pos in range(n):
+        tail_max = max(tail_max, int(num_tokens_vec[pos]))
+        new_end = pos + 1
+        new_max = max(batch_max, tail_max)
+        sentences = new_end - start
+        overflow = (max_sentences > 0 and sentences > max_sentences) or (max_tokens > 0 and sentences * new_max > max_tokens)
+        mult_ok = sentences < bsz_mult or sentences % bsz_mult == 0
+        if overflow:
+            if max_tokens > 0 and tail_max * (new_end - ends[count]) > max_tokens:
+                count += 1                      # the tail alone overflows: close it before this sample
+                ends[count] = pos
+                tail_max = int(num_tokens_vec[pos])
+            start = ends[count]
+            count += 1
+            new_max = tail_max
+        if overflow or mult_ok:
+            ends[count] = new_end
+            batch_max = new_max
+            tail_max = 0
+    if ends[count] != n:
+        count += 1
+    return np.split(np.asarray(indices), np.asarray(ends[:count], dtype=np.int64))
+
+
+def ordered_indices(sizes, shuffle: bool = True) -> np.ndarray:
+    """RawAudioDataset.ordered_indices, fs/data/audio/raw_audio_dataset.py:214-224: a random permutation
+    (numpy global generator) as the tie-break key, sizes as the primary key, longest first."""
+    n = len(sizes)
+    order = [np.random.permutation(n)] if shuffle else [np.arange(n)]
+    order.append(sizes)
+    return np.lexsort(order)[::-1]
+
+
+def collate(sources: List[torch.Tensor], *, pad: bool, max_sample_size: int, normalize: bool = False):
+    """RawAudioDataset.collater (raw_audio_dataset.py:123-156) with postprocess's normalisation (:60-72:
+    ``F.layer_norm(feats, feats.shape)`` over the whole utterance, before any crop).  Consumes
+    ``np.random.randint(0, diff + 1)`` once per utterance longer than the target (:73-81), in order.
+    Returns (source [B, target] fp32, padding_mask [B, target] bool or None, crop starts)."""
+    if normalize:
+        sources = [F.layer_norm(s.float(), s.shape) for s in sources]
+    sizes = [len(s) for s in sources]
+    target = min(max(sizes), max_sample_size) if pad else min(min(sizes), max_sample_size)
+    out = sources[0].new_zeros(len(sources), target)
+    pm = torch.zeros(out.shape, dtype=torch.bool) if pad else None
+    starts = []
+    for i, (src, size) in enumerate(zip(sources, sizes)):
+        diff = size - target
+        if diff == 0:
+            out[i] = src
+            starts.append(0)
+        elif diff < 0:
+            assert pad
+            out[i, :size] = src
+            pm[i, diff:] = True
+            starts.append(0)
+        else:
+            st = int(np.random.randint(0, diff + 1))
+            out[i] = src[st:st + target]
+            starts.append(st)
+    return out, pm, starts
+
+
 def init_params(cfg: OracleCfg, seed: int = 1) -> Dict[str, torch.Tensor]:
     """Seeded random parameters with the reference's key names/shapes (SURVEY.md section
     8a 'Parameter inventory') and init distributions (kaiming-normal convs

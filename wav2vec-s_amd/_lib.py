@@ -79,7 +79,12 @@ class LayerDesc(C.Structure):
                                                                             ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp)])
 
 
-_DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc]
+class CollateDesc(C.Structure):
+    _fields_ = [("flat", vp), ("offset", vp), ("size", vp), ("crop_start", vp), ("out", vp), ("padding_mask", vp),
+                ("partial", vp), ("B", i32), ("target", i32), ("width", i32), ("max_size", i32), ("normalize", i32), ("out_f32", i32)]
+
+
+_DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc, CollateDesc]
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_ADD, EPI_BIAS_GELU_SAVEG, EPI_MUL = range(9)
 
@@ -115,6 +120,9 @@ _SIGS = {
     "w2vs_dropout": [vp, vp, i64, f32, u64, vp],
     "w2vs_adam_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp],
     "w2vs_sumsq": [vp, i64, vp, vp],
+    "w2vs_batch_by_size": [vp, i64, i64, i64, i32, vp, vp],
+    "w2vs_collate_chunks": [i32],
+    "w2vs_collate": [C.POINTER(CollateDesc), vp],
 }
 EXPORTS = ["w2vs_abi_version", "w2vs_last_error", "w2vs_sizeof"] + list(_SIGS)
 

@@ -30,6 +30,7 @@ int w2vs_sizeof(int which) {
     case 5: return (int)sizeof(w2vs_quant_desc);
     case 6: return (int)sizeof(w2vs_nce_desc);
     case 7: return (int)sizeof(w2vs_layer_desc);
+    case 8: return (int)sizeof(w2vs_collate_desc);
   }
   return -1;
 }
@@ -80,6 +81,12 @@ int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, in
                    float wd, int32_t step, const float* scale_dev, float scale_host, void* s) {
   return adam_step(p32, p16, m, v, g, n, lr, b1, b2, eps, wd, step, scale_dev, scale_host, ST(s));
 }
+int w2vs_batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens, int64_t max_sentences, int32_t bsz_mult,
+                       int32_t* batch_ends, int32_t* n_batches) {
+  return batch_by_size(num_tokens, n, max_tokens, max_sentences, bsz_mult, batch_ends, n_batches);
+}
+int32_t w2vs_collate_chunks(int32_t max_size) { return collate_chunks(max_size); }
+int w2vs_collate(const w2vs_collate_desc* d, void* s) { NONNULL(d); return collate(*d, ST(s)); }
 int w2vs_sumsq(const float* x, int64_t n, float* out, void* s) { return sumsq(x, n, out, ST(s)); }
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* s) { return colsum(in, out, M, N, ld, ST(s)); }
 }

@@ -58,6 +58,11 @@ int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t 
 int transpose_multi(const w2vs_transpose_item* items, int n, hipStream_t st);
 int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st);
 int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream_t st);
+// data.hip (row f3)
+int batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens, int64_t max_sentences, int32_t bsz_mult,
+                  int32_t* ends, int32_t* n_batches);
+int collate_chunks(int max_size);
+int collate(const w2vs_collate_desc& d, hipStream_t st);
 int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n, float lr, float b1, float b2, float eps,
               float wd, int step, const float* scale_dev, float scale_host, hipStream_t st);
 int sumsq(const float* x, long n, float* out, hipStream_t st);
