@@ -158,3 +158,21 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "w2vs_oracle" not in src and "ref_import" not in src, fn
+
+
+def test_rnnt_header_symbols_are_exported():
+    """Every function include/w2vs_rnnt.h declares (the reference's warp_transducer/include/rnnt.h names + additions)
+    is exported by libw2vs.so."""
+    import ctypes
+    import re
+    from wav2vec_s_amd import _lib, transducer
+    hdr = open(os.path.join(ROOT, "include", "w2vs_rnnt.h")).read()
+    names = set(re.findall(r"\b(?:rnntStatus_t|int|const char\*)\s+(\w+)\s*\(", hdr))
+    assert {"compute_rnnt_loss", "compute_rnnt_delay_loss", "get_workspace_size", "get_delay_workspace_size",
+            "get_warprnnt_version", "rnntGetStatusString", "w2vs_rnnt_forward_async", "w2vs_rnnt_backward_async",
+            "w2vs_rnnt_delay_values"} <= names
+    assert names == set(transducer.RNNT_EXPORTS)
+    lib = _lib.load()
+    for n in names:
+        getattr(lib, n)
+    assert ctypes.sizeof(transducer.RnntOptions) == 32

@@ -1,0 +1,218 @@
+"""Row f4 on the GPU: the HIP transducer loss (csrc/rnnt.hip) through the reference's own C interface
+(include/w2vs_rnnt.h = warp_transducer/include/rnnt.h) and through the PyTorch front end mirror, against
+ (a) the known answers the reference's tests hold, (b) the reference's CPU implementation compiled into oracle/_ref,
+ (c) the float64 oracle restatement of the CUDA kernels, (d) size-independent properties at a realistic size.
+Needs an MI355X: pytest -m gpu.   Tolerance: 1e-4 (what the reference's tests use), fp32 arithmetic."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rnnt_oracle as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ka(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "rnnt_known_answers.json")))
+
+
+def _dev(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def _c_api(acts, labels, xl, yl, blank=0, delay=None, delay_scale=1.0, smooth=1.0, want_grad=True):
+    """Drive the reference-named entry points exactly as warp_transducer/tests/test_delay.cu does."""
+    from wav2vec_s_amd import transducer as tr
+    lib = tr._rnnt_lib()
+    B, T, U, V = acts.shape
+    a = _dev(acts, torch.float32)
+    g = torch.full_like(a, float("nan")) if want_grad else None
+    lab, x, y = _dev(labels, torch.int32), _dev(xl, torch.int32), _dev(yl, torch.int32)
+    if lab.numel() == 0:                              # U = 1: no labels, but the interface (like the reference's) wants a pointer
+        lab = torch.zeros(1, dtype=torch.int32, device="cuda")
+    size = C.c_size_t(0)
+    opt = tr.RnntOptions(1, 1, torch.cuda.current_stream().cuda_stream, blank, T, U, False)
+    if delay is None:
+        assert lib.get_workspace_size(T, U, B, True, C.byref(size), 4) == 0
+        ws = torch.empty(size.value, dtype=torch.uint8, device="cuda")
+        costs = np.zeros(B, dtype=np.float32)
+        rc = lib.compute_rnnt_loss(a.data_ptr(), g.data_ptr() if want_grad else None, lab.data_ptr(), y.data_ptr(), x.data_ptr(),
+                                   V, B, costs.ctypes.data, ws.data_ptr(), opt)
+    else:
+        assert lib.get_delay_workspace_size(T, U, B, True, C.byref(size), 4) == 0
+        ws = torch.empty(size.value, dtype=torch.uint8, device="cuda")
+        costs = np.zeros(3 * B, dtype=np.float32)
+        dv = _dev(delay, torch.float32)
+        rc = lib.compute_rnnt_delay_loss(a.data_ptr(), g.data_ptr() if want_grad else None, lab.data_ptr(), y.data_ptr(),
+                                         x.data_ptr(), dv.data_ptr(), V, B, costs.ctypes.data, ws.data_ptr(), delay_scale,
+                                         smooth, opt)
+    assert rc == 0, lib.rnntGetStatusString(rc)
+    return costs, (g.cpu().numpy() if want_grad else None)
+
+
+def _case(c):
+    acts = np.array(c["acts"], dtype=np.float32).reshape(c["B"], c["T"], c["U"], c["V"])
+    return acts, np.array(c["labels"]), np.array(c["input_lengths"]), np.array(c["label_lengths"])
+
+
+def test_reference_known_answers_through_the_c_api(ka):
+    from wav2vec_s_amd import transducer as tr
+    assert tr._rnnt_lib().get_warprnnt_version() == 1
+    acts, lab, xl, yl = _case(ka["small"])                                   # test_gpu.cu small_test
+    costs, _ = _c_api(acts, lab, xl, yl, want_grad=False)
+    assert abs(costs[0] - ka["small"]["expected_score"]) < 1e-4
+    dv = R.delay_cost("zero", 1, 2, 3, xl, yl)
+    costs3, _ = _c_api(acts, lab, xl, yl, delay=dv, want_grad=False)         # test_delay.cu small_test: scores[0]
+    assert abs(costs3[0] - ka["small"]["expected_score"]) < 1e-4
+    c = ka["options"]                                                        # options_test: scores and gradients
+    acts, lab, xl, yl = _case(c)
+    costs, g = _c_api(acts, lab, xl, yl)
+    np.testing.assert_allclose(costs, c["expected_scores"], atol=1e-4)
+    np.testing.assert_allclose(g.reshape(-1), c["expected_grads_wrt_acts"], atol=1e-4)
+    dv = R.delay_cost("zero", 2, 4, 3, xl, yl)
+    costs3, g3 = _c_api(acts, lab, xl, yl, delay=dv, delay_scale=0.0, smooth=1.0)     # grad_check's setting
+    np.testing.assert_allclose(costs3[:2], c["expected_scores"], atol=1e-4)
+    np.testing.assert_allclose(costs3[4:], costs3[:2], atol=1e-6)
+    np.testing.assert_allclose(g3.reshape(-1), c["expected_grads_wrt_acts"], atol=1e-4)
+
+
+def _random_case(rng, B, T, U, V, scale=1.5):
+    acts = (rng.randn(B, T, U, V) * scale).astype(np.float32)
+    xl = rng.randint(max(2, T // 2), T + 1, size=B); xl[0] = T
+    yl = rng.randint(1, U, size=B); yl[-1] = U - 1
+    lab = rng.randint(1, V, size=(B, U - 1))
+    return acts, lab, xl, yl
+
+
+@pytest.mark.skipif(not R.RefCpuRnnt.available(), reason="oracle/_ref/libwarprnnt_cpu.so not built")
+def test_plain_rnnt_equals_compiled_reference_cpu():
+    ref = R.RefCpuRnnt()
+    rng = np.random.RandomState(0)
+    for B, T, U, V in ((3, 17, 6, 11), (2, 40, 13, 32), (4, 9, 9, 5), (2, 70, 80, 12), (1, 1, 1, 8), (2, 5, 1, 7)):
+        acts, lab, xl, yl = _random_case(rng, B, T, U, V) if U > 1 else (
+            (rng.randn(B, T, U, V)).astype(np.float32), np.zeros((B, 0), dtype=np.int64), np.full(B, T), np.zeros(B, dtype=np.int64))
+        want_c, want_g = ref.loss_and_act_grads(acts, lab, xl, yl)
+        got_c, got_g = _c_api(acts, lab, xl, yl)
+        np.testing.assert_allclose(got_c, want_c, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got_g, want_g, atol=1e-4)
+        for b in range(B):                                                   # zeros outside T x U (the reference memsets)
+            assert not got_g[b, xl[b]:].any() and not got_g[b, :, yl[b] + 1:].any()
+
+
+@pytest.mark.parametrize("kind,smooth,scale", [("zero", 1.0, 1.0), ("diagonal", 1.0, 0.3), ("diag_positive", 0.7, 2.0),
+                                               ("zero", 1.3, 0.0)])
+def test_delay_transducer_equals_oracle(kind, smooth, scale):
+    from wav2vec_s_amd import transducer as tr
+    rng = np.random.RandomState(3)
+    for B, T, U, V in ((3, 12, 5, 9), (2, 33, 17, 24), (2, 6, 70, 8)):
+        acts, lab, xl, yl = _random_case(rng, B, T, U, V)
+        dv = R.delay_cost(kind, B, T, U, xl, yl)
+        want_c, want_g = R.delay_loss(acts, lab, xl, yl, dv, delay_scale=scale, smooth=smooth)
+        got_c, got_g = _c_api(acts, lab, xl, yl, delay=dv, delay_scale=scale, smooth=smooth)
+        # fp32 lattice values reach |alpha| ~ 200 for 70 labels (ulp 1.5e-5); the path weights exp(emit - alpha) inherit that
+        # and the expected delay (~30) moves by ~1e-3 - an fp32 evaluation of the reference's own recursion on the CPU
+        # lands on the same digits (33.1399 vs 33.1390 in float64 for this very case).  Short lattices: 2e-4.
+        tol = 2e-4 if T + U <= 50 else 1.5e-3
+        np.testing.assert_allclose(got_c.reshape(3, B), want_c, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(got_g, want_g, atol=tol * max(1.0, scale))
+        # the front end: device costs, gradient in backward, both index conventions, upstream gradient folded in
+        a = _dev(acts, torch.float32).requires_grad_(True)
+        dvt = getattr(tr, "delay_cost_" + kind)(a, _dev(xl, torch.int32), _dev(yl, torch.int32))
+        np.testing.assert_allclose(dvt.cpu().numpy(), dv, rtol=1e-6, atol=1e-6)
+        for consistent in (False, True):
+            loss = tr.DelayTLoss(blank=0, delay_scale=scale, temperature=smooth, reduction="none", delay_func=kind,
+                                 consistent_delay_index=consistent)
+            tot, nll, dly = loss(a, _dev(lab, torch.int32), _dev(xl, torch.int32), _dev(yl, torch.int32))
+            assert tot.is_cuda and tot.shape == (B,)
+            np.testing.assert_allclose(torch.stack([nll, dly, tot]).detach().cpu().numpy(), want_c, rtol=2e-4, atol=2e-4)
+            up = torch.linspace(0.5, 2.0, B).cuda()
+            a.grad = None
+            (tot * up).sum().backward()
+            _, wg = R.delay_loss(acts, lab, xl, yl, dv, delay_scale=scale, smooth=smooth, consistent_delay_index=consistent)
+            np.testing.assert_allclose(a.grad.cpu().numpy(), wg * up.cpu().numpy()[:, None, None, None], atol=2 * tol * max(1.0, scale))
+
+
+def test_front_end_reductions_checks_and_rnnt_loss():
+    from wav2vec_s_amd import transducer as tr
+    from wav2vec_s_amd._lib import W2vsError
+    rng = np.random.RandomState(5)
+    B, T, U, V = 3, 10, 4, 6
+    acts, lab, xl, yl = _random_case(rng, B, T, U, V)
+    xl[:] = [T, 7, 9]; yl[:] = [2, U - 1, 1]
+    want_c, want_g = R.rnnt_loss(acts, lab, xl, yl)
+    a = _dev(acts, torch.float32).requires_grad_(True)
+    L, X, Y = _dev(lab, torch.int32), _dev(xl, torch.int32), _dev(yl, torch.int32)
+    for red, cw, gw in (("mean", want_c.sum() / B, want_g / B), ("sum", want_c.sum(), want_g)):
+        a.grad = None
+        out = tr.RNNTLoss(blank=0, reduction=red)(a, L, X, Y)
+        assert out.shape == (1,) and out.is_cuda
+        np.testing.assert_allclose(out.item(), cw, rtol=1e-4)
+        out.backward()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gw, atol=1e-4)
+    out = tr.rnnt_loss(a, L, X, Y, reduction="none")
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want_c, rtol=1e-4)
+    tot, nll, dly = tr.DelayTLoss(reduction="mean")(a, L, X, Y)
+    np.testing.assert_allclose(nll.item(), want_c.sum() / B, rtol=1e-4)
+    with pytest.raises(TypeError, match="labels must be torch.int32"):
+        tr.rnnt_loss(a, L.long(), X, Y)
+    with pytest.raises(ValueError, match="Input length mismatch"):
+        tr.rnnt_loss(a, L, X - 1, Y)
+    with pytest.raises(ValueError, match="Output length mismatch"):
+        tr.rnnt_loss(a, L, X, torch.ones_like(Y))
+    with pytest.raises(ValueError, match="contiguous"):
+        tr.rnnt_loss(a.transpose(1, 2), L, X, Y)
+    with pytest.raises(NotImplementedError):
+        tr.DelayTLoss()(a.detach().cpu(), L.cpu(), X.cpu(), Y.cpu())
+    with pytest.raises(NotImplementedError):
+        tr.DelayTLoss(delay_func="cubic")
+    with pytest.raises(W2vsError):
+        tr.rnnt_loss(a.detach().cpu(), L.cpu(), X.cpu(), Y.cpu())
+    lib = tr._rnnt_lib()                                                     # the C interface rejects what the reference rejects
+    opt = tr.RnntOptions(0, 1, None, 0, T, U, True)
+    costs = np.zeros(B, dtype=np.float32)
+    assert lib.compute_rnnt_loss(a.data_ptr(), None, L.data_ptr(), Y.data_ptr(), X.data_ptr(), V, B, costs.ctypes.data,
+                                 a.data_ptr(), opt) == 3                    # RNNT_CPU: no CPU path -> EXECUTION_FAILED
+    opt = tr.RnntOptions(1, 1, None, 0, T, U, True)
+    assert lib.compute_rnnt_loss(None, None, L.data_ptr(), Y.data_ptr(), X.data_ptr(), V, B, costs.ctypes.data,
+                                 a.data_ptr(), opt) == 2                    # INVALID_VALUE
+    assert lib.rnntGetStatusString(2) == b"invalid value"
+
+
+def test_speech_translation_sized_batch_properties():
+    """B=8, T=160 frames, U=48 tokens, V=8000 (a CAAT joint output): no oracle at this size; check what must hold.
+    Every valid row's gradient sums to zero (occupancy in = transition mass out), rows outside T x U are zero, the
+    costs equal those of a V-reduced problem solved by the compiled reference, nothing is NaN/Inf."""
+    from wav2vec_s_amd import transducer as tr
+    g = torch.Generator().manual_seed(0)
+    B, T, U, V = 8, 160, 48, 8000
+    acts = (torch.randn(B, T, U, V, generator=g) * 2).cuda().requires_grad_(True)
+    xl = torch.tensor([160, 151, 120, 99, 160, 80, 143, 160], dtype=torch.int32)
+    yl = torch.tensor([47, 30, 12, 40, 1, 25, 47, 33], dtype=torch.int32)
+    lab = torch.randint(1, V, (B, U - 1), generator=g, dtype=torch.int32)
+    tot, nll, dly = tr.DelayTLoss(delay_scale=1.0, reduction="sum", delay_func="zero")(acts, lab.cuda(), xl.cuda(), yl.cuda())
+    tot.backward()
+    gr = acts.grad
+    assert bool(torch.isfinite(gr).all()) and bool(torch.isfinite(tot))
+    none = tr.rnnt_loss(acts.detach().requires_grad_(True), lab.cuda(), xl.cuda(), yl.cuda(), reduction="none")
+    np.testing.assert_allclose(none.sum().item(), nll.item(), rtol=1e-5)
+    a2 = acts.detach().clone().requires_grad_(True)
+    tr.rnnt_loss(a2, lab.cuda(), xl.cuda(), yl.cuda(), reduction="sum").backward()
+    rs = a2.grad.sum(-1)
+    assert float(rs.abs().max()) < 2e-4
+    for b in range(B):
+        assert not bool(a2.grad[b, xl[b]:].any()) and not bool(a2.grad[b, :, yl[b] + 1:].any())
+        assert not bool(gr[b, xl[b]:].any()) and not bool(gr[b, :, yl[b] + 1:].any())
+    # expected delay: a sum of s / src_len over emitted labels
+    dl = tr.DelayTLoss(delay_scale=1.0, reduction="none")(acts.detach(), lab.cuda(), xl.cuda(), yl.cuda())[2].cpu()
+    assert bool((dl > 0).all()) and bool((dl < yl.float()).all())
+    if R.RefCpuRnnt.available():                       # the loss only sees log p(blank) and log p(label): check it via the reference
+        b = 2
+        Tb, Ub = int(xl[b]), int(yl[b]) + 1
+        lp = torch.log_softmax(acts.detach()[b:b + 1, :Tb, :Ub].double(), -1).cpu().numpy()
+        want, _ = R.RefCpuRnnt().loss_and_logprob_grads(lp, lab[b:b + 1, :Ub - 1].numpy(), [Tb], [Ub - 1])
+        np.testing.assert_allclose(none[b].item(), want[0], rtol=2e-4)
