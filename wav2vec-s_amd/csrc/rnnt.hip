@@ -10,7 +10,7 @@
 //   lattice_kernel  grid (B, 2): block (b, 0) runs the alpha AND alpha-delay recursions, block (b, 1) beta AND beta-delay.
 //                   Thread u walks the anti-diagonals; a cell's two predecessors are its own previous value (a register)
 //                   and its neighbour's previous value (LDS, double buffered: one barrier per diagonal); the
-//                   log-probabilities of diagonal n are contiguous in memory and are loaded one diagonal ahead.
+//                   log-probabilities of diagonal n are contiguous in memory and are loaded four diagonals ahead.
 //   grad_kernel     one wave per row: every per-cell scalar is computed once, then the row is streamed with 16-byte
 //                   loads / stores (1-2 exp per element); rows outside a sample's T x U are written as zeros here, which
 //                   replaces the reference's memset pass over the whole gradient.
@@ -65,10 +65,16 @@ __device__ __forceinline__ long dix(const Dims& d, int b, int t, int u) {       
   return ((long)b * d.D + (t + u)) * d.maxU + u;
 }
 
-__device__ __forceinline__ float lse(float a, float b) {                         // rnnt_helper.h:17-26
+// rnnt_helper.h:17-26 log_sum_exp.  The correction log(1 + e^-|a-b|) lies in (0, ln 2]; evaluated with the hardware
+// exp2 / log2 (v_exp_f32, v_log_f32: ~1 ulp) its absolute error is ~1e-7, far below one ulp of a lattice value
+// (|alpha| reaches the 100s: ulp 1.5e-5) - and the recursion's critical path per anti-diagonal shrinks from ~100 to ~15
+// dependent instructions, which is what bounds this latency-bound kernel.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float lse(float a, float b) {
   if (a == -INFINITY) return b;
   if (b == -INFINITY) return a;
-  return a > b ? log1pf(expf(b - a)) + a : log1pf(expf(a - b)) + b;
+  const float m = fmaxf(a, b), dlt = -fabsf(a - b);
+  return m + __builtin_amdgcn_logf(1.f + fast_exp(dlt)) * 0.69314718055994530942f;
 }
 
 // ------------------------------------------------------------------------------------------------ rows: denominators
@@ -123,6 +129,10 @@ __global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void rows_kernel(const float*
 }
 
 // ------------------------------------------------------------------------------------------------ lattice recursions
+constexpr int PF = 4;                                  // diagonals of inputs in flight per thread
+
+struct LatIn { float pb, pl, dv; };                    // log p(blank), log p(label), emission cost feeding one step
+
 template <bool DELAY>
 __global__ void lattice_kernel(const int* __restrict__ xlen, const int* __restrict__ ylen,
                                const float* __restrict__ delay_values, Work w, Dims d) {
@@ -136,121 +146,117 @@ __global__ void lattice_kernel(const int* __restrict__ xlen, const int* __restri
   const float* lpl = w.lpl + base;
   const float* dv = DELAY ? delay_values + (long)b * d.maxT * d.maxU : nullptr;
   const int N = T + U - 1;                             // diagonals 0 .. N-1
-  if (blockIdx.y == 0) {
-    // ---- alpha(t,u) and alpha_delay(t,u): gpu_rnnt_kernel.h:12-51, 54-100
-    float* out = w.alpha + base;
-    float* outd = DELAY ? w.adel + base : nullptr;
-    float self = 0.f, selfd = 0.f;                     // alpha(t-1, u), alpha_delay(t-1, u)
-    if (u == 0) {
-      out[0] = 0.f;
-      if (DELAY) outd[0] = 0.f;
+  const bool fwd = blockIdx.y == 0;
+  float* out = (fwd ? w.alpha : w.beta) + base;
+  float* outd = DELAY ? (fwd ? w.adel : w.bdel) + base : nullptr;
+
+  // Inputs of step n do not depend on the recursion, so they are fetched PF diagonals ahead (a step is ~300 cycles of
+  // LDS + exp/log1p latency; a global load issued in the same step would add its full latency to every diagonal).
+  //  alpha step n, cell (t,u) = (n-u, u): blank from (t-1,u) = diagonal n-1 column u; label from (t,u-1) = diagonal n-1
+  //                                       column u-1; emission cost dv[t,u] (gpu_rnnt_kernel.h:76, :81)
+  //  beta  step n, cell (t,u):            blank / label / emission cost of the cell itself (:186, :193)
+  // Unconditional loads from clamped (always in-bounds) addresses: a load under a per-lane condition makes the compiler
+  // resolve the "else 0" right away, i.e. wait for the load it just issued.  Values of cells outside the lattice are
+  // loaded (workspace garbage) and never used.
+  const int uc = min(u, d.maxU - 1), um1 = clampi(u - 1, 0, d.maxU - 1);
+  auto fetch = [&](int n) -> LatIn {
+    LatIn r;
+    const int row = clampi(fwd ? n - 1 : n, 0, d.D - 1);
+    r.pb = lpb[(long)row * d.maxU + uc];
+    r.pl = lpl[(long)row * d.maxU + (fwd ? um1 : uc)];
+    r.dv = 0.f;
+    if (DELAY) r.dv = dv[(long)clampi(n - u, 0, T - 1) * d.maxU + uc];
+    return r;
+  };
+
+  float self = 0.f, selfd = 0.f;                       // alpha(t-1,u) / beta(t+1,u) and the matching delay
+  shv[u] = 0.f; shd[u] = 0.f; shv[W + u] = 0.f; shd[W + u] = 0.f;
+  if (fwd && u == 0) {                                 // alpha(0,0) = 0, alpha_delay(0,0) = 0
+    out[0] = 0.f;
+    if (DELAY) outd[0] = 0.f;
+  }
+  const int dir = fwd ? 1 : -1;
+  const int first = fwd ? 1 : N - 1, steps = fwd ? N - 1 : N;
+  LatIn cur[PF], nxt[PF];
+  float resv[PF], resd[PF];
+  int resn[PF];                                        // diagonal of a finished cell, -1 = nothing to write
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    cur[j] = fetch(first + dir * j);
+    resn[j] = -1;
+  }
+  // Loads and stores share one in-order counter (vmcnt) on gfx9: a wait for prefetched inputs also waits for every store
+  // issued before it.  So results are parked in registers and written at the START of the next chunk, BEFORE that chunk's
+  // prefetches: whatever a later wait covers was issued at least PF diagonals earlier and has long completed.
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      if (resn[j] >= 0) {
+        out[(long)resn[j] * d.maxU + u] = resv[j];
+        if (DELAY) outd[(long)resn[j] * d.maxU + u] = resd[j];
+      }
+      resn[j] = -1;
     }
-    shv[u] = 0.f;                                      // buffer 0 holds diagonal 0: only (0,0) = 0 matters
-    shd[u] = 0.f;
-    // log-probabilities of diagonal n-1 feed step n: blank at column u (cell (t-1,u)), label at column u-1 (cell (t,u-1))
-    float pb = (u < d.maxU && N > 1) ? lpb[u] : 0.f;
-    float pl = (u >= 1 && u <= d.maxU && N > 1) ? lpl[u - 1] : 0.f;
-    __syncthreads();
-    for (int n = 1; n < N; ++n) {
+  };
+  __syncthreads();
+  for (int s0 = 0; s0 < steps; s0 += PF) {
+    flush();
+#pragma unroll
+    for (int j = 0; j < PF; ++j) nxt[j] = fetch(first + dir * (s0 + PF + j));
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      if (s0 + j >= steps) break;                      // block-uniform
+      const int n = first + dir * (s0 + j);
       const int t = n - u;
-      const float* prv = shv + ((n - 1) & 1) * W;
-      const float* prd = shd + ((n - 1) & 1) * W;
+      const float* prv = shv + ((n - dir) & 1) * W;    // the neighbouring diagonal computed in the previous step
+      const float* prd = shd + ((n - dir) & 1) * W;
       const bool valid = u < U && t >= 0 && t < T;
-      float npb = 0.f, npl = 0.f;                      // next diagonal's inputs, loaded before this step's math
-      if (n + 1 < N) {
-        if (u < d.maxU) npb = lpb[(long)n * d.maxU + u];
-        if (u >= 1 && u <= d.maxU) npl = lpl[(long)n * d.maxU + u - 1];
+      const LatIn in = cur[j];
+      // branch-free: every lane evaluates the general cell, boundary cells are selected afterwards
+      const int nb = fwd ? max(u - 1, 0) : min(u + 1, W - 1);
+      const float nbv = prv[nb], nbd = prd[nb];        // alpha(t,u-1) / beta(t,u+1) and its delay
+      const float no_emit = self + in.pb, emit = nbv + in.pl;
+      const float gen = lse(emit, no_emit);
+      float gend = 0.f;
+      if (DELAY) gend = selfd + fast_exp(emit - gen) * (nbd + in.dv - selfd);   // convex form: the two path weights sum to 1,
+                                                       // so fp32 rounding of `gen` scales only the DIFFERENCE of the delays
+      float v, vd;
+      if (fwd) {
+        // u == 0: only the blank transition (t > 0 here); t == 0: only the label transition (gpu_rnnt_kernel.h:27-38, :75-84)
+        v = (u == 0) ? no_emit : (t == 0 ? emit : gen);
+        vd = (u == 0) ? 0.f : (t == 0 ? nbd + in.dv : gend);
+      } else {
+        // (T-1,U-1): log p(blank); u == U-1: blank only; t == T-1: label only (:136-150, :180-195)
+        const bool lastu = u == U - 1, lastt = t == T - 1;
+        v = lastu ? (lastt ? in.pb : no_emit) : (lastt ? emit : gen);
+        vd = lastu ? (lastt ? 0.f : selfd) : (lastt ? nbd + in.dv : gend);
       }
-      float dval = 0.f;
-      if (DELAY && valid && u > 0) dval = dv[(long)t * d.maxU + u];
-      float a = 0.f, ad = 0.f;
-      if (valid) {
-        if (u == 0) {
-          a = self + pb;                               // t > 0 here (n >= 1)
-          ad = 0.f;
-        } else {
-          const float left = prv[u - 1], leftd = prd[u - 1];
-          if (t == 0) {
-            a = left + pl;
-            ad = leftd + dval;
-          } else {
-            const float no_emit = self + pb, emit = left + pl;
-            a = lse(emit, no_emit);
-            // the two path weights exp(no_emit - a), exp(emit - a) sum to 1: written as a convex combination the rounding of
-            // a (|a| ~ 100s in fp32) only scales the DIFFERENCE of the two delays, not their magnitude
-            if (DELAY) ad = selfd + expf(emit - a) * (leftd + dval - selfd);
-          }
-        }
-        out[(long)n * d.maxU + u] = a;
-        if (DELAY) outd[(long)n * d.maxU + u] = ad;
-        self = a;
-        selfd = ad;
-      }
-      shv[(n & 1) * W + u] = a;
-      shd[(n & 1) * W + u] = ad;
-      pb = npb;
-      pl = npl;
-      __syncthreads();
+      v = valid ? v : 0.f;
+      vd = valid ? vd : 0.f;
+      resv[j] = v;
+      resd[j] = vd;
+      resn[j] = valid ? n : -1;
+      self = valid ? v : self;
+      selfd = valid ? vd : selfd;
+      shv[(n & 1) * W + u] = v;
+      shd[(n & 1) * W + u] = vd;
+      // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait every diagonal for this step's global stores
+      // and for the prefetches just issued (~1 us per diagonal, measured)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    if (u == U - 1) {                                  // this thread holds alpha(T-1, U-1) in `self`
+#pragma unroll
+    for (int j = 0; j < PF; ++j) cur[j] = nxt[j];
+  }
+  flush();
+  if (fwd) {
+    if (u == U - 1) {                                  // `self` is alpha(T-1, U-1)
       w.ll[b] = self + lpb[(long)(N - 1) * d.maxU + (U - 1)];
       if (DELAY) w.dexp[b] = selfd;
     }
-  } else {
-    // ---- beta(t,u) and beta_delay(t,u): gpu_rnnt_kernel.h:126-163, 166-213
-    float* out = w.beta + base;
-    float* outd = DELAY ? w.bdel + base : nullptr;
-    float self = 0.f, selfd = 0.f;                     // beta(t+1, u), beta_delay(t+1, u)
-    shv[u] = 0.f; shd[u] = 0.f; shv[W + u] = 0.f; shd[W + u] = 0.f;
-    float pb = 0.f, pl = 0.f;                          // log-probabilities of THIS diagonal's cell (t, u)
-    if (u < d.maxU) {
-      pb = lpb[(long)(N - 1) * d.maxU + u];
-      pl = lpl[(long)(N - 1) * d.maxU + u];
-    }
-    __syncthreads();
-    for (int n = N - 1; n >= 0; --n) {
-      const int t = n - u;
-      const float* prv = shv + ((n + 1) & 1) * W;
-      const float* prd = shd + ((n + 1) & 1) * W;
-      const bool valid = u < U && t >= 0 && t < T;
-      float npb = 0.f, npl = 0.f;
-      if (n > 0 && u < d.maxU) {
-        npb = lpb[(long)(n - 1) * d.maxU + u];
-        npl = lpl[(long)(n - 1) * d.maxU + u];
-      }
-      float dval = 0.f;
-      if (DELAY && valid && u < U - 1) dval = dv[(long)t * d.maxU + u];
-      float bb = 0.f, bd = 0.f;
-      if (valid) {
-        if (u == U - 1) {
-          bb = (t == T - 1) ? pb : self + pb;
-          bd = (t == T - 1) ? 0.f : selfd;
-        } else {
-          const float right = prv[u + 1], rightd = prd[u + 1];
-          if (t == T - 1) {
-            bb = right + pl;
-            bd = rightd + dval;
-          } else {
-            const float no_emit = self + pb, emit = right + pl;
-            bb = lse(emit, no_emit);
-            if (DELAY) bd = selfd + expf(emit - bb) * (rightd + dval - selfd);
-          }
-        }
-        out[(long)n * d.maxU + u] = bb;
-        if (DELAY) outd[(long)n * d.maxU + u] = bd;
-        self = bb;
-        selfd = bd;
-      }
-      shv[(n & 1) * W + u] = bb;
-      shd[(n & 1) * W + u] = bd;
-      pb = npb;
-      pl = npl;
-      __syncthreads();
-    }
-    if (u == 0) {
-      w.llb[b] = self;
-      if (DELAY) w.dexpb[b] = selfd;
-    }
+  } else if (u == 0) {                                 // `self` is beta(0, 0)
+    w.llb[b] = self;
+    if (DELAY) w.dexpb[b] = selfd;
   }
 }
 
