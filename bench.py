@@ -70,6 +70,56 @@ def cpu_baseline(threads):
             "sample": "oracle fp32, base model, 2 x 80000 samples, fwd+loss+bwd, median of 2 after 1 warm-up, %.2f s/step" % t}
 
 
+def _cpu_baseline_rnnt(acts1, labels1, T, U, gpu_cost):
+    """cpu_baseline leg of --workload rnnt: warp_transducer's own CpuRNNT (compiled into oracle/_ref by `make -C oracle ref`)
+    on ONE utterance; it takes log-probabilities, so numpy's log-softmax of that utterance is timed with it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rnnt_oracle as R
+    if not R.RefCpuRnnt.available():
+        return "unavailable: oracle/_ref/libwarprnnt_cpu.so not built"
+    ref = R.RefCpuRnnt()
+    x = acts1.astype(np.float64)
+    t0 = time.perf_counter()
+    lp = x + R.log_softmax_denom(x)[..., None]
+    c, _ = ref.loss_and_logprob_grads(lp, labels1, [T], [U - 1])
+    dt = time.perf_counter() - t0
+    return {"kind": "reference", "cores": 1, "value": round(T * U / dt), "unit": "lattice cells/s", "seconds": round(dt, 3),
+            "sample": "utterance 0 (%d x %d cells, V=%d), numpy log-softmax + warp_transducer CpuRNNT (plain RNN-T, no delay "
+                      "terms)" % (T, U, acts1.shape[-1]),
+            "cost_equal": bool(abs(float(c[0]) - gpu_cost) < 2e-4 * abs(float(c[0])))}
+
+
+def _cpu_baseline_data(idx, sizes, product_batches):
+    """cpu_baseline leg of --workload data: the reference's Cython batch_by_size_vec compiled into oracle/_ref."""
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.isdir(ref_dir):
+        return {"reference_cython": "unavailable: oracle/_ref not built"}
+    sys.path.insert(0, ref_dir)
+    try:
+        import data_utils_fast as fast          # the compiled reference; /root/reference is not needed at run time
+    except ImportError as e:
+        return {"reference_cython": "unavailable: %r" % (e,)}
+    t0 = time.perf_counter()
+    for _ in range(5):
+        rb = fast.batch_by_size_vec(idx, sizes, 1400000, -1, 8)
+    tr = (time.perf_counter() - t0) / 5
+    same = len(rb) == len(product_batches) and all(np.array_equal(x, y) for x, y in zip(rb, product_batches))
+    return {"reference_cython_ms": round(tr * 1e3, 3), "identical_to_reference": bool(same)}
+
+
+def side_workload(name, no_cpu):
+    """Rows f1 / f3 / f4: one JSON line each, same spirit as the headline line (tools/bench_*.py do the GPU part)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if name == "stream":
+        import bench_stream
+        return bench_stream.main([])
+    if name == "data":
+        import bench_data
+        return bench_data.main([], cpu_baseline=None if no_cpu else _cpu_baseline_data)
+    import bench_rnnt
+    return bench_rnnt.main([], cpu_baseline=None if no_cpu else _cpu_baseline_rnnt)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +129,12 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--samples", type=int, default=L_SAMPLES)
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "stream", "data", "rnnt"],
+                    help="pretrain (default) = the headline step; stream / data / rnnt = the SURVEY section 8 rows f1 / f3 / f4 "
+                         "measurements (tools/bench_*.py) with their CPU baselines attached here")
     args = ap.parse_args()
+    if args.workload != "pretrain":
+        return side_workload(args.workload, args.no_cpu_baseline)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -4,7 +4,8 @@
     python tools/bench_data.py [--out gpurun_out/data_bench.json]
 
 * batcher: `w2vs_batch_by_size` (C ABI, host) on a LibriSpeech-960-sized epoch (281 241 utterances, max_tokens
-  1.4 M, multiple of 8), beside the reference's own compiled Cython (oracle/_ref) when it is present;
+  1.4 M, multiple of 8); the reference's own compiled Cython (oracle/_ref) is timed beside it only through
+  `python bench.py --workload data` (bench.py's cpu_baseline leg owns every use of oracle/);
 * collater: `w2vs_collate` at the pre-training batch shape (8 utterances of 11-16 s -> [8, 175 000] bf16, with and
   without whole-utterance normalisation): kernel time from HIP events on the launching stream with inputs resident
   (HBM-bound: algorithmic bytes = 4 B x all samples for the statistics + 4 B read and 2 B written per output sample),
@@ -22,13 +23,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
-def main():
+def main(argv=None, cpu_baseline=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "data_bench.json"))
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from wav2vec_s_amd import _lib, data
     rep = {}
     rng = np.random.RandomState(0)
@@ -41,20 +41,8 @@ def main():
         b = data.batch_by_size_vec(idx, sizes, 1400000, -1, 8)
     t = (time.perf_counter() - t0) / 5
     rep["batch_by_size"] = {"n": n, "batches": len(b), "ms": round(t * 1e3, 3), "utterances_per_s": round(n / t)}
-    try:
-        import ref_import
-        if os.path.isdir(os.path.join(ROOT, "oracle", "_ref")):
-            sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
-            import data_utils_fast as fast          # the compiled reference; no /root/reference needed at run time
-            t0 = time.perf_counter()
-            for _ in range(5):
-                rb = fast.batch_by_size_vec(idx, sizes, 1400000, -1, 8)
-            tr = (time.perf_counter() - t0) / 5
-            same = len(rb) == len(b) and all(np.array_equal(x, y) for x, y in zip(rb, b))
-            rep["batch_by_size"]["reference_cython_ms"] = round(tr * 1e3, 3)
-            rep["batch_by_size"]["identical_to_reference"] = bool(same)
-    except Exception as e:                           # pragma: no cover
-        rep["batch_by_size"]["reference_cython"] = "unavailable: %r" % (e,)
+    if cpu_baseline is not None:                    # bench.py's cpu_baseline leg: the reference's compiled Cython batcher
+        rep["batch_by_size"].update(cpu_baseline(idx, sizes, b))
 
     g = torch.Generator().manual_seed(3)
     lens = [250000, 176000, 243111, 175000, 201234, 199999, 180001, 250000]

@@ -32,12 +32,12 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stream_bench.json"))
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from wav2vec_s_amd import streaming
     from wav2vec_s_amd.config import base_librispeech_config
     cfg = base_librispeech_config(main_context=16, right_context=8, context_type="constant")
