@@ -216,3 +216,45 @@ def test_speech_translation_sized_batch_properties():
         lp = torch.log_softmax(acts.detach()[b:b + 1, :Tb, :Ub].double(), -1).cpu().numpy()
         want, _ = R.RefCpuRnnt().loss_and_logprob_grads(lp, lab[b:b + 1, :Ub - 1].numpy(), [Tb], [Ub - 1])
         np.testing.assert_allclose(none[b].item(), want[0], rtol=2e-4)
+
+
+def _gen_labels(rng, V, L):
+    """warp_transducer/tests/random.cpp genLabels: uniform labels in [1, V-1] with guaranteed repeats."""
+    lab = rng.randint(1, V, size=L)
+    if L >= 3:
+        lab[L // 2] = lab[L // 2 + 1]
+        lab[L // 2 - 1] = lab[L // 2]
+    return lab
+
+
+def test_reference_inf_test_and_grad_check_mirrors():
+    """test_delay.cu inf_test (:247-333: V=15, T=50, L=10, activations uniform in [0,1): finite cost, no NaN) and
+    run_tests / grad_check (:463-500: (V,T,L,B) = (20,50,15,1) and (5,10,5,65), analytic gradient against a central
+    difference of the TOTAL cost with delay_scale = 0, epsilon 1e-2, rel_diff < 1e-2), through the same C entry point."""
+    rng = np.random.RandomState(0)
+    V, T, L = 15, 50, 10
+    acts = rng.uniform(0, 1, size=(1, T, L, V)).astype(np.float32)
+    lab = _gen_labels(rng, V, L - 1)[None]
+    lab[0, 0] = 2
+    dv = R.delay_cost("zero", 1, T, L, [T], [L - 1])
+    costs, g = _c_api(acts, lab, [T], [L - 1], delay=dv, delay_scale=1.0, smooth=1.0)
+    assert np.isfinite(costs).all() and not np.isnan(g).any()
+    for V, T, L, B in ((20, 50, 15, 1), (5, 10, 5, 65)):
+        acts = rng.uniform(0, 1, size=(B, T, L, V)).astype(np.float32)
+        lab = np.stack([_gen_labels(rng, V, L - 1) for _ in range(B)])
+        xl, yl = np.full(B, T), np.full(B, L - 1)
+        dv = R.delay_cost("zero", B, T, L, xl, yl)
+        _, g = _c_api(acts, lab, xl, yl, delay=dv, delay_scale=0.0, smooth=1.0)
+        idx = rng.choice(acts.size, size=160, replace=False)     # a random subset of the coordinates grad_check sweeps
+        eps = 1e-2
+        num = np.zeros(len(idx))
+        for k, i in enumerate(idx):
+            ap, am = acts.copy().reshape(-1), acts.copy().reshape(-1)
+            ap[i] += eps
+            am[i] -= eps
+            cp, _ = _c_api(ap.reshape(acts.shape), lab, xl, yl, delay=dv, delay_scale=0.0, want_grad=False)
+            cm, _ = _c_api(am.reshape(acts.shape), lab, xl, yl, delay=dv, delay_scale=0.0, want_grad=False)
+            num[k] = (cp[2 * B:].astype(np.float64).sum() - cm[2 * B:].astype(np.float64).sum()) / (2 * eps)
+        ana = g.reshape(-1)[idx]
+        rel_diff = ((ana - num) ** 2).sum() / (ana ** 2).sum()     # tests/test.h:22-32
+        assert rel_diff < 1e-2, (V, T, L, B, rel_diff)

@@ -98,3 +98,28 @@ def test_delay_cost_builders():
     dp = R.delay_cost("diag_positive", 1, 4, 3, [4], [2])
     want = (np.arange(1, 5)[:, None] * 0.5 - np.arange(1, 4)[None, :]) / 2
     assert np.allclose(dd[0], np.abs(want)) and np.allclose(dp[0], np.clip(want, 0, None))
+
+
+def test_oracle_equals_reference_numpy_transducer():
+    """The reference's own numpy oracle (warp_transducer/pytorch_binding/test/transducer_np.py), imported from where it
+    lies: costs and gradients w.r.t. log-probabilities on a ragged batch."""
+    import importlib.util
+    path = "/root/reference/warp_transducer/pytorch_binding/test/transducer_np.py"
+    if not os.path.isfile(path):
+        pytest.skip("reference tree not present")
+    spec = importlib.util.spec_from_file_location("ref_transducer_np", path)
+    tnp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tnp)
+    rng = np.random.RandomState(4)
+    B, T, U, V = 3, 11, 5, 7
+    acts = rng.randn(B, T, U, V)
+    xl, yl = np.array([11, 8, 6]), np.array([4, 2, 3])
+    lab = rng.randint(1, V, size=(B, U - 1))
+    lp = acts + R.log_softmax_denom(acts)[..., None]
+    want_c, want_g = tnp.transduce_batch(lp.astype(np.float32), lab, xl, yl)
+    got_c, got_g = R.rnnt_loss(acts, lab, xl, yl)
+    np.testing.assert_allclose(got_c, want_c, rtol=1e-5)
+    # transducer_np differentiates w.r.t. log-probabilities; chain through the softmax like RefCpuRnnt.loss_and_act_grads
+    want_act = want_g.astype(np.float64) - np.exp(lp) * want_g.astype(np.float64).sum(-1, keepdims=True)
+    for b in range(B):
+        np.testing.assert_allclose(got_g[b, :xl[b], :yl[b] + 1], want_act[b, :xl[b], :yl[b] + 1], atol=2e-5)
