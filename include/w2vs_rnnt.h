@@ -98,15 +98,22 @@ rnntStatus_t get_delay_workspace_size(int maxT, int maxU, int minibatch, bool gp
  * by d(loss)/d(cost): grad_scale_host * grad_scale_dev[0] (grad_scale_n = 1), * grad_scale_dev[b] (= minibatch) or 1
  * (= 0) - the reference multiplies the finished gradient tensor once more in Python (delay_transducer.py:86-90).
  * flags bit 0: read the emission cost in the gradient as delay_values[b, t, u] instead of the reference's
- * delay_values[b * maxT + t] (gpu_rnnt_kernel.h:409 indexes the B x T x U array with a B x T index; clear = reproduce). */
+ * delay_values[b * maxT + t] (gpu_rnnt_kernel.h:409 indexes the B x T x U array with a B x T index; clear = reproduce).
+ * flags bit 1: write the gradients as bf16 (what the GEMMs of the output projection's backward consume). */
 rnntStatus_t w2vs_rnnt_forward_async(const float* activations, const int* flat_labels, const int* label_lengths,
                                      const int* input_lengths, const float* delay_values, int alphabet_size, int minibatch,
                                      float* costs_dev, void* workspace, float delay_scale, struct rnntOptions options);
-rnntStatus_t w2vs_rnnt_backward_async(const float* activations, float* gradients, const int* flat_labels,
+rnntStatus_t w2vs_rnnt_backward_async(const float* activations, void* gradients, const int* flat_labels,
                                       const int* label_lengths, const int* input_lengths, const float* delay_values,
                                       int alphabet_size, int minibatch, void* workspace, float delay_scale, float smooth,
                                       int flags, const float* grad_scale_dev, int grad_scale_n, float grad_scale_host,
                                       struct rnntOptions options);
+/* Label-smoothed cross-entropy rows: fairseq's label_smoothed_nll_loss (fs/criterions/label_smoothed_cross_entropy.py:33-50)
+ * on log_softmax(logits [rows, V] fp32), summed over rows whose target != pad, as TransducerOut.cross_entropy uses it
+ * (rain/layers/attention_transducer.py:339-360).  sums2[0] += loss, sums2[1] += nll (device, caller zeroes); grads: NULL
+ * or [rows, V] (fp32, or bf16 with grads_bf16) = grad_scale * d loss / d logits. */
+rnntStatus_t w2vs_ls_ce_rows(const float* logits, const int* target, void* grads, float* sums2, int64_t rows, int V, int pad,
+                             float epsilon, float grad_scale, int grads_bf16, void* stream);
 /* delay_values builders of pytorch_binding/warprnnt_pytorch/delay_transducer.py:96-134 as one kernel.
  * kind 0 "zero": s / src_len; 1 "diagonal": |(s+1) * tgt/src - (u+1)| / tgt; 2 "diag_positive": max(.., 0) / tgt. */
 rnntStatus_t w2vs_rnnt_delay_values(int kind, const int* src_lens, const int* tgt_lens, float* out, int minibatch,

@@ -265,3 +265,64 @@ class RefCpuRnnt:
         costs, g = self.loss_and_logprob_grads(lp, labels, input_lengths, label_lengths, blank)
         g = g.astype(np.float64)
         return costs, g - np.exp(lp) * g.sum(-1, keepdims=True)
+
+
+# ----------------------------------------------------------------------------------------------------
+# the CAAT loss head: TransducerOut.train_step, rain/layers/attention_transducer.py:289-408
+# ----------------------------------------------------------------------------------------------------
+def label_smoothed_ce(logits, target, eps, pad):
+    """fs/criterions/label_smoothed_cross_entropy.py:33-50 on log_softmax(logits), summed, rows with target == pad
+    ignored.  Returns (loss, nll, d loss / d logits)."""
+    logits = np.asarray(logits, dtype=np.float64)
+    V = logits.shape[-1]
+    lp = logits + log_softmax_denom(logits)[..., None]
+    keep = (target != pad)
+    rows = np.arange(logits.shape[0])
+    nll_r = -lp[rows, np.where(keep, target, 0)] * keep
+    smooth_r = -lp.sum(-1) * keep
+    eps_i = eps / (V - 1)
+    loss = (1.0 - eps - eps_i) * nll_r.sum() + eps_i * smooth_r.sum()
+    p = np.exp(lp)
+    g = (1.0 - eps - eps_i) * p + eps_i * (V * p - 1.0)
+    g[rows, np.where(keep, target, 0)] -= (1.0 - eps - eps_i)
+    g *= keep[:, None]
+    return loss, nll_r.sum(), g
+
+
+def transducer_out_step(x, W, targets, src_lengths, tgt_lengths, *, delay_scale=1.0, temperature=1.0, blank=0,
+                        label_smoothing=0.1, pad=1, ce_scale=1.0, delay_func="zero", loss_scale=1.0, tokens_per_step=None):
+    """TransducerOut.train_step (:362-408).  x [B, T, U, d] joint states, W [V, d] bias-free output projection, targets
+    [B, U-1].  Returns the result dictionary's four losses and (d x, d W) of loss_scale * (rnnt_total + ce_scale * ce).
+    ``tokens_per_step`` splits the batch exactly as :370-373 does.  Every term is a sum over samples, so the split would
+    not matter - except that the gradient kernel's ``delay_values[b * maxT + t]`` index (see module docstring) uses the
+    micro-batch-local b: with the reference's index the delay gradient DOES depend on the micro-batching."""
+    x = np.asarray(x, dtype=np.float64)
+    W = np.asarray(W, dtype=np.float64)
+    B, T, U, d = x.shape
+    src_lengths, tgt_lengths, targets = np.asarray(src_lengths), np.asarray(tgt_lengths), np.asarray(targets)
+    step = B if tokens_per_step is None else max(tokens_per_step // (T * U), 1)
+    out = {"loss": 0.0, "loss_prob": 0.0, "loss_delay": 0.0, "nll_loss": 0.0}
+    dx = np.zeros_like(x)
+    dW = np.zeros_like(W)
+    for i in range(0, B, step):
+        sl = slice(i, min(i + step, B))
+        xb, n = x[sl], x[sl].shape[0]
+        logits = xb @ W.T
+        dv = delay_cost(delay_func, n, T, U, src_lengths[sl], tgt_lengths[sl])
+        costs, dl = delay_loss(logits, targets[sl], src_lengths[sl], tgt_lengths[sl], dv, delay_scale=delay_scale,
+                               smooth=temperature, blank=blank)
+        dl = dl * loss_scale
+        dxb = dl @ W
+        dW += dl.reshape(-1, W.shape[0]).T @ xb.reshape(-1, d)
+        bidx = np.arange(n)
+        last_h = xb[bidx, src_lengths[sl] - 1][:, :-1]                              # :345-348
+        ce, nll, g2 = label_smoothed_ce((last_h @ W.T).reshape(n * (U - 1), -1), targets[sl].reshape(-1), label_smoothing, pad)
+        g2 = g2.reshape(n, U - 1, -1) * (ce_scale * loss_scale)
+        dxb[bidx, src_lengths[sl] - 1, :U - 1] += g2 @ W
+        dW += g2.reshape(-1, W.shape[0]).T @ last_h.reshape(-1, d)
+        dx[sl] = dxb
+        out["loss"] += costs[2].sum() + ce_scale * ce
+        out["loss_prob"] += costs[0].sum()
+        out["loss_delay"] += costs[1].sum()
+        out["nll_loss"] += nll
+    return out, dx, dW

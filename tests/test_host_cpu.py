@@ -170,7 +170,7 @@ def test_rnnt_header_symbols_are_exported():
     names = set(re.findall(r"\b(?:rnntStatus_t|int|const char\*)\s+(\w+)\s*\(", hdr))
     assert {"compute_rnnt_loss", "compute_rnnt_delay_loss", "get_workspace_size", "get_delay_workspace_size",
             "get_warprnnt_version", "rnntGetStatusString", "w2vs_rnnt_forward_async", "w2vs_rnnt_backward_async",
-            "w2vs_rnnt_delay_values"} <= names
+            "w2vs_rnnt_delay_values", "w2vs_ls_ce_rows"} <= names
     assert names == set(transducer.RNNT_EXPORTS)
     lib = _lib.load()
     for n in names:

@@ -258,3 +258,48 @@ def test_reference_inf_test_and_grad_check_mirrors():
         ana = g.reshape(-1)[idx]
         rel_diff = ((ana - num) ** 2).sum() / (ana ** 2).sum()     # tests/test.h:22-32
         assert rel_diff < 1e-2, (V, T, L, B, rel_diff)
+
+
+@pytest.mark.parametrize("tokens_per_step,scaled", [(20000, False), (60, True)])
+def test_transducer_out_head_equals_oracle(tokens_per_step, scaled):
+    """TransducerOut.train_step / eval_step (rain/layers/attention_transducer.py:289-446): projection + delay transducer +
+    label-smoothed CE on the last frame, micro-batched (tokens_per_step = 60 forces 1 sample per micro-batch here), loss
+    scaling, gradient of the projection weight and of the joint states pushed into the upstream graph."""
+    from wav2vec_s_amd import transducer as tr
+    rng = np.random.RandomState(11)
+    B, T, U, d, V = 3, 9, 5, 16, 24
+    x = torch.tensor(rng.randn(B, T, U, d), dtype=torch.float32).to(torch.bfloat16)
+    W = torch.tensor(rng.randn(V, d) * 0.4, dtype=torch.float32).to(torch.bfloat16)
+    tg = rng.randint(2, V, size=(B, U - 1)); tg[1, 3] = 1; tg[2, 2:] = 1
+    sl, tl = np.array([9, 7, 5]), np.array([4, 3, 2])
+    scale = 4.0 if scaled else 1.0
+    want, wdx, wdW = R.transducer_out_step(x.float().numpy(), W.float().numpy(), tg, sl, tl, delay_scale=0.8, temperature=1.0,
+                                           label_smoothing=0.1, pad=1, ce_scale=0.5, loss_scale=scale,
+                                           tokens_per_step=tokens_per_step)
+    proj = torch.nn.Linear(d, V, bias=False).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        proj.weight.copy_(W)
+    head = tr.TransducerOut(proj, delay_scale=0.8, tokens_per_step=tokens_per_step, blank=0, label_smoothing=0.1, pad=1,
+                            ce_scale=0.5, temperature=1.0)
+    up = torch.nn.Parameter(x.clone().cuda())                # stands for the joint network: x = 1.0 * up
+    xin = up * 1.0
+
+    class _Scaler:
+        def get_scale(self):
+            return scale
+    res = head.train_step(xin, torch.tensor(tg).cuda(), torch.tensor(sl).cuda(), torch.tensor(tl).cuda(),
+                          scaler=_Scaler() if scaled else None)
+    for k in ("loss", "loss_prob", "loss_delay", "nll_loss"):
+        assert res[k].is_cuda
+        np.testing.assert_allclose(float(res[k]), want[k], rtol=2e-3, atol=2e-3)
+    assert res["sample_size"] == int((tg != 1).sum())
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))      # noqa: E731
+    assert rel(up.grad.float().cpu().numpy(), wdx) < 1e-2
+    assert rel(proj.weight.grad.float().cpu().numpy(), wdW) < 1e-2
+    ev = head.eval_step(up.detach(), torch.tensor(tg).cuda(), torch.tensor(sl).cuda(), torch.tensor(tl).cuda())
+    np.testing.assert_allclose(float(ev["loss"]), want["loss"], rtol=2e-3, atol=2e-3)
+    logits = head(up.detach())
+    assert logits.shape == (B, T, U, V) and logits.dtype == torch.bfloat16
+    assert rel(logits.float().cpu().numpy(), x.float().numpy() @ W.float().numpy().T) < 1e-2
+    with pytest.raises(Exception, match="bias-free"):
+        tr.TransducerOut(torch.nn.Linear(d, V, bias=True))

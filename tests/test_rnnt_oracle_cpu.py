@@ -123,3 +123,45 @@ def test_oracle_equals_reference_numpy_transducer():
     want_act = want_g.astype(np.float64) - np.exp(lp) * want_g.astype(np.float64).sum(-1, keepdims=True)
     for b in range(B):
         np.testing.assert_allclose(got_g[b, :xl[b], :yl[b] + 1], want_act[b, :xl[b], :yl[b] + 1], atol=2e-5)
+
+
+def test_label_smoothed_ce_and_head_against_torch_autograd():
+    """The loss head's restatement (parity unpinned: rain/layers/attention_transducer.py imports the CUDA-only
+    warprnnt_pytorch and the whole fairseq Transformer stack): its cross-entropy equals fairseq's formula evaluated by torch,
+    and the head's gradients equal torch autograd through the same composition."""
+    import torch
+    rng = np.random.RandomState(8)
+    R_, V = 7, 11
+    logits = rng.randn(R_, V)
+    tgt = rng.randint(2, V, size=R_); tgt[2] = 1
+    loss, nll, g = R.label_smoothed_ce(logits, tgt, 0.1, 1)
+    lt = torch.tensor(logits, requires_grad=True)
+    lp = torch.log_softmax(lt, -1)
+    t = torch.tensor(tgt).unsqueeze(-1)
+    nl = -lp.gather(-1, t); sm = -lp.sum(-1, keepdim=True)
+    m = t.eq(1); nl = nl.masked_fill(m, 0.0).sum(); sm = sm.masked_fill(m, 0.0).sum()       # label_smoothed_cross_entropy.py:36-47
+    eps_i = 0.1 / (V - 1)
+    want = (1.0 - 0.1 - eps_i) * nl + eps_i * sm
+    want.backward()
+    np.testing.assert_allclose(loss, want.item(), rtol=1e-12)
+    np.testing.assert_allclose(nll, nl.item(), rtol=1e-12)
+    np.testing.assert_allclose(g, lt.grad.numpy(), atol=1e-12)
+    B, T, U, d, V = 2, 6, 4, 5, 9
+    x, W = rng.randn(B, T, U, d), rng.randn(V, d) * 0.5
+    tg = rng.randint(2, V, size=(B, U - 1)); tg[1, 2] = 1
+    sl, tl = np.array([6, 4]), np.array([3, 2])
+    out, dx, dW = R.transducer_out_step(x, W, tg, sl, tl, delay_scale=0.0, ce_scale=0.7, loss_scale=2.0)
+    # with delay_scale = 0 the transducer term is the plain NLL, whose gradient torch can reproduce from the oracle's dlogits
+    xt, Wt = torch.tensor(x, requires_grad=True), torch.tensor(W, requires_grad=True)
+    logits = xt @ Wt.T
+    _, dl = R.rnnt_loss(logits.detach().numpy(), tg, sl, tl)
+    last = xt[torch.arange(B), torch.tensor(sl) - 1][:, :-1]
+    lp = torch.log_softmax((last @ Wt.T).reshape(B * (U - 1), V), -1)
+    t = torch.tensor(tg).reshape(-1, 1)
+    nl = (-lp.gather(-1, t)).masked_fill(t.eq(1), 0.0).sum(); sm = (-lp.sum(-1, keepdim=True)).masked_fill(t.eq(1), 0.0).sum()
+    eps_i = 0.1 / (V - 1)
+    ce = (1.0 - 0.1 - eps_i) * nl + eps_i * sm
+    (2.0 * ((logits * torch.tensor(dl)).sum() + 0.7 * ce)).backward()
+    np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(dW, Wt.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(out["loss"], out["loss_prob"] + 0.7 * ce.item(), rtol=1e-12)

@@ -16,6 +16,7 @@
 //                   replaces the reference's memset pass over the whole gradient.
 // HBM-bound: rows_kernel reads 4 V bytes per valid row, grad_kernel reads 4 V and writes 4 V bytes per row.
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 #include <math.h>
 #include "../../include/w2vs_rnnt.h"
 
@@ -282,8 +283,15 @@ __device__ __forceinline__ float grad_elem(const RowK& k, float x, int v) {
   return (g + k.scale * g2) * k.up;
 }
 
-template <bool DELAY>
-__global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void grad_kernel(const float* __restrict__ acts, float* __restrict__ grads,
+// OUT16: gradients as bf16 (what the projection's dgrad / wgrad GEMMs consume) - halves the kernel's write traffic
+__device__ __forceinline__ unsigned short to_bf16(float v) {                // round to nearest even
+  unsigned int x = __float_as_uint(v);
+  if ((x & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((x >> 16) | 0x40);
+  return (unsigned short)((x + 0x7fffu + ((x >> 16) & 1u)) >> 16);
+}
+
+template <bool DELAY, bool OUT16>
+__global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void grad_kernel(const float* __restrict__ acts, void* __restrict__ grads_,
                                                                     const int* __restrict__ labels,
                                                                     const int* __restrict__ xlen, const int* __restrict__ ylen,
                                                                     const float* __restrict__ delay_values, Work w, Dims d,
@@ -297,10 +305,18 @@ __global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void grad_kernel(const float*
   const long bt = row / d.maxU;
   const int t = (int)(bt % d.maxT), b = (int)(bt / d.maxT);
   const int T = clampi(xlen[b], 1, d.maxT), U = clampi(ylen[b] + 1, 1, d.maxU);   // lengths past the tensor would read out of bounds
-  float* g = grads + row * d.V;
+  float* g = (float*)grads_ + (OUT16 ? 0 : row * d.V);
+  unsigned short* g16 = (unsigned short*)grads_ + (OUT16 ? row * d.V : 0);
   const bool vec = (d.V & 3) == 0;
   if (t >= T || u >= U) {                              // the reference zeroes the whole tensor first
-    if (vec) {
+    if (OUT16) {
+      if (vec) {
+        uint2* g2 = (uint2*)g16;
+        for (int i = lane; i < (d.V >> 2); i += WAVE) g2[i] = make_uint2(0u, 0u);
+      } else {
+        for (int i = lane; i < d.V; i += WAVE) g16[i] = 0;
+      }
+    } else if (vec) {
       float4* g4 = (float4*)g;
       for (int i = lane; i < (d.V >> 2); i += WAVE) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
@@ -356,10 +372,17 @@ __global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void grad_kernel(const float*
       o.y = grad_elem(k, v.y, 4 * i + 1);
       o.z = grad_elem(k, v.z, 4 * i + 2);
       o.w = grad_elem(k, v.w, 4 * i + 3);
-      g4[i] = o;
+      if (OUT16)
+        ((uint2*)g16)[i] = make_uint2((unsigned)to_bf16(o.x) | ((unsigned)to_bf16(o.y) << 16),
+                                      (unsigned)to_bf16(o.z) | ((unsigned)to_bf16(o.w) << 16));
+      else
+        g4[i] = o;
     }
   } else {
-    for (int i = lane; i < d.V; i += WAVE) g[i] = grad_elem(k, x[i], i);
+    for (int i = lane; i < d.V; i += WAVE) {
+      const float o = grad_elem(k, x[i], i);
+      if (OUT16) g16[i] = to_bf16(o); else g[i] = o;
+    }
   }
 }
 
@@ -390,6 +413,57 @@ __global__ void delay_values_kernel(int kind, const int* __restrict__ src, const
     v = v / tl;
   }
   out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ label-smoothed CE rows
+// fairseq label_smoothed_nll_loss (fs/criterions/label_smoothed_cross_entropy.py:33-50) on log_softmax(logits), summed
+// over rows whose target is not `pad`, as TransducerOut.cross_entropy uses it (rain/layers/attention_transducer.py:339-360):
+//   nll = lse - x_y ; smooth = V lse - sum x ; loss = (1 - eps - eps_i) nll + eps_i smooth,  eps_i = eps / (V - 1)
+// One wave per row: statistics in one pass, then (optionally) the gradient row
+//   d loss / d x_v = (1 - eps - eps_i) (p_v - [v = y]) + eps_i (V p_v - 1), times `scale`.
+template <bool OUT16>
+__global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void ls_ce_kernel(const float* __restrict__ logits, const int* __restrict__ target,
+                                                                     void* __restrict__ grads_, float* __restrict__ sums, long R,
+                                                                     int V, int pad, float eps, float scale) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int y = target[row];
+  const float* x = logits + row * V;
+  float* g = (float*)grads_ + (OUT16 ? 0 : row * V);
+  unsigned short* g16 = (unsigned short*)grads_ + (OUT16 ? row * V : 0);
+  if (y == pad || y < 0 || y >= V) {
+    if (grads_)
+      for (int i = lane; i < V; i += WAVE) { if (OUT16) g16[i] = 0; else g[i] = 0.f; }
+    return;
+  }
+  float m = -INFINITY, s = 0.f, sx = 0.f;
+  for (int i = lane; i < V; i += WAVE) {
+    const float v = x[i];
+    online_add(m, s, v);
+    sx += v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, WAVE), s2 = __shfl_xor(s, o, WAVE);
+    const float mm = fmaxf(m, m2);
+    s = ((m == -INFINITY) ? 0.f : s * expf(m - mm)) + ((m2 == -INFINITY) ? 0.f : s2 * expf(m2 - mm));
+    m = mm;
+    sx += __shfl_xor(sx, o, WAVE);
+  }
+  const float lse = m + logf(s);
+  const float eps_i = eps / (float)(V - 1), c_nll = 1.f - eps - eps_i;
+  if (lane == 0) {
+    const float nll = lse - x[y], smooth = (float)V * lse - sx;
+    atomicAdd(&sums[0], c_nll * nll + eps_i * smooth);
+    atomicAdd(&sums[1], nll);
+  }
+  if (!grads_) return;
+  const float cp = (c_nll + eps_i * (float)V) * scale;
+  for (int i = lane; i < V; i += WAVE) {
+    const float p = expf(x[i] - lse);
+    const float o = cp * p - (i == y ? c_nll * scale : 0.f) - eps_i * scale;
+    if (OUT16) g16[i] = to_bf16(o); else g[i] = o;
+  }
 }
 
 rnntStatus_t check(const float* acts, const int* labels, const int* ylen, const int* xlen, void* workspace, int V, int B,
@@ -426,7 +500,7 @@ rnntStatus_t run_fwd(const float* acts, const int* labels, const int* ylen, cons
 }
 
 // gradient rows; needs the workspace run_fwd filled for the same arguments
-rnntStatus_t run_bwd(const float* acts, float* grads, const int* labels, const int* ylen, const int* xlen,
+rnntStatus_t run_bwd(const float* acts, void* grads, const int* labels, const int* ylen, const int* xlen,
                      const float* delay_values, int V, int B, void* workspace, float delay_scale, float smooth, int flags,
                      const float* up_dev, int up_n, float up_host, const rnntOptions& opt) {
   const rnntStatus_t rc = check(acts, labels, ylen, xlen, workspace, V, B, opt);
@@ -439,12 +513,14 @@ rnntStatus_t run_bwd(const float* acts, float* grads, const int* labels, const i
   Work w = carve(workspace, B, opt.maxT, opt.maxU, delay);
   const long rows = (long)B * opt.maxT * opt.maxU;
   const unsigned row_blocks = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-  if (delay)
-    hipLaunchKernelGGL(grad_kernel<true>, dim3(row_blocks), dim3(WAVE * ROWS_PER_BLOCK), 0, st, acts, grads, labels, xlen,
-                       ylen, delay_values, w, d, delay_scale, smooth, flags & 1, up_dev, up_n, up_host);
-  else
-    hipLaunchKernelGGL(grad_kernel<false>, dim3(row_blocks), dim3(WAVE * ROWS_PER_BLOCK), 0, st, acts, grads, labels, xlen,
-                       ylen, delay_values, w, d, 0.f, smooth, 0, up_dev, up_n, up_host);
+  const dim3 gr(row_blocks), bl(WAVE * ROWS_PER_BLOCK);
+  const bool o16 = (flags & 2) != 0;
+#define W2VS_GRAD(DL, O16)                                                                                              \
+  hipLaunchKernelGGL((grad_kernel<DL, O16>), gr, bl, 0, st, acts, grads, labels, xlen, ylen, delay_values, w, d,         \
+                     DL ? delay_scale : 0.f, smooth, DL ? (flags & 1) : 0, up_dev, up_n, up_host)
+  if (delay) { if (o16) W2VS_GRAD(true, true); else W2VS_GRAD(true, false); }
+  else       { if (o16) W2VS_GRAD(false, true); else W2VS_GRAD(false, false); }
+#undef W2VS_GRAD
   return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
 
@@ -527,13 +603,24 @@ rnntStatus_t w2vs_rnnt_forward_async(const float* activations, const int* flat_l
                  workspace, delay_scale, options);
 }
 
-rnntStatus_t w2vs_rnnt_backward_async(const float* activations, float* gradients, const int* flat_labels,
+rnntStatus_t w2vs_rnnt_backward_async(const float* activations, void* gradients, const int* flat_labels,
                                       const int* label_lengths, const int* input_lengths, const float* delay_values,
                                       int alphabet_size, int minibatch, void* workspace, float delay_scale, float smooth,
                                       int flags, const float* grad_scale_dev, int grad_scale_n, float grad_scale_host,
                                       rnntOptions options) {
   return run_bwd(activations, gradients, flat_labels, label_lengths, input_lengths, delay_values, alphabet_size, minibatch,
                  workspace, delay_scale, smooth, flags, grad_scale_dev, grad_scale_n, grad_scale_host, options);
+}
+
+rnntStatus_t w2vs_ls_ce_rows(const float* logits, const int* target, void* grads, float* sums2, int64_t rows, int V, int pad,
+                             float epsilon, float grad_scale, int grads_bf16, void* stream) {
+  if (!logits || !target || !sums2 || rows <= 0 || V <= 1) return RNNT_STATUS_INVALID_VALUE;
+  const dim3 gr((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), bl(WAVE * ROWS_PER_BLOCK);
+  if (grads_bf16)
+    hipLaunchKernelGGL(ls_ce_kernel<true>, gr, bl, 0, (hipStream_t)stream, logits, target, grads, sums2, (long)rows, V, pad, epsilon, grad_scale);
+  else
+    hipLaunchKernelGGL(ls_ce_kernel<false>, gr, bl, 0, (hipStream_t)stream, logits, target, grads, sums2, (long)rows, V, pad, epsilon, grad_scale);
+  return hipGetLastError() == hipSuccess ? RNNT_STATUS_SUCCESS : RNNT_STATUS_EXECUTION_FAILED;
 }
 
 rnntStatus_t w2vs_rnnt_delay_values(int kind, const int* src_lens, const int* tgt_lens, float* out, int minibatch, int maxT,

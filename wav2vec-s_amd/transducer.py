@@ -46,8 +46,10 @@ def _rnnt_lib():
         lib.w2vs_rnnt_backward_async.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, f32, i32, vp, i32, f32,
                                                  RnntOptions]
         lib.w2vs_rnnt_delay_values.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
+        lib.w2vs_ls_ce_rows.argtypes = [vp, vp, vp, vp, C.c_int64, i32, i32, f32, f32, i32, vp]
         for n in ("get_workspace_size", "get_delay_workspace_size", "compute_rnnt_loss", "compute_rnnt_delay_loss",
-                  "w2vs_rnnt_forward_async", "w2vs_rnnt_backward_async", "w2vs_rnnt_delay_values", "get_warprnnt_version"):
+                  "w2vs_rnnt_forward_async", "w2vs_rnnt_backward_async", "w2vs_rnnt_delay_values", "get_warprnnt_version",
+                  "w2vs_ls_ce_rows"):
             getattr(lib, n).restype = C.c_int
         _SIGS_DONE = True
     return lib
@@ -55,7 +57,7 @@ def _rnnt_lib():
 
 RNNT_EXPORTS = ["get_warprnnt_version", "rnntGetStatusString", "compute_rnnt_loss", "get_workspace_size",
                 "compute_rnnt_delay_loss", "get_delay_workspace_size", "w2vs_rnnt_forward_async",
-                "w2vs_rnnt_backward_async", "w2vs_rnnt_delay_values"]
+                "w2vs_rnnt_backward_async", "w2vs_rnnt_delay_values", "w2vs_ls_ce_rows"]
 
 
 def _check(rc, what):
@@ -251,3 +253,143 @@ class RNNTLoss(Module):
 
     def forward(self, acts, labels, act_lens, label_lens):
         return rnnt_loss(acts, labels, act_lens, label_lens, self.blank, self.reduction)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The loss head of the CAAT transducer: output projection + delay-transducer loss + label-smoothed CE on the last frame
+# ---------------------------------------------------------------------------------------------------------------------
+class TransducerOut(Module):
+    """rain/layers/attention_transducer.py:289-456.  "This module is special": ``train_step`` runs the forward AND the
+    backward of the head itself, in micro-batches bounded by ``tokens_per_step`` lattice cells, accumulates the
+    gradient of ``output_proj`` and pushes the gradient of the joint states ``x`` into the rest of the network with ONE
+    ``autograd.backward(x, input_grads)`` (:401).
+
+    Same constructor arguments, same methods and result dictionaries.  The computation is explicit HIP launches instead
+    of an autograd graph per micro-batch: logits = x W^T (bf16 MFMA GEMM, fp32 out) -> transducer forward -> gradient
+    rows written directly as bf16 with the loss scale folded in -> d x = d logits W and d W += d logits^T x (bf16 GEMMs,
+    fp32 accumulation); the cross-entropy branch likewise (``w2vs_ls_ce_rows``).  Losses stay on the device.
+    ``output_proj`` must be a bias-free ``nn.Linear`` (what the reference builds, :851) with widths multiple of 8."""
+
+    def __init__(self, output_proj, delay_scale=1.0, tokens_per_step=20000, blank=0, smoothing=0.0, label_smoothing=0.1,
+                 delay_func="zero", pad=1, ce_scale=1.0, temperature=1.0):
+        super().__init__()
+        self.rnnt_loss = DelayTLoss(blank=blank, delay_scale=delay_scale, temperature=temperature, reduction="sum",
+                                    delay_func=delay_func)
+        self.output_proj = output_proj
+        self.vocab_size = output_proj.weight.shape[0]
+        self.delay_scale, self.tokens_per_step, self.smoothing, self.pad = delay_scale, tokens_per_step, smoothing, pad
+        self.label_smoothing, self.ce_scale = label_smoothing, ce_scale
+        self.blank, self.temperature = blank, temperature
+        if getattr(output_proj, "bias", None) is not None:
+            raise W2vsError("TransducerOut: output_proj must be bias-free (rain/layers/attention_transducer.py:851)")
+
+    # ---- plumbing
+    def _w16(self):
+        w = self.output_proj.weight.detach()
+        return (w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)).contiguous()
+
+    @staticmethod
+    def _logits(x2, w16):
+        from . import ops
+        R, d = x2.shape
+        V = w16.shape[0]
+        out = torch.empty(R, V, dtype=torch.float32, device=x2.device)
+        ops.gemm_nt(x2, w16, M=R, N=V, K=d, lda=d, ldb=d, ldc=V, out_f32=out, epi=_lib.EPI_F32)
+        return out
+
+    def forward(self, x):
+        """:320-321 ``self.output_proj(x)`` (model dtype in and out)."""
+        if not x.is_cuda:
+            raise W2vsError("TransducerOut runs on an MI355X only (there is no CPU path)")
+        shp = x.shape
+        x2 = x.detach().to(torch.bfloat16).reshape(-1, shp[-1]).contiguous()
+        return self._logits(x2, self._w16()).view(*shp[:-1], self.vocab_size).to(x.dtype)
+
+    def _chunk(self, x, targets, slen, tlen, w16, wt16, dw32, loss_scale):
+        """One micro-batch: returns (loss_total, loss_prob, loss_delay, nll) as device scalars and d x (bf16), or None
+        for d x when ``dw32`` is None (evaluation)."""
+        from . import ops
+        lib = _rnnt_lib()
+        B, T, U, d = x.shape
+        V = self.vocab_size
+        dev = x.device
+        train = dw32 is not None
+        x2 = x.reshape(-1, d)
+        logits = self._logits(x2, w16)                                        # [B*T*U, V] fp32 (:375-376)
+        lab, sl, tl = targets.int().contiguous(), slen.int().contiguous(), tlen.int().contiguous()
+        logits4 = logits.view(B, T, U, V)
+        dv = self.rnnt_loss.delay_func(logits4, sl, tl)
+        ws = torch.empty(workspace_bytes(T, U, B, True) // 4, dtype=torch.float32, device=dev)
+        costs = torch.empty(3, B, dtype=torch.float32, device=dev)
+        opt = _options(logits4, self.blank)
+        _check(lib.w2vs_rnnt_forward_async(logits.data_ptr(), lab.data_ptr(), tl.data_ptr(), sl.data_ptr(), dv.data_ptr(), V, B,
+                                           costs.data_ptr(), ws.data_ptr(), float(self.delay_scale), opt), "w2vs_rnnt_forward_async")
+        dx = None
+        if train:
+            dl = torch.empty(B * T * U, V, dtype=torch.bfloat16, device=dev)
+            _check(lib.w2vs_rnnt_backward_async(logits.data_ptr(), dl.data_ptr(), lab.data_ptr(), tl.data_ptr(), sl.data_ptr(),
+                                                dv.data_ptr(), V, B, ws.data_ptr(), float(self.delay_scale),
+                                                float(self.temperature), 2, None, 0, float(loss_scale), opt),
+                   "w2vs_rnnt_backward_async")
+            dx = ops.linear_dgrad(dl, wt16)                                   # [B*T*U, d] bf16
+            ops.linear_wgrad(dl, x2, dw32)
+            del dl
+        del logits, logits4
+        # ---- cross-entropy on the hidden state at each sample's last frame (:339-360)
+        bidx = torch.arange(B, device=dev)
+        last_h = x[bidx, (slen.long() - 1).clamp_(0, T - 1)][:, :-1].contiguous()      # [B, U-1, d]
+        R2 = B * (U - 1)
+        logits2 = self._logits(last_h.view(R2, d), w16)
+        sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        tgt = targets.int().contiguous()
+        if tuple(tgt.shape) != (B, U - 1):
+            raise W2vsError("TransducerOut: targets must be [B, U-1] for joint states [B, T, U, d]")
+        dl2 = torch.empty(R2, V, dtype=torch.bfloat16, device=dev) if train else None
+        _check(lib.w2vs_ls_ce_rows(logits2.data_ptr(), tgt.data_ptr(), dl2.data_ptr() if train else None, sums.data_ptr(), R2, V,
+                                   int(self.pad), float(self.label_smoothing), float(self.ce_scale * loss_scale), 1,
+                                   torch.cuda.current_stream(dev).cuda_stream), "w2vs_ls_ce_rows")
+        if train:
+            dh = ops.linear_dgrad(dl2, wt16).view(B, U - 1, d)
+            ops.linear_wgrad(dl2, last_h.view(R2, d), dw32)
+            dx4 = dx.view(B, T, U, d)
+            dx4[bidx, (slen.long() - 1).clamp_(0, T - 1), :U - 1] += dh      # one (b, t) row per sample: no collisions
+        loss = costs[2].sum() + self.ce_scale * sums[0]
+        return (loss, costs[0].sum(), costs[1].sum(), sums[1]), dx
+
+    def _run(self, x, targets, src_lengths, tgt_lengths, scaler, train):
+        from . import ops
+        if not x.is_cuda:
+            raise W2vsError("TransducerOut runs on an MI355X only (there is no CPU path)")
+        B, T, U, d = x.shape
+        bsz_per_step = max(self.tokens_per_step // (T * U), 1)                 # :370, :421
+        w16 = self._w16()
+        wt16 = ops.transpose2d(w16) if train else None
+        dw32 = torch.zeros(w16.shape, dtype=torch.float32, device=x.device) if train else None
+        loss_scale = float(scaler.get_scale()) if (scaler is not None and train) else 1.0
+        xs = x.detach()
+        xs = (xs if xs.dtype == torch.bfloat16 else xs.to(torch.bfloat16)).contiguous()
+        losses = [0, 0, 0, 0]
+        grads = []
+        for i in range(0, B, bsz_per_step):
+            j = min(i + bsz_per_step, B)
+            ls, dx = self._chunk(xs[i:j], targets[i:j], src_lengths[i:j], tgt_lengths[i:j], w16, wt16, dw32, loss_scale)
+            losses = [a + b.detach() for a, b in zip(losses, ls)]
+            if train:
+                grads.append(dx.view(j - i, T, U, d))
+        if train:
+            w = self.output_proj.weight
+            g = dw32.to(w.dtype)
+            w.grad = g if w.grad is None else w.grad + g
+            torch.autograd.backward(x, torch.cat(grads, dim=0).to(x.dtype))    # :401
+        ntokens = targets.ne(self.pad).sum().item()
+        return {"loss": losses[0], "loss_prob": losses[1], "loss_delay": losses[2], "nll_loss": losses[3],
+                "sample_size": ntokens}
+
+    def train_step(self, x, targets, src_lengths, tgt_lengths, scaler=None):
+        """:362-408.  x [B, T, U+1, d] joint states (requires grad), targets [B, U]."""
+        return self._run(x, targets, src_lengths, tgt_lengths, scaler, True)
+
+    def eval_step(self, x, targets, src_lengths, tgt_lengths):
+        """:410-446."""
+        with torch.no_grad():
+            return self._run(x, targets, src_lengths, tgt_lengths, None, False)
