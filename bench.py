@@ -224,7 +224,7 @@ def main():
                    "tokens_last_step": {"T": st.T, "N": st.N, "M": st.M, "m": st.m, "r": st.r}},
         "roofline": roof,
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg runs at N = 1 only
         threads = min(os.cpu_count() or 1, 16)
         out["cpu_baseline"] = cpu_baseline(threads)
     if dist is not None:
