@@ -135,7 +135,9 @@ class TrainStep:
         if self.exchange is not None:
             self.exchange.finish()
             # the global sample_size: mask lengths can differ across ranks (own batches, own masks)
-            ss = torch.tensor([float(sample_size)], device=f.p16.device)
+            # torch.full is a fill kernel with the value as a launch argument; torch.tensor([...], device=) would be a
+            # synchronous pageable H2D copy on this stream, i.e. the host would wait for the whole backward every step
+            ss = torch.full((1,), float(sample_size), device=f.p16.device, dtype=torch.float32)
             self.dist.all_reduce(ss)
             self.ss_dev = ss
             total = None
