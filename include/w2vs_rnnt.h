@@ -99,15 +99,19 @@ rnntStatus_t get_delay_workspace_size(int maxT, int maxU, int minibatch, bool gp
  * (= 0) - the reference multiplies the finished gradient tensor once more in Python (delay_transducer.py:86-90).
  * flags bit 0: read the emission cost in the gradient as delay_values[b, t, u] instead of the reference's
  * delay_values[b * maxT + t] (gpu_rnnt_kernel.h:409 indexes the B x T x U array with a B x T index; clear = reproduce).
- * flags bit 1: write the gradients as bf16 (what the GEMMs of the output projection's backward consume). */
+ * flags bit 1: write the gradients as bf16 (what the GEMMs of the output projection's backward consume).
+ * cell_index / n_cells (both calls): NULL / 0 = dense activations [B, maxT, maxU, V].  Otherwise activations and gradients
+ * hold ONLY the n_cells lattice cells cell_index[i] = (b * maxT + t) * maxU + u (device, int32; every cell with t < T_b and
+ * u <= U_b must be listed): a ragged batch then costs the projection GEMMs and these kernels nothing for its padding. */
 rnntStatus_t w2vs_rnnt_forward_async(const float* activations, const int* flat_labels, const int* label_lengths,
                                      const int* input_lengths, const float* delay_values, int alphabet_size, int minibatch,
-                                     float* costs_dev, void* workspace, float delay_scale, struct rnntOptions options);
+                                     float* costs_dev, void* workspace, float delay_scale, struct rnntOptions options,
+                                     const int* cell_index, int64_t n_cells);
 rnntStatus_t w2vs_rnnt_backward_async(const float* activations, void* gradients, const int* flat_labels,
                                       const int* label_lengths, const int* input_lengths, const float* delay_values,
                                       int alphabet_size, int minibatch, void* workspace, float delay_scale, float smooth,
                                       int flags, const float* grad_scale_dev, int grad_scale_n, float grad_scale_host,
-                                      struct rnntOptions options);
+                                      struct rnntOptions options, const int* cell_index, int64_t n_cells);
 /* Label-smoothed cross-entropy rows: fairseq's label_smoothed_nll_loss (fs/criterions/label_smoothed_cross_entropy.py:33-50)
  * on log_softmax(logits [rows, V] fp32), summed over rows whose target != pad, as TransducerOut.cross_entropy uses it
  * (rain/layers/attention_transducer.py:339-360).  sums2[0] += loss, sums2[1] += nll (device, caller zeroes); grads: NULL

@@ -52,9 +52,9 @@ def main(argv=None, cpu_baseline=None):
     grads = torch.empty_like(acts)
     opt = tr._options(acts, 0)
     args_f = (acts.data_ptr(), lab.data_ptr(), yl.data_ptr(), xl.data_ptr(), dv.data_ptr(), V, B, costs.data_ptr(),
-              ws.data_ptr(), 1.0, opt)
+              ws.data_ptr(), 1.0, opt, None, 0)
     args_b = (acts.data_ptr(), grads.data_ptr(), lab.data_ptr(), yl.data_ptr(), xl.data_ptr(), dv.data_ptr(), V, B,
-              ws.data_ptr(), 1.0, 1.0, 0, None, 0, 1.0, opt)
+              ws.data_ptr(), 1.0, 1.0, 0, None, 0, 1.0, opt, None, 0)
     t_f = ev_time(lambda: lib.w2vs_rnnt_forward_async(*args_f))
     t_b = ev_time(lambda: lib.w2vs_rnnt_backward_async(*args_b))
     valid = int((xl.long() * (yl.long() + 1)).sum())
@@ -65,7 +65,7 @@ def main(argv=None, cpu_baseline=None):
     acts_s = acts[..., :8].contiguous()
     lab_s = (lab % 7 + 1).to(torch.int32)
     args_s = (acts_s.data_ptr(), lab_s.data_ptr(), yl.data_ptr(), xl.data_ptr(), dv.data_ptr(), 8, B, costs.data_ptr(),
-              ws.data_ptr(), 1.0, opt)
+              ws.data_ptr(), 1.0, opt, None, 0)
     t_lat = ev_time(lambda: lib.w2vs_rnnt_forward_async(*args_s))
     lib.w2vs_rnnt_forward_async(*args_f)
     rep = {"shape": {"B": B, "T": T, "U": U, "V": V, "valid_cells": valid, "cells": rows},

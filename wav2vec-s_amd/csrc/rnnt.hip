@@ -27,6 +27,8 @@ constexpr int ROWS_PER_BLOCK = 4;     // 256 threads, one wave per row
 
 struct Dims {
   int B, maxT, maxU, V, blank, D;     // D = maxT + maxU - 1 anti-diagonals
+  const int* cells;                   // compact mode: acts / grads hold ONLY these cells (b*maxT*maxU + t*maxU + u), in this
+  long n_rows;                        // order; NULL = dense [B, maxT, maxU, V].  n_rows = rows of acts / grads
 };
 
 struct Work {                         // workspace carve-up (floats)
@@ -94,15 +96,16 @@ __global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void rows_kernel(const float*
                                                                     const int* __restrict__ xlen,
                                                                     const int* __restrict__ ylen, Work w, Dims d) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  const long rows = (long)d.B * d.maxT * d.maxU;
-  if (row >= rows) return;
+  const long arow = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);    // row of acts
+  if (arow >= d.n_rows) return;
+  const long row = d.cells ? (long)d.cells[arow] : arow;                        // lattice cell
+  if (row < 0 || row >= (long)d.B * d.maxT * d.maxU) return;
   const int u = (int)(row % d.maxU);
   const long bt = row / d.maxU;
   const int t = (int)(bt % d.maxT), b = (int)(bt / d.maxT);
   const int T = clampi(xlen[b], 1, d.maxT), U = clampi(ylen[b] + 1, 1, d.maxU);   // lengths past the tensor would read out of bounds
   if (t >= T || u >= U) return;                       // never read: the lattice and the gradient skip these cells
-  const float* x = acts + row * d.V;
+  const float* x = acts + arow * d.V;
   float m = -INFINITY, s = 0.f;
   if ((d.V & 3) == 0) {
     const float4* x4 = (const float4*)x;
@@ -298,17 +301,19 @@ __global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void grad_kernel(const float*
                                                                     float delay_scale, float smooth, int consistent_index,
                                                                     const float* __restrict__ up_dev, int up_n, float up_host) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  const long rows = (long)d.B * d.maxT * d.maxU;
-  if (row >= rows) return;
+  const long arow = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);    // row of acts / grads
+  if (arow >= d.n_rows) return;
+  long row = d.cells ? (long)d.cells[arow] : arow;                              // lattice cell
+  const bool in_range = row >= 0 && row < (long)d.B * d.maxT * d.maxU;
+  if (!in_range) row = 0;
   const int u = (int)(row % d.maxU);
   const long bt = row / d.maxU;
   const int t = (int)(bt % d.maxT), b = (int)(bt / d.maxT);
   const int T = clampi(xlen[b], 1, d.maxT), U = clampi(ylen[b] + 1, 1, d.maxU);   // lengths past the tensor would read out of bounds
-  float* g = (float*)grads_ + (OUT16 ? 0 : row * d.V);
-  unsigned short* g16 = (unsigned short*)grads_ + (OUT16 ? row * d.V : 0);
+  float* g = (float*)grads_ + (OUT16 ? 0 : arow * d.V);
+  unsigned short* g16 = (unsigned short*)grads_ + (OUT16 ? arow * d.V : 0);
   const bool vec = (d.V & 3) == 0;
-  if (t >= T || u >= U) {                              // the reference zeroes the whole tensor first
+  if (!in_range || t >= T || u >= U) {                              // the reference zeroes the whole tensor first
     if (OUT16) {
       if (vec) {
         uint2* g2 = (uint2*)g16;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(WAVE* ROWS_PER_BLOCK) void grad_kernel(const float*
   if (has_t) k.sub_blank += expf(smooth * (a - ll + b_t1 + logpb));                    // :416
   k.sub_label = has_u ? expf(smooth * (a + b_u1 - ll + logpy)) : 0.f;                  // :420
   if (!has_t && has_u) { /* t = T-1, u < U-1: only the label transition leaves the cell */ }
-  const float* x = acts + row * d.V;
+  const float* x = acts + arow * d.V;
   if (vec) {
     const float4* x4 = (const float4*)x;
     float4* g4 = (float4*)g;
@@ -478,14 +483,16 @@ rnntStatus_t check(const float* acts, const int* labels, const int* ylen, const 
 
 // rows + lattice (+ device costs)
 rnntStatus_t run_fwd(const float* acts, const int* labels, const int* ylen, const int* xlen, const float* delay_values, int V,
-                     int B, float* costs_dev, void* workspace, float delay_scale, const rnntOptions& opt) {
+                     int B, float* costs_dev, void* workspace, float delay_scale, const rnntOptions& opt,
+                     const int* cells = nullptr, long n_cells = 0) {
   const rnntStatus_t rc = check(acts, labels, ylen, xlen, workspace, V, B, opt);
   if (rc != RNNT_STATUS_SUCCESS) return rc;
   const bool delay = delay_values != nullptr;
   hipStream_t st = (hipStream_t)opt.stream;
-  Dims d{B, opt.maxT, opt.maxU, V, opt.blank_label, opt.maxT + opt.maxU - 1};
+  if (cells && n_cells <= 0) return RNNT_STATUS_INVALID_VALUE;
+  const long rows = cells ? n_cells : (long)B * opt.maxT * opt.maxU;
+  Dims d{B, opt.maxT, opt.maxU, V, opt.blank_label, opt.maxT + opt.maxU - 1, cells, rows};
   Work w = carve(workspace, B, opt.maxT, opt.maxU, delay);
-  const long rows = (long)B * opt.maxT * opt.maxU;
   const unsigned row_blocks = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   hipLaunchKernelGGL(rows_kernel, dim3(row_blocks), dim3(WAVE * ROWS_PER_BLOCK), 0, st, acts, labels, xlen, ylen, w, d);
   const int W = ((opt.maxU + WAVE - 1) / WAVE) * WAVE;
@@ -502,16 +509,18 @@ rnntStatus_t run_fwd(const float* acts, const int* labels, const int* ylen, cons
 // gradient rows; needs the workspace run_fwd filled for the same arguments
 rnntStatus_t run_bwd(const float* acts, void* grads, const int* labels, const int* ylen, const int* xlen,
                      const float* delay_values, int V, int B, void* workspace, float delay_scale, float smooth, int flags,
-                     const float* up_dev, int up_n, float up_host, const rnntOptions& opt) {
+                     const float* up_dev, int up_n, float up_host, const rnntOptions& opt, const int* cells = nullptr,
+                     long n_cells = 0) {
   const rnntStatus_t rc = check(acts, labels, ylen, xlen, workspace, V, B, opt);
   if (rc != RNNT_STATUS_SUCCESS) return rc;
   if (!grads || ((uintptr_t)grads & 15) || (up_n != 0 && up_n != 1 && up_n != B) || (up_n != 0 && !up_dev))
     return RNNT_STATUS_INVALID_VALUE;
   const bool delay = delay_values != nullptr;
   hipStream_t st = (hipStream_t)opt.stream;
-  Dims d{B, opt.maxT, opt.maxU, V, opt.blank_label, opt.maxT + opt.maxU - 1};
+  if (cells && n_cells <= 0) return RNNT_STATUS_INVALID_VALUE;
+  const long rows = cells ? n_cells : (long)B * opt.maxT * opt.maxU;
+  Dims d{B, opt.maxT, opt.maxU, V, opt.blank_label, opt.maxT + opt.maxU - 1, cells, rows};
   Work w = carve(workspace, B, opt.maxT, opt.maxU, delay);
-  const long rows = (long)B * opt.maxT * opt.maxU;
   const unsigned row_blocks = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   const dim3 gr(row_blocks), bl(WAVE * ROWS_PER_BLOCK);
   const bool o16 = (flags & 2) != 0;
@@ -597,19 +606,21 @@ rnntStatus_t get_delay_workspace_size(int maxT, int maxU, int minibatch, bool gp
 
 rnntStatus_t w2vs_rnnt_forward_async(const float* activations, const int* flat_labels, const int* label_lengths,
                                      const int* input_lengths, const float* delay_values, int alphabet_size, int minibatch,
-                                     float* costs_dev, void* workspace, float delay_scale, rnntOptions options) {
+                                     float* costs_dev, void* workspace, float delay_scale, rnntOptions options,
+                                     const int* cell_index, int64_t n_cells) {
   if (!costs_dev) return RNNT_STATUS_INVALID_VALUE;
   return run_fwd(activations, flat_labels, label_lengths, input_lengths, delay_values, alphabet_size, minibatch, costs_dev,
-                 workspace, delay_scale, options);
+                 workspace, delay_scale, options, cell_index, (long)n_cells);
 }
 
 rnntStatus_t w2vs_rnnt_backward_async(const float* activations, void* gradients, const int* flat_labels,
                                       const int* label_lengths, const int* input_lengths, const float* delay_values,
                                       int alphabet_size, int minibatch, void* workspace, float delay_scale, float smooth,
                                       int flags, const float* grad_scale_dev, int grad_scale_n, float grad_scale_host,
-                                      rnntOptions options) {
+                                      rnntOptions options, const int* cell_index, int64_t n_cells) {
   return run_bwd(activations, gradients, flat_labels, label_lengths, input_lengths, delay_values, alphabet_size, minibatch,
-                 workspace, delay_scale, smooth, flags, grad_scale_dev, grad_scale_n, grad_scale_host, options);
+                 workspace, delay_scale, smooth, flags, grad_scale_dev, grad_scale_n, grad_scale_host, options, cell_index,
+                 (long)n_cells);
 }
 
 rnntStatus_t w2vs_ls_ce_rows(const float* logits, const int* target, void* grads, float* sums2, int64_t rows, int V, int pad,

@@ -42,9 +42,9 @@ def _rnnt_lib():
         lib.get_delay_workspace_size.argtypes = [i32, i32, i32, C.c_bool, C.POINTER(C.c_size_t), C.c_size_t]
         lib.compute_rnnt_loss.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, RnntOptions]
         lib.compute_rnnt_delay_loss.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, RnntOptions]
-        lib.w2vs_rnnt_forward_async.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, f32, RnntOptions]
+        lib.w2vs_rnnt_forward_async.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, f32, RnntOptions, vp, C.c_int64]
         lib.w2vs_rnnt_backward_async.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, f32, f32, i32, vp, i32, f32,
-                                                 RnntOptions]
+                                                 RnntOptions, vp, C.c_int64]
         lib.w2vs_rnnt_delay_values.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp]
         lib.w2vs_ls_ce_rows.argtypes = [vp, vp, vp, vp, C.c_int64, i32, i32, f32, f32, i32, vp]
         for n in ("get_workspace_size", "get_delay_workspace_size", "compute_rnnt_loss", "compute_rnnt_delay_loss",
@@ -148,7 +148,7 @@ class _Transducer(Function):
         opt = _options(x, blank)
         dvp = delay_values.data_ptr() if delay_values is not None else None
         _check(lib.w2vs_rnnt_forward_async(x.data_ptr(), labels.data_ptr(), label_lens.data_ptr(), act_lens.data_ptr(), dvp,
-                                           V, B, costs.data_ptr(), ws.data_ptr(), float(delay_scale), opt),
+                                           V, B, costs.data_ptr(), ws.data_ptr(), float(delay_scale), opt, None, 0),
                "w2vs_rnnt_forward_async")
         ctx.saved = (x, labels, act_lens, label_lens, delay_values, ws)
         ctx.args = (float(delay_scale), int(blank), float(temperature), reduction, bool(consistent_delay_index))
@@ -174,7 +174,7 @@ class _Transducer(Function):
         _check(lib.w2vs_rnnt_backward_async(x.data_ptr(), grads.data_ptr(), labels.data_ptr(), label_lens.data_ptr(),
                                             act_lens.data_ptr(), dvp, V, B, ws.data_ptr(), delay_scale, temperature,
                                             1 if consistent else 0, up.data_ptr(), up.numel(),
-                                            1.0 / B if reduction == "mean" else 1.0, opt), "w2vs_rnnt_backward_async")
+                                            1.0 / B if reduction == "mean" else 1.0, opt, None, 0), "w2vs_rnnt_backward_async")
         return grads, None, None, None, None, None, None, None, None, None
 
 
@@ -305,36 +305,47 @@ class TransducerOut(Module):
         x2 = x.detach().to(torch.bfloat16).reshape(-1, shp[-1]).contiguous()
         return self._logits(x2, self._w16()).view(*shp[:-1], self.vocab_size).to(x.dtype)
 
-    def _chunk(self, x, targets, slen, tlen, w16, wt16, dw32, loss_scale):
+    def _chunk(self, x, targets, slen, tlen, w16, wt16, dw32, loss_scale, slen_h, tlen_h):
         """One micro-batch: returns (loss_total, loss_prob, loss_delay, nll) as device scalars and d x (bf16), or None
-        for d x when ``dw32`` is None (evaluation)."""
+        for d x when ``dw32`` is None (evaluation).  Only the lattice cells inside each sample's T_b x (U_b + 1) go
+        through the projection, the loss kernels and the two gradient GEMMs (``cell_index`` of the async API): the padding
+        of a ragged batch costs nothing."""
         from . import ops
+        import numpy as np
         lib = _rnnt_lib()
         B, T, U, d = x.shape
         V = self.vocab_size
         dev = x.device
         train = dw32 is not None
         x2 = x.reshape(-1, d)
-        logits = self._logits(x2, w16)                                        # [B*T*U, V] fp32 (:375-376)
+        tt = np.arange(T)[None, :, None] < np.clip(slen_h, 1, T)[:, None, None]
+        uu = np.arange(U)[None, None, :] < np.clip(tlen_h + 1, 1, U)[:, None, None]
+        cells_h = torch.from_numpy(np.flatnonzero(tt & uu).astype(np.int32)).pin_memory()
+        n = int(cells_h.numel())
+        cells = cells_h.to(dev, non_blocking=True)
+        xc = ops.gather_rows(x2, cells, n)                                    # [n, d] bf16
+        logits = self._logits(xc, w16)                                        # [n, V] fp32 (:375-376)
         lab, sl, tl = targets.int().contiguous(), slen.int().contiguous(), tlen.int().contiguous()
-        logits4 = logits.view(B, T, U, V)
-        dv = self.rnnt_loss.delay_func(logits4, sl, tl)
+        dv = self.rnnt_loss.delay_func(x, sl, tl)                             # [B, T, U] (only the shape of x is used)
         ws = torch.empty(workspace_bytes(T, U, B, True) // 4, dtype=torch.float32, device=dev)
         costs = torch.empty(3, B, dtype=torch.float32, device=dev)
-        opt = _options(logits4, self.blank)
+        opt = RnntOptions(1, 0, torch.cuda.current_stream(dev).cuda_stream, int(self.blank), T, U, True)
         _check(lib.w2vs_rnnt_forward_async(logits.data_ptr(), lab.data_ptr(), tl.data_ptr(), sl.data_ptr(), dv.data_ptr(), V, B,
-                                           costs.data_ptr(), ws.data_ptr(), float(self.delay_scale), opt), "w2vs_rnnt_forward_async")
+                                           costs.data_ptr(), ws.data_ptr(), float(self.delay_scale), opt, cells.data_ptr(), n),
+               "w2vs_rnnt_forward_async")
         dx = None
         if train:
-            dl = torch.empty(B * T * U, V, dtype=torch.bfloat16, device=dev)
+            dl = torch.empty(n, V, dtype=torch.bfloat16, device=dev)
             _check(lib.w2vs_rnnt_backward_async(logits.data_ptr(), dl.data_ptr(), lab.data_ptr(), tl.data_ptr(), sl.data_ptr(),
                                                 dv.data_ptr(), V, B, ws.data_ptr(), float(self.delay_scale),
-                                                float(self.temperature), 2, None, 0, float(loss_scale), opt),
+                                                float(self.temperature), 2, None, 0, float(loss_scale), opt, cells.data_ptr(), n),
                    "w2vs_rnnt_backward_async")
-            dx = ops.linear_dgrad(dl, wt16)                                   # [B*T*U, d] bf16
-            ops.linear_wgrad(dl, x2, dw32)
-            del dl
-        del logits, logits4
+            dxc = ops.linear_dgrad(dl, wt16)                                  # [n, d] bf16
+            ops.linear_wgrad(dl, xc, dw32)
+            dx = torch.zeros(B * T * U, d, dtype=torch.bfloat16, device=dev)
+            ops.gather_rows(dxc, cells, n, scatter=True, out=dx)
+            del dl, dxc
+        del logits, xc
         # ---- cross-entropy on the hidden state at each sample's last frame (:339-360)
         bidx = torch.arange(B, device=dev)
         last_h = x[bidx, (slen.long() - 1).clamp_(0, T - 1)][:, :-1].contiguous()      # [B, U-1, d]
@@ -358,6 +369,7 @@ class TransducerOut(Module):
 
     def _run(self, x, targets, src_lengths, tgt_lengths, scaler, train):
         from . import ops
+        import numpy as np
         if not x.is_cuda:
             raise W2vsError("TransducerOut runs on an MI355X only (there is no CPU path)")
         B, T, U, d = x.shape
@@ -368,11 +380,15 @@ class TransducerOut(Module):
         loss_scale = float(scaler.get_scale()) if (scaler is not None and train) else 1.0
         xs = x.detach()
         xs = (xs if xs.dtype == torch.bfloat16 else xs.to(torch.bfloat16)).contiguous()
+        # the one host round trip of the step (the reference has one too: `.item()` on the token count, :402): the lengths decide
+        # which lattice cells exist, and only those are projected
+        slen_h, tlen_h = src_lengths.cpu().numpy().astype(np.int64), tgt_lengths.cpu().numpy().astype(np.int64)
         losses = [0, 0, 0, 0]
         grads = []
         for i in range(0, B, bsz_per_step):
             j = min(i + bsz_per_step, B)
-            ls, dx = self._chunk(xs[i:j], targets[i:j], src_lengths[i:j], tgt_lengths[i:j], w16, wt16, dw32, loss_scale)
+            ls, dx = self._chunk(xs[i:j], targets[i:j], src_lengths[i:j], tgt_lengths[i:j], w16, wt16, dw32, loss_scale,
+                                 slen_h[i:j], tlen_h[i:j])
             losses = [a + b.detach() for a, b in zip(losses, ls)]
             if train:
                 grads.append(dx.view(j - i, T, U, d))
