@@ -76,3 +76,34 @@ def test_gen_block_atten_mask_api_helper(T, m, r):
     if r > 0:
         assert torch.equal(x2[T:], x.index_select(0, rc_idx))
         assert torch.equal(pad2[:, T:], pad.index_select(1, rc_idx) | rc_oob.unsqueeze(0))
+
+
+def test_online_encoder_loads_both_checkpoint_styles(golden_dir, tmp_path):
+    """rain/layers/unidirect_w2v2_encoder.py:541-556: new checkpoints carry cfg["model"], old ones an argparse Namespace in
+    ckpt["args"] (for which extractor_mode / pos_type are forced); the caller's contexts replace the checkpoint's."""
+    from wav2vec_s_amd import streaming
+    z = np.load(os.path.join(golden_dir, "stream_online.npz"))
+    over = ast.literal_eval(bytes(z["cfg_json"]).decode())
+    sd = {k[len("param.w2v2_model."):]: torch.tensor(z[k]) for k in z.files if k.startswith("param.w2v2_model.")}
+    new_style = os.path.join(tmp_path, "new.pt")
+    old_style = os.path.join(tmp_path, "old.pt")
+    torch.save({"args": None, "cfg": {"model": dict(over)}, "model": sd}, new_style)
+    old_args = argparse.Namespace(**dict(over, extractor_mode="default", pos_type="conv"))
+    torch.save({"args": old_args, "model": sd}, old_style)
+    for path in (new_style, old_style):
+        args = argparse.Namespace(w2v2_model_path=path, main_context=4, right_context=2, use_linear_layer=True,
+                                  encoder_embed_dim=over["encoder_embed_dim"], freeze_finetune_updates=3)
+        enc = streaming.OnlineW2V2TransformerEncoder(args)
+        assert enc.encoder_proj is None                          # same width: no projection (:566-568)
+        assert (enc.w2v2_model.cfg.main_context, enc.w2v2_model.cfg.right_context) == (4, 2)
+        assert enc.w2v2_model.cfg.extractor_mode == "layer_norm" and enc.w2v2_model.cfg.pos_type == "sin"
+        assert enc.init_frames == 6 and enc.step_frames == 4
+        for k, v in enc.w2v2_model.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+        enc.set_num_updates(2)
+        assert enc.num_updates == 2 and not (enc.freeze_finetune_updates <= enc.num_updates)
+    args = argparse.Namespace(w2v2_model_path=new_style, main_context=4, right_context=2, use_linear_layer=True,
+                              encoder_embed_dim=48)
+    enc = streaming.OnlineW2V2TransformerEncoder(args)
+    assert enc.encoder_proj is not None and tuple(enc.encoder_proj.weight.shape) == (48, over["encoder_embed_dim"])
+    assert enc.freeze_finetune_updates == -1                     # default: tuned from the first update
