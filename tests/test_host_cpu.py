@@ -176,3 +176,17 @@ def test_rnnt_header_symbols_are_exported():
     for n in names:
         getattr(lib, n)
     assert ctypes.sizeof(transducer.RnntOptions) == 32
+
+
+def test_public_headers_compile_as_c_and_cpp(tmp_path):
+    """include/*.h is the drop-in boundary: plain C (what a cgo / ctypes / JNI binding consumes) and C++."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    src = '#include "w2vs.h"\n#include "w2vs_rnnt.h"\nint main(void){ struct rnntOptions o; (void)o; return (int)sizeof(w2vs_collate_desc) == 0; }\n'
+    inc = os.path.join(ROOT, "include")
+    for name, cc, std in (("h.c", "gcc", "-std=c99"), ("h.cpp", "g++", "-std=c++17")):
+        p = os.path.join(tmp_path, name)
+        open(p, "w").write(src)
+        subprocess.check_call([cc, std, "-Wall", "-Werror", "-I", inc, "-c", p, "-o", p + ".o"])
