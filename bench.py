@@ -201,7 +201,8 @@ def main():
     # same command (counters cannot be read in-process); the committed summary is quoted here, null if it is absent
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")))
-        key = {"gemm_tn_lc_kernel": "w2vs::gemm_tn_lc_kernel<true>", "gemm_tn_kernel": "w2vs::gemm_tn_kernel"}.get(
+        key = {"gemm_tn_lc_kernel": "w2vs::gemm_tn_lc_kernel<true>", "gemm_tn_kernel": "w2vs::gemm_tn_kernel",
+               "gemm_tn_group_kernel": "w2vs::gemm_tn_group_kernel"}.get(
             roof["kernel"].split(" ")[0])
         if key in pmc:
             roof["traffic"] = int((pmc[key]["read_MB_per_launch_corrected"] + pmc[key]["write_MB_per_launch"]) * 1e6)

@@ -78,6 +78,11 @@ int w2vs_gemm_tune(int32_t nt_mode, int32_t lc_height, int32_t tn_lc);
 int w2vs_prof_enable(int stride);
 int w2vs_prof_read(int id, double* total_ms, double* total_flops, int* launches);
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
+/* n <= 4 weight-gradient GEMMs (e.g. the four of one encoder layer: fused QKV, out_proj, fc1, fc2) as ONE launch without
+ * a K split: together their 256x128 tiles fill the chip, every tile has a single writer (C += A^T B with plain stores:
+ * no partial-tile workspace, no summing launch, no atomics except the optional column sums).  Same result as n calls of
+ * w2vs_gemm_tn; falls back to exactly that when the group does not qualify. */
+int w2vs_gemm_tn_group(const w2vs_gemm_desc* descs, int32_t n, int32_t num_cu_hint, void* stream);
 
 /* ---- conv layer 0: Conv1d(1->C,k,s) + Fp32LayerNorm(C) + GELU ------------------------------
  * fs/models/wav2vec/wav2vec2.py:733-743, 773-781 (layer 0 of ConvFeatureExtractionModel).
@@ -187,6 +192,9 @@ typedef struct w2vs_layer_desc {
    * (s1, x1, hpre, h, s2, x_out, mean/rstd then hold n_sel rows, in sel_idx order) and the attention takes the
    * n_q = Tp main frames as queries.  ctx_sel / xin_sel: [n_sel, E] scratch kept for the backward. */
   const int32_t* sel_idx; int32_t n_sel, n_q; void* ctx_sel; void* xin_sel;
+  /* optional fourth [R,E] backward scratch: with it (and without sel_idx) layer_bwd keeps every weight-gradient operand
+   * alive to the end of the layer and computes the four weight gradients as ONE w2vs_gemm_tn_group launch */
+  void* ws_e3;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

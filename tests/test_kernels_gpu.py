@@ -616,3 +616,34 @@ def test_conv0_ln_gelu_with_conv_bias(ops):
     assert rel(db, bf_.grad) < 5e-3
     # d(conv bias) is a sum of the LayerNorm-backward output, which is zero-mean per frame: compare with an absolute floor
     assert float((dcb.cpu() - cbf.grad).abs().max()) < 5e-3 * max(1.0, float(cbf.grad.abs().max())) + 2e-2
+
+
+def test_gemm_tn_group_equals_single_launches():
+    """w2vs_gemm_tn_group: the four weight gradients of an encoder layer (shared token dimension) in one launch, no K
+    split, single writer per tile - same result as four w2vs_gemm_tn calls, accumulation into non-zero targets and the
+    bias column sums included; and the fallback when the group does not qualify."""
+    from wav2vec_s_amd import ops
+    g = torch.Generator().manual_seed(0)
+    R, E, F = 5584, 768, 3072
+    mk = lambda r, c: (torch.randn(r, c, generator=g) * 0.5).to(BF).cuda()      # noqa: E731
+    dys = [mk(R, E), mk(R, F), mk(R, E), mk(R, 3 * E)]
+    xs = [mk(R, F), mk(R, E), mk(R, E), mk(R, E)]
+
+    def targets():
+        gg = torch.Generator().manual_seed(1)
+        return ([torch.randn(dy.shape[1], x.shape[1], generator=gg).cuda() for dy, x in zip(dys, xs)],
+                [torch.randn(dy.shape[1], generator=gg).cuda() for dy in dys])
+    w1, b1 = targets()
+    for dy, x, w, b in zip(dys, xs, w1, b1):
+        ops.linear_wgrad(dy, x, w, 0.5, b)
+    w2, b2 = targets()
+    ops.gemm_tn_group([dict(a=dy, b=x, out_f32=w, M=dy.shape[1], N=x.shape[1], K=R, lda=dy.shape[1], ldb=x.shape[1],
+                            ldc=x.shape[1], alpha=0.5, colsum_out=b) for dy, x, w, b in zip(dys, xs, w2, b2)])
+    for a, b in zip(w1 + b1, w2 + b2):
+        assert rel(b, a) < 2e-5, rel(b, a)            # same products, different (K-split) summation order
+    ref = (dys[1].float().t() @ xs[1].float()) * 0.5
+    assert rel(w2[1] - targets()[0][1], ref) < 2e-3
+    # a group that does not fill half the chip runs as single launches (the same kernels linear_wgrad uses)
+    w3, b3 = targets()
+    ops.gemm_tn_group([dict(a=dys[2], b=xs[2], out_f32=w3[2], M=E, N=E, K=R, lda=E, ldb=E, ldc=E, alpha=0.5, colsum_out=b3[2])])
+    assert torch.equal(w3[2], w1[2]) and rel(b3[2], b1[2]) < 1e-5     # the column sums arrive through atomics: order varies

@@ -76,7 +76,7 @@ class LayerDesc(C.Structure):
                     "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_ln1_g", "g_ln1_b", "g_w1", "g_b1", "g_w2", "g_b2",
                     "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta",
                     "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64), ("sel_idx", vp), ("n_sel", i32),
-                                                                            ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp)])
+                                                                            ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp), ("ws_e3", vp)])
 
 
 class CollateDesc(C.Structure):
@@ -92,6 +92,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_A
 _SIGS = {
     "w2vs_gemm_nt": [C.POINTER(GemmDesc), vp],
     "w2vs_gemm_tn": [C.POINTER(GemmDesc), i32, vp],
+    "w2vs_gemm_tn_group": [vp, i32, i32, vp],
     "w2vs_prof_enable": [i32],
     "w2vs_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)],
     "w2vs_conv0_fwd": [vp] * 8 + [i32] * 5 + [vp],

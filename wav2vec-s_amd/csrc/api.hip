@@ -38,6 +38,7 @@ int w2vs_prof_enable(int stride) { prof_enable(stride); return 0; }
 int w2vs_prof_read(int id, double* ms, double* flops, int* n) { return prof_read(id, ms, flops, n); }
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* s) { NONNULL(d); return gemm_nt(*d, ST(s)); }
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int cu, void* s) { NONNULL(d); return gemm_tn(*d, cu, ST(s)); }
+int w2vs_gemm_tn_group(const w2vs_gemm_desc* d, int32_t n, int32_t cu, void* s) { NONNULL(d); return gemm_tn_group(d, n, cu, ST(s)); }
 int w2vs_conv0_fwd(const void* wave, const void* w, const void* cb, const void* lw, const void* lb, void* y, float* mean,
                    float* rstd, int B, int L, int C, int k, int st, void* s) {
   return conv0_fwd(wave, w, cb, lw, lb, y, mean, rstd, B, L, C, k, st, ST(s));

@@ -932,32 +932,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmP p) {
 // added with fp32 atomics.  The optional column sum of A (bias gradient) rides on the matrix cores: consumers
 // with wn == 0 of the tn == 0 blocks multiply their A fragments with an all-ones B fragment.
 // ---------------------------------------------------------------------------------------------
-template <bool SLAB>
-__global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
+// MODE 0: partial sums added with fp32 atomics; 1: partial tiles to the slab (summing launch follows); 2: the ONLY writer
+// of its tile (no K split): Cf tile += acc with plain 16-byte loads / stores
+template <int MODE>
+__device__ __forceinline__ void tn_lc_body(const GemmP& p, const int tm_, const int tn_, const int zz) {
+  constexpr bool SLAB = MODE == 1;
   constexpr int IMG = TK * TP;                       // one [64][128] image, 16 KiB
   constexpr int STAGE_EL = 3 * IMG, NST = 3, LP = 12;
   __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];   // 144 KiB
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool loader = wid >= 8;
   const int wm = (wid >> 1) & 3, wn = wid & 1;
-  // XCD-aware order over the WHOLE 3-D grid: workgroups are dealt to the 8 XCDs round-robin in dispatch order
-  // (x fastest, then y, then z); every XCD gets one contiguous run of (K-split, tile) pairs, K-split major and
-  // tiles in group-M order, i.e. a few M tiles x all N tiles of one token range.  With the per-plane order the
-  // three planes of an encoder wgrad put three different token ranges on every XCD and the kernel fetched 3.2x
-  // its algorithmic bytes (rocprofv3 FETCH_SIZE: 199 MB per launch, ~5 TB/s of fabric traffic).
-  int tm_, tn_, zz;
-  {
-    const int plane = gridDim.x * gridDim.y, nwg = plane * gridDim.z;
-    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = lin & 7;
-    const int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (lin >> 3);
-    zz = id / plane;
-    const int t = id - zz * plane, ntm = gridDim.y, ntn = gridDim.x, GM = 4;
-    const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
-    const int gsz = min(ntm - first_m, GM), in_group = t - group * per_group;
-    tm_ = first_m + in_group % gsz;
-    tn_ = in_group / gsz;
-  }
   const int m0 = tm_ * 256, n0 = tn_ * 128;
   const int bz = zz / p.n_split, sp = zz % p.n_split;
   const int k_begin = sp * p.k_split;
@@ -1079,6 +1064,11 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
       if (SLAB) {
         *(f32x4*)(p.slab + ((long)zz * p.M + row) * p.N + col) =
             f32x4{acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+      } else if (MODE == 2) {
+        f32x4* dst = (f32x4*)(p.Cf + (long)row * p.ldc + col);
+        f32x4 o = *dst;
+        o[0] += acc[i][j][0] * p.alpha; o[1] += acc[i][j][1] * p.alpha; o[2] += acc[i][j][2] * p.alpha; o[3] += acc[i][j][3] * p.alpha;
+        *dst = o;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) atomicAdd(&p.Cf[(long)row * p.ldc + col + r], acc[i][j][r] * p.alpha);
@@ -1091,6 +1081,50 @@ __global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
       if (row < p.M) atomicAdd(&p.colsum[row], cs[i][0] * p.alpha);
     }
   }
+}
+
+template <bool SLAB>
+__global__ __launch_bounds__(768) void gemm_tn_lc_kernel(GemmP p) {
+  // XCD-aware order over the WHOLE 3-D grid: workgroups are dealt to the 8 XCDs round-robin in dispatch order
+  // (x fastest, then y, then z); every XCD gets one contiguous run of (K-split, tile) pairs, K-split major and
+  // tiles in group-M order, i.e. a few M tiles x all N tiles of one token range.  With the per-plane order the
+  // three planes of an encoder wgrad put three different token ranges on every XCD and the kernel fetched 3.2x
+  // its algorithmic bytes (rocprofv3 FETCH_SIZE: 199 MB per launch, ~5 TB/s of fabric traffic).
+  int tm_, tn_, zz;
+  {
+    const int plane = gridDim.x * gridDim.y, nwg = plane * gridDim.z;
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = lin & 7;
+    const int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (lin >> 3);
+    zz = id / plane;
+    const int t = id - zz * plane, ntm = gridDim.y, ntn = gridDim.x, GM = 4;
+    const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
+    const int gsz = min(ntm - first_m, GM), in_group = t - group * per_group;
+    tm_ = first_m + in_group % gsz;
+    tn_ = in_group / gsz;
+  }
+  tn_lc_body<SLAB ? 1 : 0>(p, tm_, tn_, zz);
+}
+
+// Several weight-gradient GEMMs that share the reduction dimension (the four of one encoder layer) as ONE launch, no K
+// split: 54 + 18 + 72 + 72 tiles fill 216 CUs with full-length K loops, every tile has a single writer (no partial-tile
+// slab, no summing launch, no atomics), and one ramp-up / tail instead of four.
+struct TnGroupP { GemmP p[4]; int first[5]; };
+__global__ __launch_bounds__(768) void gemm_tn_group_kernel(TnGroupP g) {
+  const int nwg = gridDim.x, lin = blockIdx.x;
+  const int qd = nwg >> 3, rm = nwg & 7, xcd = lin & 7;
+  const int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (lin >> 3);   // contiguous run per XCD
+  int pi = 0;
+  if (id >= g.first[1]) pi = 1;
+  if (id >= g.first[2]) pi = 2;
+  if (id >= g.first[3]) pi = 3;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  const GemmP& p = g.p[pi];
+  const int t = id - g.first[pi];
+  const int ntm = (p.M + 255) / 256, ntn = (p.N + 127) / 128, GM = 4;
+  const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
+  const int gsz = min(ntm - first_m, GM), in_group = t - group * per_group;
+  tn_lc_body<2>(p, first_m + in_group % gsz, in_group / gsz, 0);
 }
 
 // Cf[m][n] += sum over parts of slab[part][m][n]   (M x N fp32, N % 4 == 0; Cf rows are ldc apart)
@@ -1322,6 +1356,47 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, s, p);
   prof_end(pe, 7, 2.0 * d.M * d.N * d.K * nb, s);
   return hip_check(hipGetLastError(), "gemm_tn launch");
+}
+
+// n <= 4 weight-gradient GEMMs in one launch (see gemm_tn_group_kernel).  Falls back to one gemm_tn per problem when the
+// group does not qualify (alignment, batching, more tiles than CUs, tiny K).
+int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
+  if (!ds || n < 1 || n > 4) return set_error("gemm_tn_group: 1..4 problems");
+  const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
+  TnGroupP g{};
+  int tiles = 0;
+  double flops = 0;
+  bool ok = true;
+  for (int i = 0; i < n; ++i) {
+    const GemmDesc& d = ds[i];
+    if (int e = check_common(d)) return e;
+    if (!d.Cf) return set_error("gemm_tn: needs an fp32 accumulation target");
+    if ((d.M % 8) || (d.N % 8)) return set_error("gemm_tn: M and N must be multiples of 8");
+    GemmP& p = g.p[i];
+    p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.Cf = d.Cf;
+    p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.a_off = d.a_off; p.alpha = d.alpha;
+    p.colsum = d.colsum;
+    const long a_ext = d.a_bytes ? d.a_bytes : ((long)d.a_off + (long)(d.K - 1) * d.lda + d.M) * 2;
+    const long b_ext = d.b_bytes ? d.b_bytes : ((long)(d.K - 1) * d.ldb + d.N) * 2;
+    if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_tn: operand extent must be < 2 GiB per batch");
+    p.a_bytes = (uint32_t)a_ext; p.b_bytes = (uint32_t)b_ext;
+    p.k_split = ((d.K + TK - 1) / TK) * TK; p.n_split = 1;
+    g.first[i] = tiles;
+    tiles += ((d.N + 127) / 128) * ((d.M + 255) / 256);
+    flops += 2.0 * d.M * d.N * d.K;
+    ok = ok && (d.batch <= 1) && d.sC == 0 && (d.ldc % 4) == 0 && ((uintptr_t)d.Cf % 16) == 0 && d.K >= 8 * TK;
+  }
+  for (int i = n; i <= 4; ++i) g.first[i] = tiles;
+  static const int grp_env = [] { const char* e = getenv("W2VS_TN_GROUP"); return e ? atoi(e) : 1; }();
+  if (!ok || tiles > ncu || tiles < ncu / 2 || !grp_env) {
+    for (int i = 0; i < n; ++i)
+      if (int e = gemm_tn(ds[i], num_cu_hint, s)) return e;
+    return 0;
+  }
+  hipEvent_t pe = prof_begin(s);
+  hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles), dim3(768), 0, s, g);
+  prof_end(pe, 9, flops, s);                       // id 9: the grouped weight-gradient launch
+  return hip_check(hipGetLastError(), "gemm_tn_group launch");
 }
 
 }  // namespace w2vs

@@ -38,6 +38,15 @@ static int lin_wgrad(const void* dy, const void* x, float* dw, float* db, int R,
   return gemm_tn(d, num_cu, s);
 }
 
+static GemmDesc wgrad_desc(const void* dy, const void* x, float* dw, float* db, int R, int N, int K, void* ws, int64_t ws_bytes) {
+  GemmDesc d{};
+  d.ws = ws; d.ws_bytes = ws_bytes;
+  d.A = dy; d.B = x; d.Cf = dw;
+  d.M = N; d.N = K; d.K = R; d.batch = 1; d.lda = N; d.ldb = K; d.ldc = K; d.alpha = 1.f;
+  d.colsum = db;
+  return d;
+}
+
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
 
 static int layer_check(const w2vs_layer_desc& L) {
@@ -121,25 +130,35 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   b2.p_drop = L.p_drop; b2.seed = L.seed_drop2; b2.out_scale = 1.f;
   b2.ws = L.ws_f; b2.ws_bytes = (int64_t)R * F * 2;   // ws_f is not live yet: dgamma/dbeta partial slab
   TRY(ln_bwd(b2, s));
+  // With a fourth [R,E] scratch (ws_e3) every operand of the four weight gradients stays alive to the end of the layer
+  // (d_f in ws_e0, d_hpre in ws_f, d_a in ws_e3, d_qkv in ws_qkv) and they run as ONE grouped launch without a K split
+  // (gemm_tn_group: 216 tiles of full-length K loops, no partial-tile slab, no summing launches).  Not in selected-rows
+  // mode, whose scatter step reuses ws_e0 / ws_f.
+  const bool defer = L.ws_e3 != nullptr && !sel;
+  void* d_a = defer ? L.ws_e3 : L.ws_e0;
   // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
-  TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, Rt, E, F, cu, s, L.tn_ws, L.tn_ws_bytes));
+  if (!defer) TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, Rt, E, F, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w2, L.wt_scratch, E, F, 1, s));           // [E,F] -> [F,E]
   TRY(lin_dgrad(L.ws_e0, pre_t ? L.w2_t : L.wt_scratch, L.ws_f, L.hpre, Rt, E, F, EPI_MUL, s));
   // fc1: wgrad, bias, dgrad + residual branch -> d_x1 (ws_e2)
-  TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, Rt, F, E, cu, s, L.tn_ws, L.tn_ws_bytes));
+  if (!defer) TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, Rt, F, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));           // [F,E] -> [E,F]
   TRY(lin_dgrad(L.ws_f, pre_t ? L.w1_t : L.wt_scratch, L.ws_e2, L.ws_e1, Rt, F, E, EPI_ADD, s));
-  // LN1 backward: d_a = ds1 o dropmask (ws_e0), d_xin_a = ds1 (ws_e1)
+  // LN1 backward: d_a = ds1 o dropmask, d_xin_a = ds1 (ws_e1)
   LnBwdDesc b1{};
   b1.x = L.s1; b1.gamma = L.ln1_g; b1.beta = L.ln1_b; b1.mean = L.mean1; b1.rstd = L.rstd1; b1.dy = L.ws_e2;
-  b1.dx = L.ws_e0; b1.dres = L.ws_e1; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = Rt; b1.C = E;
+  b1.dx = d_a; b1.dres = L.ws_e1; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = Rt; b1.C = E;
   b1.p_drop = L.p_drop; b1.seed = L.seed_drop1; b1.out_scale = 1.f;
-  b1.ws = L.ws_f; b1.ws_bytes = (int64_t)R * F * 2;   // fc1's wgrad/dgrad (enqueued above) were its last readers
+  if (defer) {                                         // ws_f still holds d_hpre: the partial slab goes to the GEMM scratch
+    b1.ws = L.tn_ws; b1.ws_bytes = L.tn_ws_bytes;
+  } else {
+    b1.ws = L.ws_f; b1.ws_bytes = (int64_t)R * F * 2;   // fc1's wgrad/dgrad (enqueued above) were its last readers
+  }
   TRY(ln_bwd(b1, s));
   // out_proj
-  TRY(lin_wgrad(L.ws_e0, ctx, L.g_wo, L.g_bo, Rt, E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
+  if (!defer) TRY(lin_wgrad(L.ws_e0, ctx, L.g_wo, L.g_bo, Rt, E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wo, L.wt_scratch, E, E, 1, s));
-  TRY(lin_dgrad(L.ws_e0, pre_t ? L.wo_t : L.wt_scratch, L.ws_e2, nullptr, Rt, E, E, EPI_NONE, s));   // d_ctx
+  TRY(lin_dgrad(d_a, pre_t ? L.wo_t : L.wt_scratch, L.ws_e2, nullptr, Rt, E, E, EPI_NONE, s));   // d_ctx
   const void* d_ctx = L.ws_e2;
   const void* d_res = L.ws_e1;
   if (sel) {
@@ -162,9 +181,17 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   a.dq = L.ws_qkv; a.dk = (char*)L.ws_qkv + E2; a.dv = (char*)L.ws_qkv + 2 * E2;
   TRY(attn_bwd(a, s));
   // fused QKV projection
-  TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
+  if (!defer) TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wqkv, L.wt_scratch, 3 * E, E, 1, s));     // [3E,E] -> [E,3E]
   TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, d_res, R, 3 * E, E, EPI_ADD, s));
+  if (defer) {
+    const GemmDesc g[4] = {
+        wgrad_desc(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, L.tn_ws, L.tn_ws_bytes),           // fc1   [F,E]
+        wgrad_desc(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, L.tn_ws, L.tn_ws_bytes),           // fc2   [E,F]
+        wgrad_desc(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, L.tn_ws, L.tn_ws_bytes),   // qkv [3E,E]
+        wgrad_desc(L.ws_e3, ctx, L.g_wo, L.g_bo, R, E, E, L.tn_ws, L.tn_ws_bytes)};          // out_proj [E,E]
+    TRY(gemm_tn_group(g, 4, cu, s));
+  }
   return 0;
 }
 

@@ -8,6 +8,7 @@ arena (the buffer the data-parallel all-reduce later works on).  No torch math o
 the path; torch allocates buffers and carries views.
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -392,6 +393,8 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
 # The last encoder layer of a pre-training step computes only what the loss reads (masked frames); tests switch it off
 # to compare the full encoder output.
 SELECT_LAST_LAYER = True
+# the four weight gradients of a post-LN layer as one grouped launch (w2vs_gemm_tn_group); W2VS_GROUP_WGRADS=0 disables
+GROUP_WGRADS = os.environ.get("W2VS_GROUP_WGRADS", "1") != "0"
 
 _POS_TABLES = {}
 
@@ -542,6 +545,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 offs[f_] = wp + 2 * o
                 o += n_
             d_in_bufs = [offs["d_in_a"], None]
+            e3 = ops.empty((R, E), BF16, dev) if GROUP_WGRADS else None    # fourth [R,E] scratch: grouped weight gradients
             alt = ops.empty((R, E), BF16, dev)
             d_in_bufs[1] = alt.data_ptr()
             cur = dx
@@ -576,6 +580,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 for f_ in ("ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch"):
                     setattr(d, f_, offs[f_])
                 d.delta = delta.data_ptr()
+                d.ws_e3 = e3.data_ptr() if e3 is not None else None
                 off_w = A.offsets[pre + "self_attn.q_proj.weight"][0]
                 off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
                 fp = A.flat.data_ptr()
@@ -592,7 +597,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 else:
                     cur = ws[(3 * R * E + R * F + 3 * R * E):(3 * R * E + R * F + 3 * R * E) + R * E].view(R, E)
             dx = cur
-            st._bwd_ws = (ws, alt, delta)
+            st._bwd_ws = (ws, alt, delta, e3)
         d_x0 = dx
     else:
         d_s = None

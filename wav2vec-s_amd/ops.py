@@ -117,7 +117,7 @@ class _GemmTimer:
         names = {0: "gemm_nt_kernel<none>", 1: "gemm_nt_kernel<bias>", 2: "gemm_nt_kernel<bias_gelu>",
                  3: "gemm_nt_kernel<bias_gelu_save>", 4: "gemm_nt_kernel<dgelu>", 5: "gemm_nt_kernel<f32>",
                  6: "gemm_nt_kernel<add>", 7: "gemm_tn_kernel",
-                 8: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)"}
+                 8: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)", 9: "gemm_tn_group_kernel"}
         groups = {}
         for k in names:
             ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
@@ -190,6 +190,26 @@ def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB
     ev = GEMM_TIMER.begin()
     _lib.call("w2vs_gemm_tn", C.byref(d), num_cu, _stream())
     GEMM_TIMER.end(ev, "tn", 2.0 * M * N * K * batch)
+
+
+def gemm_tn_group(problems, num_cu=256):
+    """problems: up to 4 dicts with the keyword arguments of ``gemm_tn`` (a, b, out_f32, M, N, K, lda, ldb, ldc[, alpha,
+    colsum_out]): weight-gradient GEMMs sharing the reduction dimension, enqueued as ONE launch (w2vs_gemm_tn_group)."""
+    n = len(problems)
+    arr = (GemmDesc * n)()
+    flops = 0.0
+    ws = tn_workspace(problems[0]["a"].device)
+    for d, pr in zip(arr, problems):
+        d.A, d.B, d.Cf = _p(pr["a"]), _p(pr["b"]), _p(pr["out_f32"])
+        d.M, d.N, d.K, d.batch = pr["M"], pr["N"], pr["K"], 1
+        d.lda, d.ldb, d.ldc = pr["lda"], pr["ldb"], pr["ldc"]
+        d.alpha = pr.get("alpha", 1.0)
+        d.colsum = _p(pr.get("colsum_out"))
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4       # only used if the group falls back to single launches
+        flops += 2.0 * d.M * d.N * d.K
+    ev = GEMM_TIMER.begin()
+    _lib.call("w2vs_gemm_tn_group", arr, n, num_cu, _stream())
+    GEMM_TIMER.end(ev, "tn", flops)
 
 
 def linear_fwd(x, w, bias=None, *, gelu=False, save_pre=False, save_grad=False):
