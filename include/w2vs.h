@@ -77,6 +77,8 @@ int w2vs_gemm_tune(int32_t nt_mode, int32_t lc_height, int32_t tn_lc);
  * and the number of launches timed since the last enable. */
 int w2vs_prof_enable(int stride);
 int w2vs_prof_read(int id, double* total_ms, double* total_flops, int* launches);
+/* every launch of that kernel id since w2vs_prof_enable (the timed ones are a 1-in-stride sample of them) */
+int64_t w2vs_prof_launches(int id);
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
 /* n <= 4 weight-gradient GEMMs (e.g. the four of one encoder layer: fused QKV, out_proj, fc1, fc2) as ONE launch without
  * a K split: together their 256x128 tiles fill the chip, every tile has a single writer (C += A^T B with plain stores:

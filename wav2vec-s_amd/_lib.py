@@ -95,6 +95,7 @@ _SIGS = {
     "w2vs_gemm_tn_group": [vp, i32, i32, vp],
     "w2vs_prof_enable": [i32],
     "w2vs_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)],
+    "w2vs_prof_launches": [i32],          # returns a count, not a status (read through load(), not call())
     "w2vs_conv0_fwd": [vp] * 8 + [i32] * 5 + [vp],
     "w2vs_conv0_bwd": [vp] * 12 + [i32] * 5 + [vp],
     "w2vs_conv0_gn_fwd": [vp] * 7 + [i32] * 5 + [vp],

@@ -1151,27 +1151,32 @@ struct ProfSample { hipEvent_t e0, e1; int id; double flops; };
 static std::vector<ProfSample> g_prof;
 static int g_prof_stride = 0;
 static long g_prof_count = 0;
+static long g_prof_launches[64] = {0};      // every launch per id since prof_enable (the sampled ones are a subset)
 void prof_enable(int stride) {
   for (auto& s : g_prof) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
   g_prof.clear();
   g_prof_stride = stride;
   g_prof_count = 0;
+  for (long& c : g_prof_launches) c = 0;
 }
-static inline hipEvent_t prof_begin(hipStream_t st) {
+static inline hipEvent_t prof_begin(hipStream_t st, int own_stride = 0) {
   if (g_prof_stride <= 0) return nullptr;
-  if ((g_prof_count++ % g_prof_stride) != 0) return nullptr;
+  static long own_count = 0;                       // kernels launched a few times per step keep their own, denser sample
+  if (own_stride > 0 ? (own_count++ % own_stride) != 0 : (g_prof_count++ % g_prof_stride) != 0) return nullptr;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   (void)hipEventRecord(e, st);
   return e;
 }
 static inline void prof_end(hipEvent_t e0, int id, double flops, hipStream_t st) {
+  if (g_prof_stride > 0 && id >= 0 && id < 64) ++g_prof_launches[id];
   if (!e0) return;
   hipEvent_t e1;
   if (hipEventCreate(&e1) != hipSuccess) return;
   (void)hipEventRecord(e1, st);
   g_prof.push_back({e0, e1, id, flops});
 }
+long prof_launches(int id) { return (id >= 0 && id < 64) ? g_prof_launches[id] : 0; }
 int prof_read(int id, double* total_ms, double* total_flops, int* launches) {
   double ms = 0, fl = 0;
   int n = 0;
@@ -1287,7 +1292,10 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     default: return set_error("gemm_nt: unknown epilogue");
   }
 #undef NT_LAUNCH
-  prof_end(pe, d.epi, 2.0 * d.M * d.N * d.K * (d.batch > 0 ? d.batch : 1), s);
+  // profiling id = one kernel symbol family: 16 * form + epilogue (form 0: gemm_nt_kernel, 1: gemm_nt_lc_kernel, 2: gemm_nt_p_kernel);
+  // the weight-gradient kernels use 10..12 (form 0 epilogues stop at 8)
+  const int form = (mode == 5 || mode == 6) ? 2 : (mode == 3 ? 1 : 0);
+  prof_end(pe, 16 * form + d.epi, 2.0 * d.M * d.N * d.K * (d.batch > 0 ? d.batch : 1), s);
   return hip_check(hipGetLastError(), "gemm_nt launch");
 }
 
@@ -1336,7 +1344,7 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
       } else {
         hipLaunchKernelGGL(gemm_tn_lc_kernel<false>, grid, dim3(768), 0, s, p);
       }
-      prof_end(pe, 8, 2.0 * d.M * d.N * d.K * nb, s);   // id 8: loader/consumer form (+ its summing launch)
+      prof_end(pe, 11, 2.0 * d.M * d.N * d.K * nb, s);  // id 11: loader/consumer form (+ its summing launch); NT launches use ids 0..8 = their epilogue
       return hip_check(hipGetLastError(), "gemm_tn launch");
     }
   }
@@ -1354,7 +1362,7 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, splits * nb), block(256);
   hipEvent_t pe = prof_begin(s);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, s, p);
-  prof_end(pe, 7, 2.0 * d.M * d.N * d.K * nb, s);
+  prof_end(pe, 10, 2.0 * d.M * d.N * d.K * nb, s);  // id 10: 128x128 atomics form
   return hip_check(hipGetLastError(), "gemm_tn launch");
 }
 
@@ -1393,9 +1401,9 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
       if (int e = gemm_tn(ds[i], num_cu_hint, s)) return e;
     return 0;
   }
-  hipEvent_t pe = prof_begin(s);
+  hipEvent_t pe = prof_begin(s, 5);                // ~10 launches per step: every 5th is timed (the global 1-in-29 would see 7 in a run)
   hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles), dim3(768), 0, s, g);
-  prof_end(pe, 9, flops, s);                       // id 9: the grouped weight-gradient launch
+  prof_end(pe, 12, flops, s);                      // id 12: the grouped weight-gradient launch
   return hip_check(hipGetLastError(), "gemm_tn_group launch");
 }
 

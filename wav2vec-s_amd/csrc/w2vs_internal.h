@@ -24,6 +24,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s);
 void gemm_tune(int nt_mode, int lc_height, int tn_lc);
 void prof_enable(int stride);
 int prof_read(int id, double* total_ms, double* total_flops, int* launches);
+long prof_launches(int id);
 int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, void* y,
               float* mean, float* rstd, int B, int L, int C, int k, int s, hipStream_t st);
 int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, const float* mean,

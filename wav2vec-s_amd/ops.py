@@ -114,28 +114,32 @@ class _GemmTimer:
 
     def report(self, peak_tflops):
         torch.cuda.synchronize()
-        names = {0: "gemm_nt_kernel<none>", 1: "gemm_nt_kernel<bias>", 2: "gemm_nt_kernel<bias_gelu>",
-                 3: "gemm_nt_kernel<bias_gelu_save>", 4: "gemm_nt_kernel<dgelu>", 5: "gemm_nt_kernel<f32>",
-                 6: "gemm_nt_kernel<add>", 7: "gemm_tn_kernel",
-                 8: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)", 9: "gemm_tn_group_kernel"}
+        # one id per kernel symbol family: NT = 16 * form + epilogue, the weight-gradient (TN) kernels 10..12
+        epis = ["none", "bias", "bias_gelu", "bias_gelu_save", "dgelu", "f32", "add", "bias_gelu_savegrad", "mul"]
+        names = {16 * f + e: "%s<%s>" % (fn, en) for f, fn in enumerate(("gemm_nt_kernel", "gemm_nt_lc_kernel", "gemm_nt_p_kernel"))
+                 for e, en in enumerate(epis)}
+        names.update({10: "gemm_tn_kernel", 11: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)", 12: "gemm_tn_group_kernel"})
         groups = {}
         for k in names:
             ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
             _lib.call("w2vs_prof_read", k, C.byref(ms), C.byref(fl), C.byref(n))
             if n.value:
-                groups[k] = (ms.value * 1e-3, fl.value, n.value)
+                groups[k] = (ms.value * 1e-3, fl.value, n.value, int(_lib.load().w2vs_prof_launches(k)))
         _lib.call("w2vs_prof_enable", 0)
         if not groups:
             return None
-        k, (t, fl, n) = max(groups.items(), key=lambda kv: kv[1][0])
+        # dominant = largest ESTIMATED total (mean timed launch x every launch of that kernel), not largest sampled total:
+        # a 1-in-29 sample of a kernel launched 10 times a step is too thin to rank by
+        k, (t, fl, n, _) = max(groups.items(), key=lambda kv: kv[1][0] / kv[1][2] * max(kv[1][3], kv[1][2]))
         ach = fl / t / 1e12
         out = {"bound": "mfma", "kernel": names[k], "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s",
                "frac": round(ach / peak_tflops, 4), "traffic": None, "launches_timed": n,
-               "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": round(fl / n / 1e9, 3)}
-        nt = [g for kk, g in groups.items() if kk < 7]
+               "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": round(fl / n / 1e9, 3),
+               "launches_in_timed_region": groups[k][3]}
+        nt = [g for kk, g in groups.items() if kk not in (10, 11, 12)]
         if nt:
             out["all_gemm_nt_tflops"] = round(sum(g[1] for g in nt) / sum(g[0] for g in nt) / 1e12, 1)
-        tn = [g for kk, g in groups.items() if kk >= 7]
+        tn = [g for kk, g in groups.items() if kk in (10, 11, 12)]
         if tn:
             out["all_gemm_tn_tflops"] = round(sum(g[1] for g in tn) / sum(g[0] for g in tn) / 1e12, 1)
         return out
