@@ -25,6 +25,11 @@ PARITY UNPINNED for the delay terms.  They are anchored instead on invariants th
 sum to the same expectation on every anti-diagonal; with ``consistent_delay_index`` the analytic gradient
 equals a central-difference gradient of cost_rnnt + delay_scale * cost_delay).
 
+The loss head (``transducer_out_step`` / ``label_smoothed_ce``, rain/layers/attention_transducer.py:289-408 and
+fs/criterions/label_smoothed_cross_entropy.py:33-50) is a restatement too and likewise PARITY UNPINNED: that
+reference file imports the CUDA-only ``warprnnt_pytorch`` and the fairseq Transformer stack, so it cannot be run here;
+tests/test_rnnt_oracle_cpu.py checks the restatement against torch autograd through the same composition.
+
 Reference quirk kept on purpose: the gradient kernels read ``delay_values[bt]`` (bt = b * maxT + t,
 :409) from the B x T x U array that the alpha/beta kernels index as ``[b, t, u]`` (:76, :186).  The
 restatement does the same by default (``consistent_delay_index=False``); ``True`` uses ``[b, t, u]``.
