@@ -20,7 +20,7 @@ import ctypes as C
 import os
 import sys
 import wave
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 import torch

@@ -7,9 +7,8 @@ libw2vs kernel launches on the current HIP stream, with every saved activation c
 arena (the buffer the data-parallel all-reduce later works on).  No torch math op is used on
 the path; torch allocates buffers and carries views.
 """
-import math
 import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -4,7 +4,6 @@ dict, loss hooks and ``state_dict`` keys as the reference, so the fairseq task/c
 reference checkpoints drive it unchanged; the modules below hold parameters only - all math
 runs in ``engine.py`` through libw2vs.
 """
-import math
 from typing import List, Optional, Tuple
 
 import numpy as np

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from . import engine, ops
+from . import ops
 from ._lib import W2vsError
 from .config import Wav2VecSConfig
 from .model import Wav2Vec2Model, gen_block_attn_mask
