@@ -6,7 +6,6 @@ runs in ``engine.py`` through libw2vs.
 """
 from typing import List, Optional, Tuple
 
-import numpy as np
 import torch
 import torch.nn as nn
 
