@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--samples", type=int, default=L_SAMPLES)
+    ap.add_argument("--update-freq", type=int, default=1,
+                    help="micro-batches per optimizer update (BASELINE configs[2] quotes 8); a timed 'step' stays ONE micro-batch "
+                         "pass, so K steps = K micro-batches and K / update_freq updates + gradient exchanges")
     ap.add_argument("--workload", default="pretrain", choices=["pretrain", "stream", "data", "rnnt"],
                     help="pretrain (default) = the headline step; stream / data / rnnt = the SURVEY section 8 rows f1 / f3 / f4 "
                          "measurements (tools/bench_*.py) with their CPU baselines attached here")
@@ -161,7 +164,7 @@ def main():
     model = w.Wav2VecSModel(cfg).to(torch.bfloat16).to(dev).train()
     crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0], log_keys=["prob_perplexity", "code_perplexity", "temp"])
     step_fn = trainer.TrainStep(model, crit, world_size=max(world, 2) if force_dist else world,
-                                use_optimizer=not args.no_optimizer,
+                                use_optimizer=not args.no_optimizer, update_freq=args.update_freq,
                                 lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
     B, L = args.batch, args.samples
     g = torch.Generator().manual_seed(1234 + rank)
@@ -219,7 +222,9 @@ def main():
                                "bwd%s%s; %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, LayerDrop 0.05, sampled "
                                "block contexts; random-init weights; unread rows of the last encoder layer pruned (exact)" % (
                                    " + RCCL grad all-reduce" if world > 1 else "",
-                                   "" if args.no_optimizer else " + fused Adam", B, L, audio_s),
+                                   ("" if args.no_optimizer else " + fused Adam") + (
+                                       "" if args.update_freq == 1 else " (update_freq %d: exchange + Adam every %d-th step)" % (
+                                           args.update_freq, args.update_freq)), B, L, audio_s),
                    "global_batch_samples": world * B * L, "per_gpu_audio_s_per_s": round(value / world, 2),
                    "last_loss_per_sample": round(float(loss_t) / max(1, st.B * st.M), 4),
                    "tokens_last_step": {"T": st.T, "N": st.N, "M": st.M, "m": st.m, "r": st.r}},

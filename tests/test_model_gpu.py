@@ -279,3 +279,59 @@ def test_last_layer_selected_rows_equals_full_path():
         den = float(g0[n].norm())
         if den > 1e-6:
             assert float((g0[n] - g1[n]).norm()) / den < 2e-3, n       # wgrad / reduction order differs, nothing else
+
+
+@pytest.mark.parametrize("width", ["small", "base"])
+def test_update_freq_accumulates_every_gradient(width):
+    """TrainStep(update_freq=2) fed the same micro-batch twice must leave exactly twice the gradient of one micro-batch in
+    the arena (and the doubled sample_size): every backward kernel ACCUMULATES - one that overwrote its output, or a stale
+    partial-tile slab, would show up in that parameter.  Covers the grouped weight-gradient launch (base width) and the
+    split-K / atomics forms (small width); then the update itself: one optimizer step after two micro-batches."""
+    import wav2vec_s_amd as w
+    from wav2vec_s_amd import trainer, engine, host_rng, ops
+    if width == "small":
+        kw = dict(BASE, encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,
+                  final_dim=128, latent_vars=40, num_negatives=20,
+                  conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
+        B, L = 2, 16000
+    else:
+        kw = dict(BASE, encoder_layers=2)
+        B, L = 8, 120000
+    kw = dict(kw, dropout=0.0, attention_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0)
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    arenas, steps = [], []
+    for uf, use_opt in ((1, False), (2, False), (2, True)):
+        cfg = w.Wav2VecSConfig(**kw)
+        torch.manual_seed(0); np.random.seed(0); random.seed(0)
+        model = w.Wav2VecSModel(cfg).to(BF).cuda().train()
+        crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0])
+        step = trainer.TrainStep(model, crit, lr=1e-3, update_freq=uf, use_optimizer=use_opt)
+        ocfg = O.OracleCfg(**{k: v for k, v in kw.items() if k in O.OracleCfg.__dataclass_fields__})
+        T = O.conv_out_lengths(L, ocfg.conv_layers)[-1]
+        np.random.seed(7)
+        mask = host_rng.compute_mask_indices((B, T), None, cfg.mask_prob, cfg.mask_length, "static", 0, min_masks=2)
+        torch.manual_seed(7)
+        M = int(mask[0].sum())
+        neg = host_rng.sample_negative_indices(B, M, cfg.num_negatives)
+        noise = -torch.empty(B * M * cfg.latent_groups, cfg.latent_vars).exponential_(
+            generator=torch.Generator().manual_seed(8)).log()
+        for i in range(uf):
+            model.inject_draws(engine.Draws(mask_indices=mask, neg_idx=neg, context=(16, 8),
+                                            layer_keep=[True] * cfg.encoder_layers, gumbel_noise=noise))
+            step({"net_input": {"source": src}})
+            assert step.micro == (i + 1) % uf
+        assert step.ss_acc == uf * B * M
+        arenas.append((step.flat.arena.flat.clone(), dict(step.flat.arena.offsets)))
+        steps.append(step.flat.step)
+        ops.ARENA.deactivate()
+    (g1, offs), (g2, _), _ = arenas
+    assert steps == [0, 0, 1]                                  # the optimizer ran once, after the second micro-batch
+    worst = 0.0
+    for name, (off, numel, shp) in offs.items():
+        a, b = g1[off:off + numel].double() * 2.0, g2[off:off + numel].double()
+        if float(a.norm()) < 1e-9:
+            assert float(b.norm()) < 1e-6, name
+            continue
+        worst = max(worst, float((a - b).norm() / a.norm()))
+        assert float((a - b).norm() / a.norm()) < 2e-3, (name, float((a - b).norm() / a.norm()))
+    assert worst < 2e-3

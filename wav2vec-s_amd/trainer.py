@@ -103,22 +103,28 @@ class GradExchange:
 
 
 class TrainStep:
-    """zero_grad -> forward -> criterion -> backward -> [all-reduce] -> Adam.  One call = one update
-    with update_freq = 1 (the bench's step)."""
+    """zero_grad -> forward -> criterion -> backward -> [all-reduce] -> Adam.  One call = one micro-batch; every
+    ``update_freq``-th call closes an update (fs/trainer.py:632-910 with ``optimization.update_freq``): gradients of
+    the micro-batches are SUMMED in the fp32 arena (never zeroed in between), exchanged ONCE - only the last
+    micro-batch's backward launches the bucketed all-reduces, as legacy DDP's ``accumulate_grads`` does
+    (fs/distributed/legacy_distributed_data_parallel.py:94-99) - and divided by the sample_size summed over micro-batches
+    and ranks inside the fused Adam.  update_freq = 1 (default) is the bench's step."""
 
     def __init__(self, model, criterion, world_size=1, use_optimizer=True, lr=5e-4, betas=(0.9, 0.98), eps=1e-6,
-                 weight_decay=0.01, clip_norm=0.0, arena_gib=12.0):
+                 weight_decay=0.01, clip_norm=0.0, arena_gib=12.0, update_freq=1):
         self.model, self.criterion, self.world = model, criterion, world_size
         self.flat = FlatParams(model)
         self.use_optimizer = use_optimizer
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
+        self.update_freq = max(1, int(update_freq))
+        self.micro = 0            # micro-batches accumulated in the current update
+        self.ss_acc = 0
         self.dist = None
         self.exchange = None
         if world_size > 1:
             import torch.distributed as dist
             self.dist = dist
             self.exchange = GradExchange(self.flat.arena.flat, dist)
-            model._on_grad_ready = self.exchange.on_ready
         self.norm_buf = torch.zeros(1, device=self.flat.p16.device, dtype=torch.float32)
         # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB
         ops.ARENA.activate(int(arena_gib * (1 << 30)), self.flat.p16.device)
@@ -126,18 +132,27 @@ class TrainStep:
     def __call__(self, sample):
         f = self.flat
         ops.ARENA.reset()
-        f.zero_grad()
-        if self.exchange is not None:
-            self.exchange.begin_step()
+        first, last = self.micro == 0, self.micro == self.update_freq - 1
+        if first:
+            f.zero_grad()
+            self.ss_acc = 0
+            if self.exchange is not None:
+                self.exchange.begin_step()
+        # only the closing micro-batch reports gradient milestones: earlier ones would all-reduce partial sums
+        self.model._on_grad_ready = self.exchange.on_ready if (self.exchange is not None and last) else None
         loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
         loss.backward()                           # milestones inside launch the bucketed all-reduces
-        total = sample_size
+        self.ss_acc += sample_size
+        self.micro = 0 if last else self.micro + 1
+        if not last:
+            return loss.detach()
+        total = self.ss_acc
         if self.exchange is not None:
             self.exchange.finish()
             # the global sample_size: mask lengths can differ across ranks (own batches, own masks)
             # torch.full is a fill kernel with the value as a launch argument; torch.tensor([...], device=) would be a
             # synchronous pageable H2D copy on this stream, i.e. the host would wait for the whole backward every step
-            ss = torch.full((1,), float(sample_size), device=f.p16.device, dtype=torch.float32)
+            ss = torch.full((1,), float(self.ss_acc), device=f.p16.device, dtype=torch.float32)
             self.dist.all_reduce(ss)
             self.ss_dev = ss
             total = None
