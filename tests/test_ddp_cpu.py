@@ -90,3 +90,40 @@ def test_arena_is_in_forward_order_so_backward_finalises_a_suffix():
     assert o["encoder.layers.3.self_attn.k_proj.weight"][0] == o["encoder.layers.3.self_attn.q_proj.weight"][0] + e2
     assert o["encoder.layers.3.self_attn.v_proj.weight"][0] == o["encoder.layers.3.self_attn.q_proj.weight"][0] + 2 * e2
     assert A.numel >= 90_325_120
+
+
+def test_grad_exchange_flushes_before_the_tail():
+    """flush_at: when a milestone reaches it, what is pending goes out even below a bucket, so that only the range below
+    flush_at (the conv extractor, final last) is left for after the backward.  No process group needed: a stub records."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import wav2vec_s_amd  # noqa: F401
+    from wav2vec_s_amd.trainer import GradExchange
+
+    class _Work:
+        def wait(self):
+            pass
+
+    class _Dist:
+        class ReduceOp:
+            SUM = 0
+
+        def all_reduce(self, t, op=None, group=None, async_op=False):
+            return _Work()
+
+    flat = torch.zeros(10_000)
+    for flush_at, want in ((-1, [(7000, 10000), (4000, 7000), (1000, 4000), (0, 1000)]),     # the last two only at finish()
+                           (1500, [(7000, 10000), (4000, 7000), (1500, 4000), (0, 1500)])):
+        ex = GradExchange(flat, _Dist(), bucket_elems=3_000, flush_at=flush_at)
+        ex.begin_step()
+        for off in (9_500, 8_000, 6_100, 4_000, 2_500, 1_500):
+            ex.on_ready(off)
+        before_finish = list(ex.launched)
+        ex.finish()
+        assert ex.launched == want, (flush_at, ex.launched)
+        covered = np.zeros(10_000, dtype=np.int32)
+        for lo, hi in ex.launched:
+            covered[lo:hi] += 1
+        assert (covered == 1).all()
+        if flush_at >= 0:
+            assert before_finish[-1] == (1500, 4000)          # launched at the milestone, not at finish()

@@ -66,8 +66,13 @@ class GradExchange:
     so the per-collective latency of a ring over 8 GPUs is amortised.  SUM only - the division by the
     global sample_size happens once, inside the fused Adam kernel."""
 
-    def __init__(self, flat: torch.Tensor, dist_module, bucket_elems: int = 16 << 20, group=None):
+    def __init__(self, flat: torch.Tensor, dist_module, bucket_elems: int = 16 << 20, group=None, flush_at: int = -1):
         self.flat, self.dist, self.bucket, self.group = flat, dist_module, int(bucket_elems), group
+        # flush_at: once a milestone reaches this offset, everything pending goes out even if it is less than a bucket.
+        # TrainStep sets it to the start of the encoder's parameters: what is final when only the conv extractor's
+        # backward (~2 ms) remains then travels DURING that backward, and the collective left for after the backward is
+        # the extractor's 4.2 M elements instead of up to a whole bucket.
+        self.flush_at = int(flush_at)
         self.hi = flat.numel()
         self.works = []
         self.launched = []      # (lo, hi) ranges, for tests / tracing
@@ -86,6 +91,9 @@ class GradExchange:
                 lo = 0
             self._launch(lo, self.hi)
             self.hi = lo
+        if 0 <= offset <= self.flush_at and self.hi > offset:
+            self._launch(offset, self.hi)
+            self.hi = offset
 
     def _launch(self, lo, hi):
         if hi <= lo:
@@ -124,7 +132,10 @@ class TrainStep:
         if world_size > 1:
             import torch.distributed as dist
             self.dist = dist
-            self.exchange = GradExchange(self.flat.arena.flat, dist)
+            tail = engine.milestone_offset(self.flat.arena, "post_extract_proj.")
+            if tail >= self.flat.arena.numel:
+                tail = engine.milestone_offset(self.flat.arena, "encoder.")
+            self.exchange = GradExchange(self.flat.arena.flat, dist, flush_at=tail if tail < self.flat.arena.numel else -1)
         self.norm_buf = torch.zeros(1, device=self.flat.p16.device, dtype=torch.float32)
         # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB
         ops.ARENA.activate(int(arena_gib * (1 << 30)), self.flat.p16.device)
