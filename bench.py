@@ -169,10 +169,13 @@ def main():
     B, L = args.batch, args.samples
     g = torch.Generator().manual_seed(1234 + rank)
     source = torch.randn(B, L, generator=g).to(torch.bfloat16).to(dev)
-    np.random.seed(1234 + rank)
+    # host RNG streams are seeded IDENTICALLY on every rank, as the reference does (fairseq_cli/train.py:67-68:
+    # np.random.seed(seed); utils.set_torch_seed(seed)): same mask lengths, same LayerDrop decisions and same sampled
+    # block contexts everywhere - ranks differ in their audio only, so no rank waits for one that dropped fewer layers
+    np.random.seed(1234)
     random.seed(1234)
-    torch.manual_seed(1234 + rank)
-    torch.cuda.manual_seed(1234 + rank)
+    torch.manual_seed(1234)
+    torch.cuda.manual_seed(1234)
     sample = {"net_input": {"source": source}}
 
     def barrier():
