@@ -303,3 +303,25 @@ def test_transducer_out_head_equals_oracle(tokens_per_step, scaled):
     assert rel(logits.float().cpu().numpy(), x.float().numpy() @ W.float().numpy().T) < 1e-2
     with pytest.raises(Exception, match="bias-free"):
         tr.TransducerOut(torch.nn.Linear(d, V, bias=True))
+
+
+@pytest.mark.skipif(not R.RefCpuRnnt.available(), reason="oracle/_ref/libwarprnnt_cpu.so not built")
+def test_nonzero_blank_label():
+    """options.blank_label != 0 (rnnt.h:56): against the compiled reference CPU (plain) and the oracle (delay)."""
+    ref = R.RefCpuRnnt()
+    rng = np.random.RandomState(21)
+    B, T, U, V = 3, 14, 6, 12
+    acts = (rng.randn(B, T, U, V) * 1.3).astype(np.float32)
+    xl, yl = np.array([14, 9, 12]), np.array([5, 3, 4])
+    for blank in (V - 1, 4):
+        lab = rng.randint(0, V - 1, size=(B, U - 1))
+        lab[lab >= blank] += 1                                   # any label but the blank
+        want_c, want_g = ref.loss_and_act_grads(acts, lab, xl, yl, blank=blank)
+        got_c, got_g = _c_api(acts, lab, xl, yl, blank=blank)
+        np.testing.assert_allclose(got_c, want_c, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got_g, want_g, atol=1e-4)
+        dv = R.delay_cost("diagonal", B, T, U, xl, yl)
+        oc, og = R.delay_loss(acts, lab, xl, yl, dv, delay_scale=0.6, smooth=1.0, blank=blank)
+        gc, gg = _c_api(acts, lab, xl, yl, blank=blank, delay=dv, delay_scale=0.6)
+        np.testing.assert_allclose(gc.reshape(3, B), oc, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(gg, og, atol=2e-4)
