@@ -180,3 +180,28 @@ def test_twin_full_width_padded_batch_matches_oracle():
     n_blocks = part.shape[0] // 16
     assert n_blocks >= 3
     assert rel(part[:n_blocks * 16], full[:n_blocks * 16]) < 1e-2
+
+
+def test_twin_frozen_extractor_and_no_padding_mask():
+    """feature_grad_mult = 0 (unidirect_w2v2_encoder.py:486-493: the extractor runs under no_grad): no extractor gradient,
+    everything after it unchanged; and a call without padding mask returns an all-False mask of the right shape."""
+    from wav2vec_s_amd import streaming
+    kw = dict(extractor_mode="layer_norm", encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+              encoder_attention_heads=2, conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2", dropout=0.0,
+              attention_dropout=0.0, dropout_input=0.0, main_context=8, right_context=4, pos_type="sin",
+              load_pretrained_model_from=None)
+    src = torch.randn(2, 9000, generator=torch.Generator().manual_seed(2)).to(BF).cuda()
+    grads = {}
+    for gm in (1.0, 0.0):
+        torch.manual_seed(9)
+        model = streaming.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(feature_grad_mult=gm, **kw)).to(BF).cuda().train()
+        out = model(src)
+        x, pad = out["encoder_out"][0], out["encoder_padding_mask"][0]
+        assert pad.shape == (2, x.shape[0]) and pad.dtype == torch.bool and not bool(pad.any())
+        x.float().pow(2).sum().backward()
+        grads[gm] = {n: (None if p.grad is None else p.grad.float().clone()) for n, p in model.named_parameters()}
+    for n, g in grads[0.0].items():
+        if n.startswith("feature_extractor."):
+            assert g is None or float(g.abs().max()) == 0.0, n
+        elif n.startswith("encoder.") or n.startswith("post_extract_proj.") or n == "layer_norm.weight":
+            assert g is not None and rel(g, grads[1.0][n]) < 1e-5, n       # same numbers: only the extractor is cut off
