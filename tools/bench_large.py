@@ -16,8 +16,12 @@ sys.path.insert(0, ROOT)
 def main():
     import wav2vec_s_amd as w
     from wav2vec_s_amd import trainer
+    import random
+    import numpy as np
     cfg = w.large_librivox_config()
     torch.manual_seed(1)
+    np.random.seed(1234)
+    random.seed(1234)
     model = w.Wav2VecSModel(cfg).to(torch.bfloat16).cuda().train()
     crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 0.0], log_keys=["prob_perplexity", "code_perplexity", "temp"])
     step = trainer.TrainStep(model, crit, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01, arena_gib=40.0)
