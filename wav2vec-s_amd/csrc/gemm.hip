@@ -1396,7 +1396,9 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
   }
   for (int i = n; i <= 4; ++i) g.first[i] = tiles;
   static const int grp_env = [] { const char* e = getenv("W2VS_TN_GROUP"); return e ? atoi(e) : 1; }();
-  if (!ok || tiles > ncu || tiles * 4 < ncu * 3 || !grp_env) {      // grouped only when it fills >= 3/4 of the chip
+  // grouped only when it fills >= 3/4 of the chip AND leaves some slack: with exactly one workgroup per CU a single CU that is
+  // not free at dispatch costs a whole extra round of full-length K loops (measured on the large model's 128 + 128 tiles)
+  if (!ok || tiles > ncu - ncu / 16 || tiles * 4 < ncu * 3 || !grp_env) {
     for (int i = 0; i < n; ++i)
       if (int e = gemm_tn(ds[i], num_cu_hint, s)) return e;
     return 0;
