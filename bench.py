@@ -40,13 +40,15 @@ PEAK_HBM_GBS = 8000.0
 
 def cpu_baseline(threads):
     """The oracle (a CPU port of the reference algorithm, fp32) timed on the host cores over a bounded
-    sample of the same workload: base model, 2 x 80 000 samples (10 audio-seconds), fwd+loss+bwd."""
+    sample of the same workload: base model, cfgA = 2 x 160 000 samples (20 audio-seconds; BASELINE configs[0], the
+    reference's own CPU-runnable case), fwd+loss+bwd.  The restatement / reference time ratio
+    measured in the build container is recorded in BASELINE.md (tools/cpu_ratio.py)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import w2vs_oracle as O
     torch.set_num_threads(threads)
     cfg = O.OracleCfg()
     P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
-    Bc, Lc = 2, 80000
+    Bc, Lc = 2, 160000
     g = torch.Generator().manual_seed(1234)
     src = torch.randn(Bc, Lc, generator=g)
     T = O.conv_out_lengths(Lc, cfg.conv_layers)[-1]
@@ -67,7 +69,7 @@ def cpu_baseline(threads):
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
     return {"value": round(Bc * Lc / SR / t, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": "oracle fp32, base model, 2 x 80000 samples, fwd+loss+bwd, median of 2 after 1 warm-up, %.2f s/step" % t}
+            "sample": "oracle fp32, base model, cfgA 2 x 160000 samples, fwd+loss+bwd, median of 2 after 1 warm-up, %.2f s/step" % t}
 
 
 def _cpu_baseline_rnnt(acts1, labels1, T, U, gpu_cost):
@@ -127,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the constant-context / LayerDrop-0 variant run")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--samples", type=int, default=L_SAMPLES)
     ap.add_argument("--update-freq", type=int, default=1,
@@ -183,17 +186,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from wav2vec_s_amd import flops as flops_mod
+
+    def timed(n_warm, n_steps, first_update):
+        """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds, algorithmic FLOPs of the K steps
+        as actually drawn - sampled contexts and LayerDrop change them -, last loss)."""
+        for i in range(n_warm):
+            model.set_num_updates(first_update + i)
+            step_fn(sample)
+        barrier()
+        fl = 0.0
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            model.set_num_updates(first_update + n_warm + i)
+            loss = step_fn(sample)
+            fl += flops_mod.step_flops_from_state(model._last_state)     # host arithmetic on the step's own draws
+        barrier()
+        return time.perf_counter() - t0, fl, loss
+
     for i in range(args.warmup):
         model.set_num_updates(i)
         step_fn(sample)
     barrier()
     ops.GEMM_TIMER.enable()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        model.set_num_updates(args.warmup + i)
-        loss_t = step_fn(sample)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, step_flops, loss_t = timed(0, args.steps, args.warmup)
     ops.GEMM_TIMER.disable()
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -203,19 +219,43 @@ def main():
     audio_s = B * L / SR
     value = world * audio_s * args.steps / elapsed
     roof = ops.GEMM_TIMER.report(PEAK_BF16_TFLOPS)
-    # HBM-side bytes per launch of that kernel come from SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    # same command (counters cannot be read in-process); the committed summary is quoted here, null if it is absent
+    # step level: algorithmic FLOPs of the steps actually run / their time / the bf16 MFMA peak
+    ach = step_flops / elapsed / 1e12
+    roof["step"] = {"flops_per_step": round(step_flops / args.steps / 1e12, 4), "unit": "TFLOP", "achieved_tflops": round(ach, 1),
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "note": "this run's own draws (sampled contexts, LayerDrop 0.05)"}
+    st_main = model._last_state
+    # HBM-side bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    # of this same command (counters cannot be read in-process).  The newest committed summary is quoted only if it was
+    # collected from THIS build of the kernels (it records the sha256 of csrc/gemm.hip); otherwise traffic stays null.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")))
+        import glob
+        import hashlib
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_hbm_traffic.json")))
+        pmc = json.load(open(cands[-1]))
+        src_hash = hashlib.sha256(open(os.path.join(ROOT, "wav2vec-s_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
         key = {"gemm_tn_lc_kernel": "w2vs::gemm_tn_lc_kernel<true>", "gemm_tn_kernel": "w2vs::gemm_tn_kernel",
-               "gemm_tn_group_kernel": "w2vs::gemm_tn_group_kernel"}.get(
-            roof["kernel"].split(" ")[0])
-        if key in pmc:
+               "gemm_tn_group_kernel": "w2vs::gemm_tn_group_kernel"}.get(roof["kernel"].split(" ")[0], roof["kernel"].split("<")[0])
+        if pmc.get("_gemm_hip_sha256") != src_hash:
+            roof["traffic_note"] = "%s was collected from another build of gemm.hip: not quoted" % os.path.basename(cands[-1])
+        elif key in pmc:
             roof["traffic"] = int((pmc[key]["read_MB_per_launch_corrected"] + pmc[key]["write_MB_per_launch"]) * 1e6)
-            roof["traffic_note"] = "bytes/launch, rocprofv3 --pmc (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/round1_pmc_hbm_traffic.json"
+            roof["traffic_note"] = ("bytes/launch, rocprofv3 --pmc (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/"
+                                    + os.path.basename(cands[-1]))
     except Exception:
         pass
-    st = model._last_state
+    variants = {}
+    if world == 1 and not args.no_variants:
+        # also the constant (16, 8) context with LayerDrop off - the step-level roofline number
+        model.cfg.context_type, model.cfg.encoder_layerdrop = "constant", 0.0
+        el2, fl2, _ = timed(3, args.steps, args.warmup + args.steps)
+        a2 = fl2 / el2 / 1e12
+        variants["constant_context_layerdrop_0"] = {
+            "ms_per_step": round(el2 / args.steps * 1e3, 3), "value": round(audio_s * args.steps / el2, 2), "unit": "audio-s/s",
+            "flops_per_step": round(fl2 / args.steps / 1e12, 4), "achieved_tflops": round(a2, 1),
+            "frac_of_bf16_peak": round(a2 / PEAK_BF16_TFLOPS, 4)}
+        roof["step_constant_context_layerdrop_0"] = {"flops_per_step": round(fl2 / args.steps / 1e12, 4),
+                                                     "achieved_tflops": round(a2, 1), "frac": round(a2 / PEAK_BF16_TFLOPS, 4)}
+    st = st_main
     out = {
         "metric": "audio-seconds/s/GPU, wav2vec-S base pretrain step, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -233,6 +273,8 @@ def main():
                    "tokens_last_step": {"T": st.T, "N": st.N, "M": st.M, "m": st.m, "r": st.r}},
         "roofline": roof,
     }
+    if variants:
+        out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg runs at N = 1 only
         threads = min(os.cpu_count() or 1, 16)
         out["cpu_baseline"] = cpu_baseline(threads)

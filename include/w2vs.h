@@ -205,7 +205,10 @@ int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);
  * fs/modules/gumbel_vector_quantizer.py:141-202 after the weight_proj GEMM: hard argmax +
  * code/prob perplexities (:152-169), gumbel-softmax hard sample (:173-176), codebook product
  * (:192-195) done as a 2-row gather instead of a (B*M) x 640 x 128 broadcast product.
- * logits [R, G*V] bf16; noise [R*G, V] fp32 Gumbel samples or NULL (device RNG from seed);
+ * logits [R, G*V] bf16 -- or, preferred, logits_f32 [R, G*V] fp32 (the weight_proj product through
+ * W2VS_EPI_F32, no rounding of the sums) plus logit_bias [G*V] bf16 added here: the code SELECTION is an argmax, and a
+ * bf16-rounded logit (ulp 0.25 at |x| ~ 60) flips near-ties that fp32 keeps;
+ * noise [R*G, V] fp32 Gumbel samples or NULL (device RNG from seed);
  * vars [G*V, D]; q [R, G*D]; idx [R, G]; hard_cnt/prob_sum [G*V] fp32 scratch kept for bwd;
  * ppl_out[2] = {prob_perplexity, code_perplexity}; cvec_out [G*V] = d prob_ppl / d avg_prob.
  * bwd: dsoft [R, G*V] = dq . vars^T (one batched w2vs_gemm_nt per group);
@@ -216,6 +219,8 @@ typedef struct w2vs_quant_desc {
   const void* dq; const void* dsoft; const float* cvec; void* dlogits; float* dvars;
   float ppl_grad; float tau; int32_t R, G, V, D, training; uint64_t seed;
   const float* ppl_grad_dev;   /* optional device scalar multiplied into ppl_grad (no host sync) */
+  const float* logits_f32;     /* optional: fp32 logits WITHOUT bias (then `logits` may be NULL) */
+  const void* logit_bias;      /* bf16 [G*V] added to logits_f32 (NULL = none) */
 } w2vs_quant_desc;
 int w2vs_quant_fwd(const w2vs_quant_desc* d, void* stream);
 int w2vs_quant_bwd(const w2vs_quant_desc* d, void* stream);
@@ -263,6 +268,12 @@ int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, in
                    void* stream);
 /* out[0] += sum x^2 : gradient norm (fs/utils.py:341-386) */
 int w2vs_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* clip_grad_norm_ (fs/utils.py:341-386) applied after multiply_grads(1/sample_size) (fs/trainer.py:769-774), with the
+ * norm, the comparison and the factor kept on the device (no host read): inv = scale_host * (scale_dev ? *scale_dev : 1);
+ * gnorm = sqrt(*sumsq) * inv; out3 = {inv * min(1, clip / (gnorm + 1e-6)) [inv when clip <= 0], gnorm, non-finite flag}.
+ * out3[0] is what w2vs_adam_step takes as scale_dev; a non-finite norm gives scale 0 and flag 1
+ * (the reference raises FloatingPointError, fs/trainer.py:791-793; the caller reads the flag when it chooses to). */
+int w2vs_clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, void* stream);
 /* out[n] += sum_m in[m, n] : bias gradients */
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* stream);
 

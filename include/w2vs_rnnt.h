@@ -64,7 +64,15 @@ rnntStatus_t compute_rnnt_loss(const float* const activations, float* gradients,
                                const int* const label_lengths, const int* const input_lengths, int alphabet_size,
                                int minibatch, float* costs, void* workspace, struct rnntOptions options);
 
-/* rnnt.h:144-148 (dtype_size must be 4; gpu must be true) */
+/* rnnt.h:115-124 (called for double tensors by pytorch_binding/src/binding.cpp:69, :141).  Same contract as
+ * compute_rnnt_loss with fp64 activations / gradients (device) and fp64 costs (host).  A CONVERTING WRAPPER: the
+ * lattice runs in fp32 (activations narrowed into a temporary device buffer, results widened), so results carry fp32
+ * accuracy - the reference instantiates GpuRNNT<double> here, which exists for its gradient checks. */
+rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gradients, const int* const flat_labels,
+                                    const int* const label_lengths, const int* const input_lengths, int alphabet_size,
+                                    int minibatch, double* costs, void* workspace, struct rnntOptions options);
+
+/* rnnt.h:144-148 (dtype_size 4, or 8 for the fp64 entry; gpu must be true) */
 rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, size_t* size_bytes
 #ifdef __cplusplus
                                 , size_t dtype_size = sizeof(float)

@@ -420,6 +420,23 @@ def forward_loss(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCf
     return out
 
 
+def polynomial_decay_lr(num_updates: int, lr: float, warmup_updates: int, total_num_update: float,
+                        end_learning_rate: float = 0.0, power: float = 1.0) -> float:
+    """PolynomialDecayLRSchedule.step_update, fs/optim/lr_scheduler/polynomial_decay_schedule.py:74-89: the rate applied
+    to the update that follows ``num_updates`` completed ones (linear warm-up from 0, then polynomial decay)."""
+    if warmup_updates > 0 and num_updates <= warmup_updates:
+        return num_updates / float(warmup_updates) * lr
+    if num_updates >= total_num_update:
+        return end_learning_rate
+    pct = 1 - (num_updates - warmup_updates) / (total_num_update - warmup_updates)
+    return (lr - end_learning_rate) * pct ** power + end_learning_rate
+
+
+def clip_coef(total_norm: float, max_norm: float) -> float:
+    """fs/utils.py:379-383: (max_norm / (total_norm + 1e-6)).clamp_(max=1)."""
+    return min(1.0, max_norm / (total_norm + 1e-6)) if max_norm > 0 else 1.0
+
+
 def frame_padding_mask(padding_mask: torch.Tensor, T: int) -> torch.Tensor:
     """Sample-level -> frame-level padding mask, fs/models/wav2vec/wav2vec2.py:560-565 and
     rain/layers/unidirect_w2v2_encoder.py:500-505."""

@@ -1,0 +1,232 @@
+"""The training step around the model on a real MI355X: RCCL exchange against real backward milestones, device-side
+clip_grad_norm_, LR schedule, fp32-master resync and optimizer-state round trip (e, f2).
+
+The file name sorts first on purpose: the 1-rank ``nccl`` process group is created inside THIS pytest process before the
+other GPU test modules have run."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import w2vs_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+SMALL = dict(quantize_targets=True, extractor_mode="layer_norm", final_dim=128, encoder_layerdrop=0.0, dropout_input=0.0,
+             dropout_features=0.0, dropout=0.0, attention_dropout=0.0, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+             encoder_attention_heads=2, encoder_layers=4, feature_grad_mult=0.1, context_type="constant", latent_vars=40,
+             num_negatives=20, conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    yield dist
+    # left initialised for the rest of the session: destroying RCCL mid-process buys nothing
+
+
+def _build(kw, seed=0):
+    import wav2vec_s_amd as w
+    cfg = w.Wav2VecSConfig(**kw)
+    torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
+    model = w.Wav2VecSModel(cfg).to(BF).cuda().train()
+    crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0])
+    return w, cfg, model, crit
+
+
+def _draws(cfg, B, L, keep=None, seed=7):
+    from wav2vec_s_amd import engine, host_rng
+    ocfg = O.OracleCfg(**{k: v for k, v in SMALL.items() if k in O.OracleCfg.__dataclass_fields__})
+    T = O.conv_out_lengths(L, ocfg.conv_layers)[-1]
+    np.random.seed(seed)
+    mask = host_rng.compute_mask_indices((B, T), None, cfg.mask_prob, cfg.mask_length, "static", 0, min_masks=2)
+    torch.manual_seed(seed)
+    M = int(mask[0].sum())
+    neg = host_rng.sample_negative_indices(B, M, cfg.num_negatives)
+    noise = -torch.empty(B * M * cfg.latent_groups, cfg.latent_vars).exponential_(
+        generator=torch.Generator().manual_seed(seed + 1)).log()
+    keep = keep if keep is not None else [True] * cfg.encoder_layers
+    return lambda: engine.Draws(mask_indices=mask, neg_idx=neg, context=(8, 4), layer_keep=list(keep), gumbel_noise=noise)
+
+
+@pytest.mark.parametrize("clip,update_freq,keep", [
+    (0.0, 1, None), (0.05, 1, None), (0.05, 2, [True, False, True, True]), (0.0, 2, [True, True, False, True])])
+def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
+    """TrainStep with the gradient exchange ACTIVE (world_size-2 code path on a 1-rank RCCL group: every all-reduce is an
+    identity) must leave the same arena, the same Adam state and the same parameters as the plain single-GPU step on the
+    same draws - with clipping, gradient accumulation and a LayerDrop-ped layer - and every arena element must be
+    all-reduced exactly once, from the milestones the real backward reports
+    (fs/distributed/legacy_distributed_data_parallel.py:81-170, fs/trainer.py:769-774)."""
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    res = []
+    for world in (1, 2):
+        w, cfg, model, crit = _build(SMALL)
+        step = trainer.TrainStep(model, crit, world_size=world, lr=1e-3, clip_norm=clip, update_freq=update_freq,
+                                 arena_gib=1.0)
+        if world == 2:
+            step.exchange.bucket = 50_000              # several buckets on this small model
+        mk = _draws(cfg, B, L, keep)
+        for _ in range(update_freq):
+            model.inject_draws(mk())
+            step({"net_input": {"source": src}})
+        torch.cuda.synchronize()
+        if world == 2:
+            n = step.flat.arena.numel
+            cov = np.zeros(n, dtype=np.int32)
+            for lo, hi in step.exchange.launched:
+                cov[lo:hi] += 1
+            assert (cov == 1).all(), "every arena element is reduced exactly once"
+            assert len(step.exchange.launched) >= 3
+        gn = step.grad_norm() if clip > 0 else None
+        res.append((step.flat.arena.flat.clone(), step.flat.p32.clone(), step.flat.m.clone(), step.flat.p16.clone(), gn))
+        ops.ARENA.deactivate()
+    (g1, p1, m1, q1, n1), (g2, p2, m2, q2, n2) = res
+    den = float(g1.double().norm())
+    assert float((g1.double() - g2.double()).norm()) / den < 2e-4          # fp32-atomic ordering only
+    assert float((m1.double() - m2.double()).norm()) / float(m1.double().norm()) < 2e-4
+    assert float((p1.double() - p2.double()).abs().max()) < 2e-5
+    assert float((q1.float() != q2.float()).float().mean()) < 1e-3        # bf16 images: a last-bit flip at most
+    if clip > 0:
+        assert abs(n1 - n2) / n1 < 1e-4
+        assert n1 > clip                                                   # the case does clip
+
+
+def test_clip_norm_on_device_matches_reference_formula():
+    """clip_grad_norm_ after the division by sample_size (fs/utils.py:341-386 after fs/trainer.py:769-774), then fairseq
+    Adam (fs/optim/adam.py:205-229), recomputed with torch from the raw arena of an optimizer-less twin step."""
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(5)).to(BF).cuda()
+    lr, b1, b2, eps, wd, clip = 2e-3, 0.9, 0.98, 1e-6, 0.01, 0.02
+    out = {}
+    for use_opt in (False, True):
+        w, cfg, model, crit = _build(SMALL, seed=3)
+        step = trainer.TrainStep(model, crit, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, clip_norm=clip,
+                                 use_optimizer=use_opt, arena_gib=1.0)
+        p_before = step.flat.p32.clone()
+        model.inject_draws(_draws(cfg, B, L)())
+        step({"net_input": {"source": src}})
+        out[use_opt] = (step.flat.arena.flat.clone().double(), p_before.double(), step.flat.p32.clone().double(), step.ss_acc,
+                        step.grad_norm() if use_opt else None)
+        ops.ARENA.deactivate()
+    g, p0, _, ss, _ = out[False]
+    _, _, p_new, ss2, gn_dev = out[True]
+    assert ss == ss2
+    gnorm = float(g.norm()) / ss
+    coef = min(1.0, clip / (gnorm + 1e-6))
+    assert coef < 0.9, (gnorm, clip)                                       # the case really clips
+    assert abs(gn_dev - gnorm) / gnorm < 1e-3
+    ge = g / ss * coef
+    m = (1 - b1) * ge
+    v = (1 - b2) * ge * ge
+    step_size = lr * (1 - b2) ** 0.5 / (1 - b1)
+    want = p0 - lr * wd * p0 - step_size * m / (v.sqrt() + eps)
+    # Adam's first step is ~ lr * sign(g): compare the UPDATE, elementwise, where the gradient is not rounding noise
+    upd_w, upd_g = want - p0, p_new - p0
+    big = ge.abs() > 1e-3 * ge.abs().max()
+    assert float((upd_w[big] - upd_g[big]).abs().max()) < 0.02 * lr
+    assert float((upd_w - upd_g).norm() / upd_w.norm()) < 2e-2
+
+
+def test_polynomial_decay_schedule_drives_adam():
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(6)).to(BF).cuda()
+    w, cfg, model, crit = _build(SMALL, seed=4)
+    sched = trainer.PolynomialDecayLRSchedule(5e-4, warmup_updates=4, total_num_update=10)
+    step = trainer.TrainStep(model, crit, lr=123.0, lr_scheduler=sched, arena_gib=1.0)
+    mk = _draws(cfg, B, L)
+    seen = []
+    p_prev = step.flat.p32.clone()
+    for i in range(6):
+        model.inject_draws(mk())
+        step({"net_input": {"source": src}})
+        seen.append(step.last_lr)
+        moved = float((step.flat.p32 - p_prev).abs().max())
+        if i == 0:
+            assert moved == 0.0        # the first update of a run uses lr 0 (warm-up factor 0 / warmup), as the reference
+        else:
+            assert 0 < moved < 4 * seen[-1]
+        p_prev = step.flat.p32.clone()
+    assert seen == [O.polynomial_decay_lr(n, 5e-4, 4, 10) for n in range(6)]
+    ops.ARENA.deactivate()
+
+
+def test_load_state_dict_resyncs_master_and_optimizer_state_round_trips():
+    """weights loaded AFTER TrainStep was built must survive the next update (the fp32 master is re-derived by
+    a load_state_dict hook), and step / exp_avg / exp_avg_sq / master round-trip through state_dict."""
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(8)).to(BF).cuda()
+    w, cfg, donor, _ = _build(SMALL, seed=21)
+    sd = {k: v.clone() for k, v in donor.state_dict().items()}
+    # (a) load after construction
+    w, cfg, model_a, crit_a = _build(SMALL, seed=1)
+    step_a = trainer.TrainStep(model_a, crit_a, lr=1e-3, arena_gib=1.0)
+    model_a.load_state_dict(sd)
+    assert torch.equal(step_a.flat.p32, step_a.flat.p16.float())
+    # (b) load before construction
+    w, cfg, model_b, crit_b = _build(SMALL, seed=2)
+    model_b.load_state_dict(sd)
+    step_b = trainer.TrainStep(model_b, crit_b, lr=1e-3, arena_gib=1.0)
+    mk = _draws(cfg, B, L)
+    for step, model in ((step_a, model_a), (step_b, model_b)):
+        model.inject_draws(mk())
+        step({"net_input": {"source": src}})
+    torch.cuda.synchronize()
+    assert float((step_a.flat.p32 - step_b.flat.p32).abs().max()) < 2e-5
+    for k, v in model_a.state_dict().items():
+        if "pos_conv" in k:
+            continue
+        assert float((v.float() - model_b.state_dict()[k].float()).abs().max()) <= 2e-2 * float(v.float().abs().max()) + 1e-6, k
+    # optimizer state round trip: a third trainer resumes from (a) and takes the same second step
+    osd = step_a.flat.state_dict()
+    w, cfg, model_c, crit_c = _build(SMALL, seed=9)
+    step_c = trainer.TrainStep(model_c, crit_c, lr=1e-3, arena_gib=1.0)
+    step_c.flat.load_state_dict(osd)
+    assert step_c.flat.step == 1 and torch.equal(step_c.flat.p32, step_a.flat.p32) and torch.equal(step_c.flat.m, step_a.flat.m)
+    for step, model in ((step_a, model_a), (step_c, model_c)):
+        model.inject_draws(mk())
+        step({"net_input": {"source": src}})
+    torch.cuda.synchronize()
+    assert float((step_a.flat.p32 - step_c.flat.p32).abs().max()) < 2e-5
+    with pytest.raises(ValueError):
+        bad = dict(osd, layout={})
+        step_c.flat.load_state_dict(bad)
+    ops.ARENA.deactivate()
+
+
+def test_step_arena_is_scoped_to_the_step():
+    """tensors handed out OUTSIDE TrainStep.__call__ must not live in the recycled step slab."""
+    from wav2vec_s_amd import trainer, ops, engine
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(9)).to(BF).cuda()
+    w, cfg, model, crit = _build(SMALL, seed=5)
+    step = trainer.TrainStep(model, crit, lr=1e-3, arena_gib=1.0)
+    assert not ops.ARENA.active
+    model.eval()
+    model.inject_draws(engine.Draws(context=(8, 4)))
+    x, _ = model.extract_features(src, None, mask=False)
+    keep = x.clone()
+    lo, hi = ops.ARENA.buf.data_ptr(), ops.ARENA.buf.data_ptr() + ops.ARENA.cap
+    assert not (lo <= x.data_ptr() < hi)
+    model.train()
+    model.inject_draws(_draws(cfg, B, L)())
+    step({"net_input": {"source": src}})
+    torch.cuda.synchronize()
+    assert torch.equal(x, keep)
+    assert not ops.ARENA.active
+    ops.ARENA.deactivate()

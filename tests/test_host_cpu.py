@@ -190,3 +190,19 @@ def test_public_headers_compile_as_c_and_cpp(tmp_path):
         p = os.path.join(tmp_path, name)
         open(p, "w").write(src)
         subprocess.check_call([cc, std, "-Wall", "-Werror", "-I", inc, "-c", p, "-o", p + ".o"])
+
+
+def test_integration_doc_attn_desc_mirror_matches_library():
+    """The ctypes stub printed in INTEGRATION.md must be a correct mirror of w2vs_attn_desc (round 1 shipped it one
+    field short): run the struct definition from the document against w2vs_sizeof(4) of the built library."""
+    import ctypes as C
+    import re
+    from wav2vec_s_amd import _lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"(class AttnDesc\(C\.Structure\):.*?)\nlib\.w2vs_sizeof", doc, re.S)
+    assert m, "AttnDesc snippet not found"
+    ns = {"C": C}
+    exec(m.group(1), ns)
+    lib = _lib.load()
+    assert lib.w2vs_sizeof(4) == C.sizeof(ns["AttnDesc"]) == C.sizeof(_lib.AttnDesc)
+    assert [f[0] for f in ns["AttnDesc"]._fields_] == [f[0] for f in _lib.AttnDesc._fields_]

@@ -30,4 +30,9 @@ for k in sorted(fetch, key=lambda k: -fetch[k]):
     out[k] = {"launches": fc[k],
               "read_MB_per_launch_corrected": round(2.0 * fetch[k] * 1024 / fc[k] / 1e6, 2),
               "write_MB_per_launch": round(write.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1) / 1e6, 2)}
+# bench.py quotes this file only while csrc/gemm.hip is the build it was collected from
+import hashlib
+import os
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wav2vec-s_amd", "csrc", "gemm.hip")
+out["_gemm_hip_sha256"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]
 json.dump(out, sys.stdout, indent=1)

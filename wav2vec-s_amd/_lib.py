@@ -53,7 +53,8 @@ class QuantDesc(C.Structure):
     _fields_ = [("logits", vp), ("noise", vp), ("vars", vp), ("q", vp), ("idx", vp), ("hard_cnt", vp),
                 ("prob_sum", vp), ("ppl_out", vp), ("cvec_out", vp), ("dq", vp), ("dsoft", vp), ("cvec", vp),
                 ("dlogits", vp), ("dvars", vp), ("ppl_grad", f32), ("tau", f32),
-                ("R", i32), ("G", i32), ("V", i32), ("D", i32), ("training", i32), ("seed", u64), ("ppl_grad_dev", vp)]
+                ("R", i32), ("G", i32), ("V", i32), ("D", i32), ("training", i32), ("seed", u64), ("ppl_grad_dev", vp),
+                ("logits_f32", vp), ("logit_bias", vp)]
 
 
 class NceDesc(C.Structure):
@@ -122,6 +123,7 @@ _SIGS = {
     "w2vs_dropout": [vp, vp, i64, f32, u64, vp],
     "w2vs_adam_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp],
     "w2vs_sumsq": [vp, i64, vp, vp],
+    "w2vs_clip_scale": [vp, vp, f32, f32, vp, vp],
     "w2vs_batch_by_size": [vp, i64, i64, i64, i32, vp, vp],
     "w2vs_collate_chunks": [i32],
     "w2vs_collate": [C.POINTER(CollateDesc), vp],

@@ -90,5 +90,8 @@ int w2vs_batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens,
 int32_t w2vs_collate_chunks(int32_t max_size) { return collate_chunks(max_size); }
 int w2vs_collate(const w2vs_collate_desc* d, void* s) { NONNULL(d); return collate(*d, ST(s)); }
 int w2vs_sumsq(const float* x, int64_t n, float* out, void* s) { return sumsq(x, n, out, ST(s)); }
+int w2vs_clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, void* s) {
+  return clip_scale(sumsq, scale_dev, scale_host, clip, out3, ST(s));
+}
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* s) { return colsum(in, out, M, N, ld, ST(s)); }
 }

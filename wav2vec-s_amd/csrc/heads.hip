@@ -23,6 +23,8 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 
 struct QuantP {
   const bf16* logits;   // [R, G*V]
+  const float* logits32;  // [R, G*V] fp32 without bias (preferred: no rounding before the argmax), or null
+  const bf16* lbias;      // [G*V] bias added to logits32, or null
   const float* noise;   // [R*G, V] gumbel samples or null (then seed is used when training)
   const bf16* vars;     // [G*V, D]
   bf16* q;              // [R, G*D]
@@ -59,14 +61,17 @@ __global__ __launch_bounds__(256) void quant_kernel(QuantP p) {
   for (long rg = wave_id; rg < rows; rg += nwaves) {
     const long row = rg / G;
     const int g = (int)(rg % G);
-    const bf16* lp = p.logits + row * (long)(G * V) + (long)g * V;
+    const long lofs = row * (long)(G * V) + (long)g * V;
     float x[QV_MAX], y[QV_MAX];
     float xmax = -INFINITY;
     int xarg = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < QV_MAX; ++j) {
       int v = lane + 64 * j;
-      x[j] = (v < V) ? bf2f(lp[v]) : -INFINITY;
+      if (v < V) {
+        if (p.logits32) x[j] = p.logits32[lofs + v] + (p.lbias ? bf2f(p.lbias[g * V + v]) : 0.f);
+        else x[j] = bf2f(p.logits[lofs + v]);
+      } else x[j] = -INFINITY;
       if (x[j] > xmax) { xmax = x[j]; xarg = v; }
     }
     wave_argmax(xmax, xarg);
@@ -211,7 +216,8 @@ static int quant_fill(const QuantDesc& d, QuantP& p) {
   p.hard_cnt = d.hard_cnt; p.prob_sum = d.prob_sum; p.dq = (const bf16*)d.dq; p.dsoft = (const bf16*)d.dsoft; p.cvec = d.cvec;
   p.dlogits = (bf16*)d.dlogits; p.dvars = d.dvars; p.ppl_grad = d.ppl_grad; p.ppl_dev = d.ppl_grad_dev; p.R = d.R; p.G = d.G; p.V = d.V; p.D = d.D;
   p.tau = d.tau; p.training = d.training; p.seed = d.seed;
-  if (!p.logits || !p.vars) return set_error("quantizer: null pointer");
+  p.logits32 = d.logits_f32; p.lbias = (const bf16*)d.logit_bias;
+  if ((!p.logits && !p.logits32) || !p.vars) return set_error("quantizer: null pointer");
   if (p.V > 64 * QV_MAX || p.V < 1) return set_error("quantizer: num_vars per group must be in [1, 320]");
   if (p.D % 8) return set_error("quantizer: var_dim must be a multiple of 8");
   if (p.R <= 0 || p.G <= 0) return set_error("quantizer: bad R/G");
@@ -822,9 +828,14 @@ int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n,
 }
 
 // out[0] += sum x^2 (fp32): gradient norm for clip_grad_norm_ (fs/utils.py:341-386)
-__global__ void sumsq_kernel(const float* x, long n, float* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
   float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+  const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = *(const f32x4*)(x + 4 * i);
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[(n4 << 2) + threadIdx.x]; s += t * t; }
   s = wave_sum(s);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -832,9 +843,29 @@ __global__ void sumsq_kernel(const float* x, long n, float* out) {
   if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));   // one same-address atomic per block
 }
 int sumsq(const float* x, long n, float* out, hipStream_t st) {
-  if (!x || !out || n <= 0) return set_error("sumsq: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, st, x, n, out);
+  if (!x || !out || n <= 0 || ((uintptr_t)x & 15)) return set_error("sumsq: bad arguments (x must be 16-byte aligned)");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, st, x, n, out);
   return hip_check(hipGetLastError(), "sumsq");
+}
+
+// clip_grad_norm_ without a host read (fs/utils.py:341-386 after fs/trainer.py:769-774's multiply_grads(1/sample_size)):
+//   inv = scale_host * (scale_dev ? *scale_dev : 1)          the 1 / sample_size factor
+//   gnorm = sqrt(sumsq) * inv ;  coef = clip > 0 ? min(1, clip / (gnorm + 1e-6)) : 1
+//   out = {inv * coef (what Adam multiplies the arena with), gnorm, non-finite flag}; non-finite norm -> scale 0
+__global__ void clip_scale_kernel(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3) {
+  const float inv = scale_dev ? scale_host * scale_dev[0] : scale_host;
+  const float gnorm = sqrtf(sumsq[0]) * inv;
+  const bool ok = isfinite(gnorm);
+  float coef = 1.f;
+  if (clip > 0.f) coef = fminf(1.f, clip / (gnorm + 1e-6f));
+  out3[0] = ok ? inv * coef : 0.f;
+  out3[1] = gnorm;
+  out3[2] = ok ? 0.f : 1.f;
+}
+int clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, hipStream_t st) {
+  if (!sumsq || !out3) return set_error("clip_scale: null pointer");
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq, scale_dev, scale_host, clip, out3);
+  return hip_check(hipGetLastError(), "clip_scale");
 }
 
 // out[n] += sum_m in[m][n]  (bf16 in, fp32 atomics out): bias gradients

@@ -558,6 +558,15 @@ rnntStatus_t run(const float* acts, float* grads, const int* labels, const int* 
   return RNNT_STATUS_SUCCESS;
 }
 
+__global__ void f64_to_f32_kernel(const double* in, float* out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+__global__ void f32_to_f64_kernel(const float* in, double* out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -582,10 +591,45 @@ rnntStatus_t compute_rnnt_loss(const float* const activations, float* gradients,
 }
 
 rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, size_t* size_bytes, size_t dtype_size) {
-  if (minibatch <= 0 || maxT <= 0 || maxU <= 0 || !size_bytes || dtype_size != sizeof(float) || !gpu)
+  if (minibatch <= 0 || maxT <= 0 || maxU <= 0 || !size_bytes || (dtype_size != sizeof(float) && dtype_size != sizeof(double)) ||
+      !gpu)
     return RNNT_STATUS_INVALID_VALUE;
-  *size_bytes = work_floats(minibatch, maxT, maxU, false) * sizeof(float);
+  // the fp64 entry computes in fp32 (see compute_rnnt_loss_fp64): its workspace is the fp32 one; reporting dtype_size
+  // times the float count keeps a caller that sizes by element width on the safe side
+  *size_bytes = work_floats(minibatch, maxT, maxU, false) * dtype_size;
   return RNNT_STATUS_SUCCESS;
+}
+
+// rnnt.h:115-124, called by pytorch_binding/src/binding.cpp:69 / :141 for double tensors.  A CONVERTING WRAPPER: the
+// lattice runs in fp32 exactly as compute_rnnt_loss (MI355X has no use for an fp64 transducer: the reference's fp64
+// instantiation exists for its gradient checks); activations are narrowed into a temporary device buffer, gradients
+// and costs widened on the way out.  Synchronous, like the reference's entry (costs land on the host).
+rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gradients, const int* const flat_labels,
+                                    const int* const label_lengths, const int* const input_lengths, int alphabet_size,
+                                    int minibatch, double* costs, void* workspace, rnntOptions options) {
+  if (!activations || !costs || minibatch <= 0 || alphabet_size <= 0 || options.maxT <= 0 || options.maxU <= 0)
+    return RNNT_STATUS_INVALID_VALUE;
+  if (options.loc != RNNT_GPU) return RNNT_STATUS_EXECUTION_FAILED;
+  hipStream_t st = (hipStream_t)options.stream;
+  const long n = (long)minibatch * options.maxT * options.maxU * alphabet_size;
+  float* a32 = nullptr;
+  float* g32 = nullptr;
+  if (hipMalloc((void**)&a32, sizeof(float) * n) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+  if (gradients && hipMalloc((void**)&g32, sizeof(float) * n) != hipSuccess) { (void)hipFree(a32); return RNNT_STATUS_MEMOPS_FAILED; }
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks), dim3(256), 0, st, activations, a32, n);
+  std::vector<float> c32((size_t)minibatch);
+  rnntStatus_t rc = run(a32, g32, flat_labels, label_lengths, input_lengths, nullptr, alphabet_size, minibatch, c32.data(),
+                        workspace, 0.f, 1.f, options, false);
+  if (rc == RNNT_STATUS_SUCCESS && gradients) {
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(blocks), dim3(256), 0, st, g32, gradients, n);
+    if (hipStreamSynchronize(st) != hipSuccess) rc = RNNT_STATUS_EXECUTION_FAILED;
+  }
+  if (rc == RNNT_STATUS_SUCCESS)
+    for (int b = 0; b < minibatch; ++b) costs[b] = (double)c32[b];
+  (void)hipFree(a32);
+  if (g32) (void)hipFree(g32);
+  return rc;
 }
 
 rnntStatus_t compute_rnnt_delay_loss(const float* const activations, float* gradients, const int* const flat_labels,

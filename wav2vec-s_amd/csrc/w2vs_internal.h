@@ -68,6 +68,7 @@ int collate(const w2vs_collate_desc& d, hipStream_t st);
 int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n, float lr, float b1, float b2, float eps,
               float wd, int step, const float* scale_dev, float scale_host, hipStream_t st);
 int sumsq(const float* x, long n, float* out, hipStream_t st);
+int clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, hipStream_t st);
 int colsum(const void* in, float* out, long M, int N, long ld, hipStream_t st);
 
 }  // namespace w2vs

@@ -370,14 +370,16 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         y_in = ops.dropout(y_in, p_feat, seed(3))
     st.y_in = y_in
     G, V = cfg.latent_groups, cfg.latent_vars
-    st.q_logits = ops.linear_fwd(y_in, W["quantizer.weight_proj.weight"], W["quantizer.weight_proj.bias"])
+    # fp32 logits (bias added inside the quantizer kernel): the code selection is an argmax and must not see bf16 sums
+    st.q_logits = ops.linear_fwd_f32(y_in, W["quantizer.weight_proj.weight"])
     vars2d = W["quantizer.vars"].view(G * V, -1)
     noise = draws.gumbel_noise
     if noise is not None:
         noise = noise.to(dev).float().contiguous()
     st.noise = noise
     st.tau = tau
-    q, st.qst = ops.quant_fwd(st.q_logits, vars2d, G, V, tau, training, noise=noise, seed=seed(4))
+    q, st.qst = ops.quant_fwd(st.q_logits, vars2d, G, V, tau, training, noise=noise, seed=seed(4),
+                              bias=W["quantizer.weight_proj.bias"])
     st.q = q
     yq = ops.linear_fwd(q, W["project_q.weight"], W["project_q.bias"])
     xm = enc if getattr(st, "enc_is_sel", False) else ops.gather_rows(enc, token_idx, RM)
@@ -519,7 +521,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         dql = ops.quant_bwd(dq, st.q_logits, vars2d, st.qst, G, V, st.tau, st.training,
                             1.0 if d_prob_ppl is not None else 0.0,
                             A.view("quantizer.vars").view(G * V, -1), noise=st.noise, seed=seed(4),
-                            ppl_grad_dev=d_prob_ppl)
+                            ppl_grad_dev=d_prob_ppl, bias=W["quantizer.weight_proj.bias"])
         d_yin = _linear_bwd(dql, st.y_in, "quantizer.weight_proj.weight", "quantizer.weight_proj.bias", W, A)
         if p_feat > 0:
             d_yin = ops.dropout(d_yin, p_feat, seed(3))

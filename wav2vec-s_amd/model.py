@@ -214,7 +214,7 @@ class _HotPath(torch.autograd.Function):
         pen = st.pen_acc.view(()) / float(B * T * C0)
         prob_ppl, code_ppl = st.qst.ppl[0].clone(), st.qst.ppl[1].clone()
         ctx.mark_non_differentiable(code_ppl)
-        if ops.ARENA.buf is not None:
+        if ops.ARENA.active:
             # step arena active: logits and pen are views of the ONE recycled slab; autograd outputs must not be (the
             # slab is written in place all the time), so hand out copies (0.8 MB) and keep the originals for backward
             return st.logits.clone(), pen.clone(), prob_ppl, code_ppl
@@ -241,7 +241,7 @@ class _HotPath(torch.autograd.Function):
             ctx.st = None
             return (None,) * (6 + len(names))   # gradients stay in the arena (see trainer.FlatParams)
         flat16 = ops.f32_to_bf16(A.flat)
-        if ops.ARENA.buf is not None:
+        if ops.ARENA.active:
             # a TrainStep elsewhere in the process left the step arena active: gradients handed to autograd must own
             # their memory (views of the recycled slab trip autograd's view/in-place check and would be overwritten)
             flat16 = flat16.clone()

@@ -21,19 +21,27 @@ class _StepArena:
     Sampled block contexts change the token count N every step; through torch's caching allocator
     that means fresh multi-GB hipMalloc/hipFree pairs (device-synchronising) per step.  When active,
     every buffer the kernels write comes from ONE preallocated slab that is rewound at step start -
-    288 GB of HBM3E makes reserving the worst case trivial.  Inactive (default): plain torch.empty."""
+    288 GB of HBM3E makes reserving the worst case trivial.  Inactive (default, and always outside
+    ``trainer.TrainStep.__call__``): plain torch.empty."""
 
     def __init__(self):
-        self.buf, self.off, self.cap = None, 0, 0
+        self.buf, self.off, self.cap, self.active = None, 0, 0, False
 
     def activate(self, nbytes, device):
+        """Reserve the slab (kept across steps) and start handing out from it."""
         if self.buf is None or self.cap < nbytes or self.buf.device != torch.device(device):
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self.cap = nbytes
         self.off = 0
+        self.active = True
+
+    def suspend(self):
+        """Keep the slab, stop handing out from it: outside a training step (validation forwards, the streaming twin,
+        a second model in the process) buffers come from torch's allocator and cannot be overwritten by the next step."""
+        self.active = False
 
     def deactivate(self):
-        self.buf, self.off, self.cap = None, 0, 0
+        self.buf, self.off, self.cap, self.active = None, 0, 0, False
 
     def reset(self):
         self.off = 0
@@ -41,7 +49,7 @@ class _StepArena:
     def empty(self, shape, dtype, device):
         if isinstance(shape, int):
             shape = (shape,)
-        if self.buf is None:
+        if not self.active or self.buf is None:
             return torch.empty(shape, device=device, dtype=dtype)
         n = 1
         for d in shape:
@@ -557,9 +565,31 @@ class QuantState:
     __slots__ = ("idx", "hard_cnt", "prob_sum", "ppl", "cvec")
 
 
-def quant_fwd(logits, vars2d, G, V, tau, training, noise=None, seed=0):
-    """logits [R, G*V] bf16, vars2d [G*V, D] bf16 -> q [R, G*D], state (ppl = [prob_ppl, code_ppl])."""
-    _chk(logits, BF16, "logits"); _chk(vars2d, BF16, "vars"); _chk(noise, torch.float32, "noise")
+def _quant_logits(d, logits, bias):
+    if logits.dtype == torch.float32:
+        _chk(logits, torch.float32, "logits"); _chk(bias, BF16, "logit bias")
+        d.logits_f32, d.logit_bias = _p(logits), _p(bias)
+    else:
+        _chk(logits, BF16, "logits")
+        if bias is not None:
+            raise W2vsError("bf16 quantizer logits already carry their bias")
+        d.logits = _p(logits)
+
+
+def linear_fwd_f32(x, w):
+    """x @ w.T as fp32, no bias (W2VS_EPI_F32): the quantizer logits, whose argmax must not see bf16 rounding."""
+    _chk(x, BF16, "x"); _chk(w, BF16, "w")
+    R, K = x.shape
+    N = w.shape[0]
+    y = empty((R, N), torch.float32, x.device)
+    gemm_nt(x, w, M=R, N=N, K=K, lda=K, ldb=K, ldc=N, out_f32=y, epi=EPI_F32)
+    return y
+
+
+def quant_fwd(logits, vars2d, G, V, tau, training, noise=None, seed=0, bias=None):
+    """logits [R, G*V] (fp32 without bias + ``bias`` [G*V] bf16, or bf16 with the bias folded in), vars2d [G*V, D] bf16
+    -> q [R, G*D], state (ppl = [prob_ppl, code_ppl])."""
+    _chk(vars2d, BF16, "vars"); _chk(noise, torch.float32, "noise")
     R = logits.shape[0]
     D = vars2d.shape[1]
     dev = logits.device
@@ -571,14 +601,16 @@ def quant_fwd(logits, vars2d, G, V, tau, training, noise=None, seed=0):
     st.ppl = empty((2), torch.float32, dev)
     st.cvec = empty((G * V), torch.float32, dev)
     d = QuantDesc()
-    d.logits, d.noise, d.vars, d.q, d.idx = _p(logits), _p(noise), _p(vars2d), _p(q), _p(st.idx)
+    _quant_logits(d, logits, bias)
+    d.noise, d.vars, d.q, d.idx = _p(noise), _p(vars2d), _p(q), _p(st.idx)
     d.hard_cnt, d.prob_sum, d.ppl_out, d.cvec_out = _p(st.hard_cnt), _p(st.prob_sum), _p(st.ppl), _p(st.cvec)
     d.tau, d.R, d.G, d.V, d.D, d.training, d.seed = tau, R, G, V, D, int(training), seed
     _lib.call("w2vs_quant_fwd", C.byref(d), _stream())
     return q, st
 
 
-def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, noise=None, seed=0, ppl_grad_dev=None):
+def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, noise=None, seed=0, ppl_grad_dev=None,
+              bias=None):
     """Returns dlogits [R, G*V] bf16; accumulates dvars (fp32 [G*V, D])."""
     _chk(dq, BF16, "dq")
     R = logits.shape[0]
@@ -591,7 +623,8 @@ def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, 
                 a_bytes=(R * G * D) * 2, b_bytes=V * D * 2, c_elems=R * G * V)
     dlogits = empty((R, G * V), BF16, dq.device)
     d = QuantDesc()
-    d.logits, d.noise, d.vars = _p(logits), _p(noise), _p(vars2d)
+    _quant_logits(d, logits, bias)
+    d.noise, d.vars = _p(noise), _p(vars2d)
     d.prob_sum, d.dq, d.dsoft, d.cvec, d.dlogits, d.dvars = _p(st.prob_sum), _p(dq), _p(dsoft), _p(st.cvec), _p(dlogits), _p(dvars_f32)
     d.ppl_grad, d.tau, d.R, d.G, d.V, d.D, d.training, d.seed = ppl_grad, tau, R, G, V, D, int(training), seed
     d.ppl_grad_dev = _p(ppl_grad_dev)
@@ -659,6 +692,12 @@ def adam_step(p32, p16, m, v, g, *, lr, beta1, beta2, eps, weight_decay, step, s
 def sumsq(x, out):
     _chk(x, torch.float32, "x"); _chk(out, torch.float32, "out")
     _lib.call("w2vs_sumsq", _p(x), x.numel(), _p(out), _stream())
+
+
+def clip_scale(sumsq_buf, out3, *, scale_host=1.0, scale_dev=None, clip=0.0):
+    """out3 = [grad scale incl. the clip factor, gnorm, non-finite flag], all on the device (w2vs_clip_scale)."""
+    _chk(sumsq_buf, torch.float32, "sumsq"); _chk(out3, torch.float32, "out3"); _chk(scale_dev, torch.float32, "scale_dev")
+    _lib.call("w2vs_clip_scale", _p(sumsq_buf), _p(scale_dev), scale_host, clip, _p(out3), _stream())
 
 
 def gather_rows(src, idx, R, scatter=False, out=None):

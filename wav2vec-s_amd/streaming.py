@@ -125,7 +125,7 @@ class _HipLinear(torch.autograd.Function):
         w = weight.detach().to(BF16).contiguous()
         b = bias.detach().to(BF16).contiguous() if bias is not None else None
         y = ops.linear_fwd(x2, w, b)
-        if ops.ARENA.buf is not None:
+        if ops.ARENA.active:
             y = y.clone()
         ctx.save_for_backward(x2, w)
         ctx.meta = (shp, x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -139,7 +139,7 @@ class _HipLinear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy2, ops.transpose2d(w))
-            dx = (dx.clone() if ops.ARENA.buf is not None else dx).view(shp).to(xdt)
+            dx = (dx.clone() if ops.ARENA.active else dx).view(shp).to(xdt)
         if ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2]):
             dw32 = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
             db32 = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if bdt is not None else None

@@ -47,9 +47,35 @@ class FlatParams:
         self.v = torch.zeros_like(self.p32)
         self.step = 0
         model._flat = self
+        # parameters are VIEWS of p16: load_state_dict / load_pretrained_model / manual init write the bf16 image only, and
+        # the next adam_step would rewrite it from a stale fp32 master.  Re-derive the master after every load.
+        if hasattr(model, "register_load_state_dict_post_hook"):
+            model.register_load_state_dict_post_hook(lambda _m, _inc: self.sync_master_from_model())
 
     def zero_grad(self):
         self.arena.flat.zero_()
+
+    def sync_master_from_model(self):
+        """fp32 master <- the bf16 parameters the model currently holds (call after writing ``p.data`` by hand;
+        ``load_state_dict`` does it through a hook).  Mirrors FP16Optimizer rebuilding ``fp32_params`` from the model
+        (fs/optim/fp16_optimizer.py:53-77)."""
+        self.p32.copy_(self.p16)
+
+    # ---- optimizer state (fs/optim/fp16_optimizer.py:151-177 + torch Adam state: step, exp_avg, exp_avg_sq) ----
+    def state_dict(self):
+        return {"step": int(self.step), "fp32_params": self.p32.detach().cpu().clone(),
+                "exp_avg": self.m.detach().cpu().clone(), "exp_avg_sq": self.v.detach().cpu().clone(),
+                "layout": {n: (o, k) for n, (o, k, _) in self.arena.offsets.items()}}
+
+    def load_state_dict(self, sd):
+        lay = {n: (o, k) for n, (o, k, _) in self.arena.offsets.items()}
+        if sd.get("layout") != lay or sd["fp32_params"].numel() != self.p32.numel():
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        self.step = int(sd["step"])
+        self.p32.copy_(sd["fp32_params"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.p16.copy_(self.p32)          # the working copy is the rounded master, as after every update
 
 
 class GradExchange:
@@ -110,6 +136,34 @@ class GradExchange:
         self.works = []
 
 
+class PolynomialDecayLRSchedule:
+    """fs/optim/lr_scheduler/polynomial_decay_schedule.py:40-89 (``lr_scheduler: polynomial_decay`` of both wav2vec-S yamls,
+    warm-up 5 000 / 32 000 updates, decay to ``end_learning_rate`` at ``total_num_update`` = max_update).  ``step_update(n)``
+    is the rate the trainer applies to the update that FOLLOWS ``n`` completed ones (fs/trainer.py:981-983, 1049-1052):
+    the very first update of a run therefore uses 0 (warm-up factor 0 / warmup_updates), as in the reference."""
+
+    def __init__(self, lr, warmup_updates=0, total_num_update=400000, end_learning_rate=0.0, power=1.0):
+        assert total_num_update > 0
+        self.lr = float(lr[0] if isinstance(lr, (list, tuple)) else lr)
+        self.warmup_updates, self.total_num_update = int(warmup_updates), float(total_num_update)
+        self.end_learning_rate, self.power = float(end_learning_rate), float(power)
+        self.warmup_factor = 1.0 / self.warmup_updates if self.warmup_updates > 0 else 1.0
+        self.current = self.warmup_factor * self.lr
+
+    def step_update(self, num_updates):
+        if self.warmup_updates > 0 and num_updates <= self.warmup_updates:
+            self.warmup_factor = num_updates / float(self.warmup_updates)
+            lr = self.warmup_factor * self.lr
+        elif num_updates >= self.total_num_update:
+            lr = self.end_learning_rate
+        else:
+            warmup = self.warmup_updates
+            pct_remaining = 1 - (num_updates - warmup) / (self.total_num_update - warmup)
+            lr = (self.lr - self.end_learning_rate) * pct_remaining ** self.power + self.end_learning_rate
+        self.current = lr
+        return lr
+
+
 class TrainStep:
     """zero_grad -> forward -> criterion -> backward -> [all-reduce] -> Adam.  One call = one micro-batch; every
     ``update_freq``-th call closes an update (fs/trainer.py:632-910 with ``optimization.update_freq``): gradients of
@@ -119,11 +173,13 @@ class TrainStep:
     and ranks inside the fused Adam.  update_freq = 1 (default) is the bench's step."""
 
     def __init__(self, model, criterion, world_size=1, use_optimizer=True, lr=5e-4, betas=(0.9, 0.98), eps=1e-6,
-                 weight_decay=0.01, clip_norm=0.0, arena_gib=12.0, update_freq=1):
+                 weight_decay=0.01, clip_norm=0.0, arena_gib=12.0, update_freq=1, lr_scheduler=None, group=None):
         self.model, self.criterion, self.world = model, criterion, world_size
         self.flat = FlatParams(model)
         self.use_optimizer = use_optimizer
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
+        self.lr_scheduler = lr_scheduler      # e.g. PolynomialDecayLRSchedule; None = constant ``lr``
+        self.group = group
         self.update_freq = max(1, int(update_freq))
         self.micro = 0            # micro-batches accumulated in the current update
         self.ss_acc = 0
@@ -135,14 +191,34 @@ class TrainStep:
             tail = engine.milestone_offset(self.flat.arena, "post_extract_proj.")
             if tail >= self.flat.arena.numel:
                 tail = engine.milestone_offset(self.flat.arena, "encoder.")
-            self.exchange = GradExchange(self.flat.arena.flat, dist, flush_at=tail if tail < self.flat.arena.numel else -1)
-        self.norm_buf = torch.zeros(1, device=self.flat.p16.device, dtype=torch.float32)
-        # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB
-        ops.ARENA.activate(int(arena_gib * (1 << 30)), self.flat.p16.device)
+            self.exchange = GradExchange(self.flat.arena.flat, dist, group=group,
+                                         flush_at=tail if tail < self.flat.arena.numel else -1)
+        dev = self.flat.p16.device
+        self.norm_buf = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.clip_out = torch.zeros(3, device=dev, dtype=torch.float32)   # [grad scale, gnorm, non-finite flag]
+        # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB.  It hands out
+        # memory only while a step runs: anything else in the process (validation forward, streaming twin) gets torch's.
+        self.arena_bytes = int(arena_gib * (1 << 30))
+        ops.ARENA.activate(self.arena_bytes, dev)
+        ops.ARENA.suspend()
+
+    def grad_norm(self):
+        """Gradient norm of the last update after the 1/sample_size scaling (what fairseq logs as ``gnorm``); available
+        when clip_norm > 0.  Reads the device (a sync) - call it when logging, not every step."""
+        gn, bad = float(self.clip_out[1]), float(self.clip_out[2])
+        if bad:
+            raise FloatingPointError("gradients are Nan/Inf")        # fs/trainer.py:791-793
+        return gn
 
     def __call__(self, sample):
+        ops.ARENA.activate(self.arena_bytes, self.flat.p16.device)
+        try:
+            return self._step(sample)
+        finally:
+            ops.ARENA.suspend()
+
+    def _step(self, sample):
         f = self.flat
-        ops.ARENA.reset()
         first, last = self.micro == 0, self.micro == self.update_freq - 1
         if first:
             f.zero_grad()
@@ -164,10 +240,11 @@ class TrainStep:
             # torch.full is a fill kernel with the value as a launch argument; torch.tensor([...], device=) would be a
             # synchronous pageable H2D copy on this stream, i.e. the host would wait for the whole backward every step
             ss = torch.full((1,), float(self.ss_acc), device=f.p16.device, dtype=torch.float32)
-            self.dist.all_reduce(ss)
+            self.dist.all_reduce(ss, group=self.group)
             self.ss_dev = ss
             total = None
         if self.use_optimizer:
+            lr = self.lr_scheduler.step_update(f.step) if self.lr_scheduler is not None else self.lr
             f.step += 1
             scale_dev = None
             if total is None:
@@ -175,11 +252,13 @@ class TrainStep:
             else:
                 scale = 1.0 / float(total)
             if self.clip > 0:
+                # clip_grad_norm_ (fs/utils.py:341-386) on the gradient AFTER its division by sample_size
+                # (fs/trainer.py:769-774): norm, comparison and factor stay on the device; Adam reads the product
                 self.norm_buf.zero_()
                 ops.sumsq(f.arena.flat, self.norm_buf)
-                gnorm = float(self.norm_buf.sqrt()) * scale
-                if gnorm > self.clip:
-                    scale *= self.clip / (gnorm + 1e-6)
-            ops.adam_step(f.p32, f.p16, f.m, f.v, f.arena.flat, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                ops.clip_scale(self.norm_buf, self.clip_out, scale_host=scale, scale_dev=scale_dev, clip=self.clip)
+                scale, scale_dev = 1.0, self.clip_out[0:1]
+            ops.adam_step(f.p32, f.p16, f.m, f.v, f.arena.flat, lr=lr, beta1=self.betas[0], beta2=self.betas[1],
                           eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale, scale_dev=scale_dev)
+            self.last_lr = lr
         return loss.detach()

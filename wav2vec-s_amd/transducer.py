@@ -55,7 +55,7 @@ def _rnnt_lib():
     return lib
 
 
-RNNT_EXPORTS = ["get_warprnnt_version", "rnntGetStatusString", "compute_rnnt_loss", "get_workspace_size",
+RNNT_EXPORTS = ["get_warprnnt_version", "rnntGetStatusString", "compute_rnnt_loss", "compute_rnnt_loss_fp64", "get_workspace_size",
                 "compute_rnnt_delay_loss", "get_delay_workspace_size", "w2vs_rnnt_forward_async",
                 "w2vs_rnnt_backward_async", "w2vs_rnnt_delay_values", "w2vs_ls_ce_rows"]
 
