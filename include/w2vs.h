@@ -163,6 +163,9 @@ typedef struct w2vs_attn_desc {
 } w2vs_attn_desc;
 int w2vs_attn_fwd(const w2vs_attn_desc* d, void* stream);
 int w2vs_attn_bwd(const w2vs_attn_desc* d, void* stream);
+/* tests / A-B runs: 1 = the 128-query-workgroup kernels (csrc/attention.hip), 2 = the 32-row split kernels (csrc/attention2.hip,
+ * default), -1 = default again */
+int w2vs_attn_tune(int32_t variant);
 
 /* ---- composite: one post-LN Transformer encoder layer -------------------------------------------
  * TransformerSentenceEncoderLayer.forward (fs/models/wav2vec/wav2vec2.py:955-976) with the fused QKV
@@ -221,6 +224,7 @@ typedef struct w2vs_quant_desc {
   const float* ppl_grad_dev;   /* optional device scalar multiplied into ppl_grad (no host sync) */
   const float* logits_f32;     /* optional: fp32 logits WITHOUT bias (then `logits` may be NULL) */
   const void* logit_bias;      /* bf16 [G*V] added to logits_f32 (NULL = none) */
+  const float* dsoft_f32;      /* bwd, optional: dsoft as fp32 (W2VS_EPI_F32 product); then `dsoft` may be NULL */
 } w2vs_quant_desc;
 int w2vs_quant_fwd(const w2vs_quant_desc* d, void* stream);
 int w2vs_quant_bwd(const w2vs_quant_desc* d, void* stream);

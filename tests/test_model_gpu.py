@@ -59,6 +59,27 @@ BASE = dict(quantize_targets=True, extractor_mode="layer_norm", final_dim=256, e
             conv_feature_layers="[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 2")
 
 
+def _grad_group(n):
+    """Parameter families with their own error level (bf16 HIP vs fp32 oracle): bars are ~2 x the measured worst of each
+    family, so a regression in a 1 % family is not hidden behind the 6 % of a cancellation-dominated one."""
+    if n.startswith("feature_extractor."):
+        return "extractor_norm" if ".2." in n or n.endswith(".0.bias") else "extractor_conv"
+    if n.startswith("layer_norm."):
+        return "feature_ln"
+    if n.startswith("quantizer.weight_proj"):
+        return "quant_proj"
+    if n.startswith("quantizer.") or n.startswith("project_q.") or n.startswith("final_proj."):
+        return "heads"
+    if n.startswith("encoder.layers."):
+        return "enc_ln" if "layer_norm" in n else ("enc_bias" if n.endswith(".bias") else "enc_weight")
+    return "enc_misc"        # post_extract_proj, mask_emb, encoder.layer_norm
+
+
+# measured on MI355X (gpurun_out/parity_*.json, round 2): worst relative error per family, base / cfgA / cfgB / large
+GRAD_BARS = {"extractor_conv": 0.06, "extractor_norm": 0.12, "feature_ln": 0.10, "quant_proj": 0.06, "heads": 0.05,
+             "enc_weight": 0.045, "enc_bias": 0.06, "enc_ln": 0.06, "enc_misc": 0.06}
+
+
 def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
     w, model, P, ocfg, source, draws, mask, neg, noise = _setup(cfg_kw, B, L, seed, m_ctx, r_ctx)
     ocfg.loss_weights = tuple(loss_weights)
@@ -123,6 +144,12 @@ def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
         assert p.grad is not None, n
         grads[n] = rel(p.grad, want) if float(want.norm()) > 1e-6 else float(p.grad.float().norm())
     rep["grad_worst"] = sorted(grads.items(), key=lambda kv: -kv[1])[:8]
+    by = {}
+    for n, e in grads.items():
+        if "k_proj.bias" in n:
+            continue            # analytically zero (softmax shift invariance)
+        by[_grad_group(n)] = max(by.get(_grad_group(n), 0.0), e)
+    rep["grad_by_group"] = by
     rep["grad_median"] = float(np.median(list(grads.values())))
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, f"parity_{tag}.json"), "w") as f:
@@ -133,16 +160,8 @@ def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
 def test_base_model_step_matches_oracle():
     """Full-width base (12 x 768, conv 512, 320x2 codes, 100 negatives), post-LN, short audio."""
     rep, grads = _run_both(BASE, B=2, L=24000, seed=1, m_ctx=16, r_ctx=8, loss_weights=(0.1, 10.0), tag="base")
-    assert rep["loss_rel"] < 1e-3, rep
-    assert rep["conv0"] < 1e-2 and rep["conv_out"] < 2e-2 and rep["features"] < 2e-2, rep
-    assert rep["enc_out"] < 2e-2, rep
-    assert rep["code_idx_equal"] > 0.97, rep       # bf16 logits can flip near-tied argmaxes
-    assert rep["logits_maxabs"] < 0.15, rep        # logits are cos/0.1 in [-10, 10]
-    assert rep["features_pen_rel"] < 1e-2 and rep["prob_ppl_rel"] < 1e-2, rep
-    # k_proj.bias has an analytically zero gradient (softmax shift invariance): skip relative check
-    bad = {n: e for n, e in grads.items() if e > 0.08 and "k_proj.bias" not in n}
-    assert not bad, bad
-    assert rep["grad_median"] < 3e-2, rep
+    _assert_parity(rep, grads, loss_free=1e-3)
+    assert rep["logits_maxabs"] < 0.08, rep        # logits are cos/0.1 in [-10, 10]; measured 0.022
 
 
 def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, grad=0.08, median=3e-2):
@@ -151,24 +170,29 @@ def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, grad=0.08
         assert rep["loss_rel_unpinned"] < loss_free, rep
     assert rep["conv0"] < 1e-2 and rep["conv_out"] < act and rep["features"] < act and rep["enc_out"] < act, rep
     assert rep["features_pen_rel"] < 1e-2 and rep["prob_ppl_rel"] < 1e-2, rep
-    assert rep["code_idx_equal"] >= 0.985, rep
-    assert rep["code_flip_margin_max"] < 0.02 * rep["code_logit_std"] + 0.05, rep    # flips only between near-tied codes
+    # code selection: the quantizer logits are fp32 sums, but their input (the conv stack's features) is bf16 (0.8 % rel.
+    # error, `features` above), i.e. ~0.1-0.2 on logits of std 22.8 whose top-2 gap is ~6.6 on average: 1-2 % of the
+    # argmaxes sit closer than that and may flip.  Every disagreement must be such a near-tie in the ORACLE's logits.
+    assert rep["code_idx_equal"] >= 0.975, rep
+    assert rep["code_flip_margin_max"] < 0.03 * rep["code_logit_std"], rep
     bad = {n: e for n, e in grads.items() if e > grad and "k_proj.bias" not in n}
     assert not bad, bad
+    over = {g: e for g, e in rep["grad_by_group"].items() if e > GRAD_BARS[g] * (grad / 0.08)}
+    assert not over, (over, rep["grad_worst"])
     assert rep["grad_median"] < median, rep
 
 
 def test_cfgA_full_size_step_matches_oracle():
     """BASELINE configs[0]: base model, 2 x 160 000 samples (10 s), the reference's own CPU-runnable case - at its size."""
     rep, grads = _run_both(BASE, B=2, L=160000, seed=11, m_ctx=16, r_ctx=8, loss_weights=(0.1, 10.0), tag="cfgA")
-    _assert_parity(rep, grads, loss_free=5e-3)
+    _assert_parity(rep, grads, loss_free=1e-3)
 
 
 def test_cfgB_full_size_step_matches_oracle():
     """BASELINE configs[1], the bench batch: base model, 8 x 175 000 samples (1.4 M), R = 6 544 token rows - the sizes at
     which gemm.hip picks its loader/consumer, persistent and grouped weight-gradient kernels."""
     rep, grads = _run_both(BASE, B=8, L=175000, seed=12, m_ctx=16, r_ctx=8, loss_weights=(0.1, 10.0), tag="cfgB")
-    _assert_parity(rep, grads, loss_free=5e-3)
+    _assert_parity(rep, grads, loss_free=1e-3)
 
 
 def test_large_full_width_step_matches_oracle():
@@ -177,7 +201,7 @@ def test_large_full_width_step_matches_oracle():
     kw = dict(BASE, encoder_layers=24, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
               layer_norm_first=True, conv_bias=True, feature_grad_mult=1.0, final_dim=768)
     rep, grads = _run_both(kw, B=3, L=32000, seed=13, m_ctx=16, r_ctx=8, loss_weights=(0.1, 0.0), tag="large_full")
-    _assert_parity(rep, grads, loss=2e-3, loss_free=1e-2, act=3e-2, grad=0.12, median=5e-2)
+    _assert_parity(rep, grads, loss=1e-3, loss_free=1e-3, act=2e-2, grad=0.10, median=4e-2)
 
 
 def test_large_style_model_step_matches_oracle():

@@ -54,7 +54,7 @@ class QuantDesc(C.Structure):
                 ("prob_sum", vp), ("ppl_out", vp), ("cvec_out", vp), ("dq", vp), ("dsoft", vp), ("cvec", vp),
                 ("dlogits", vp), ("dvars", vp), ("ppl_grad", f32), ("tau", f32),
                 ("R", i32), ("G", i32), ("V", i32), ("D", i32), ("training", i32), ("seed", u64), ("ppl_grad_dev", vp),
-                ("logits_f32", vp), ("logit_bias", vp)]
+                ("logits_f32", vp), ("logit_bias", vp), ("dsoft_f32", vp)]
 
 
 class NceDesc(C.Structure):
@@ -116,6 +116,7 @@ _SIGS = {
     "w2vs_ce_rows": [vp, i64, i32, vp, vp, vp],
     "w2vs_gather_rows": [vp, vp, vp, i64, i32, i32, vp],
     "w2vs_gemm_tune": [i32, i32, i32],
+    "w2vs_attn_tune": [i32],
     "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],
     "w2vs_transpose_multi": [vp, i32, vp],
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],

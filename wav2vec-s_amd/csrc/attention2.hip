@@ -1,0 +1,640 @@
+// Block-causal streaming attention, second decomposition (gfx950, head_dim 64).  Same mathematics, masks, dropout words
+// and argument contract as attention.hip; what changes is who does what.
+//
+// Why: under gen_block_attn_mask (fs/models/wav2vec/wav2vec_S.py:444-489) a query of block b sees (b+1)*m main keys, so
+// the work of a 32-query tile grows linearly along the sequence.  In attention.hip one workgroup owns 128 queries and
+// walks the visible keys in lockstep: every launch lasts as long as its longest workgroup (measured on MI355X:
+// 61 us for the 236 k visible pairs of the cfgB shape - and 62 us for the 669 k pairs of the same shape unmasked).
+//
+// Here the unit is small and the long dimension is split:
+//   forward / dQ pass : workgroup = 32 queries of one (batch, head); its 4 waves take the visible 32-key sub-tiles
+//                       round-robin, each with its own online-softmax state, and merge (m, l, O) / sum dQ through LDS;
+//   dK/dV pass        : workgroup = 32 keys; its 4 waves take the visible 32-query sub-tiles round-robin, dK / dV summed
+//                       through LDS.
+// Workgroups are launched longest-first (host-made order table), so the tail of the launch is made of the short ones.
+// A wave never waits for another inside its loop: K / V (or Q / dO) fragments come straight from global memory into
+// MFMA operand registers, the one operand that must be transposed goes through a wave-private LDS tile
+// (ds_read_b64_tr_b16) - no barrier until the final merge.  The next sub-tile's loads are issued before the current
+// one is computed (two register sets).
+#include <algorithm>
+#include <vector>
+#include "attn_common.h"
+
+namespace w2vs {
+namespace {
+
+constexpr int NW2 = 4;       // waves per workgroup
+constexpr int MAXT2 = 512;   // 32-row tiles per sequence (N <= 16384)
+
+struct Attn2P {
+  AttnP a;
+  int ntiles;                 // query tiles (fwd, dq) or key tiles (dkv)
+  uint16_t order[MAXT2];      // tile ids, longest first
+};
+
+struct SubList { int nM, rc0, nT; };   // sub-tiles [0, nM) then rc0, rc0 + 1, ... : nT in all
+
+// 32-key sub-tiles the queries [q0, q1] can see
+__device__ __host__ inline void key_ranges_h(int q0, int q1, int Tp, int m, int r, int N, int& mlim, int& clo, int& chi, int& full) {
+  int bmin, bmax;
+  bool mixed = false;
+  if (q1 < Tp) { bmin = q0 / m; bmax = q1 / m; }
+  else if (q0 >= Tp) { bmin = r > 0 ? (q0 - Tp) / r : 0; bmax = r > 0 ? (q1 - Tp) / r : 0; }
+  else { bmin = 0; bmax = (Tp - 1) / m; mixed = true; }
+  mlim = std::min((bmax + 1) * m, Tp);
+  clo = r > 0 ? Tp + bmin * r : N;
+  chi = r > 0 ? std::min(Tp + (bmax + 1) * r, N) : N;
+  full = std::min((bmin + 1) * m, Tp);      // every query of the range sees the main keys below this
+  (void)mixed;
+}
+__device__ __host__ inline SubList key_list(int q0, int q1, int Tp, int m, int r, int N, int& full) {
+  int mlim, clo, chi;
+  key_ranges_h(q0, q1, Tp, m, r, N, mlim, clo, chi, full);
+  SubList t;
+  t.nM = (mlim + 31) >> 5;
+  int lo = std::max(clo >> 5, t.nM), hi = (chi + 31) >> 5;
+  if (chi <= clo || hi < lo) hi = lo;
+  t.rc0 = lo;
+  t.nT = t.nM + (hi - lo);
+  return t;
+}
+// 32-query sub-tiles that can see the keys [k0, k1]; queries are 0..Nq-1 (Nq == N or Nq <= Tp)
+__device__ __host__ inline SubList query_list(int k0, int k1, int Tp, int m, int r, int N, int Nq) {
+  int mq0, mq1, rq0, rq1;
+  if (k1 < Tp) { const int bmin = k0 / m; mq0 = bmin * m; mq1 = Tp; rq0 = r > 0 ? Tp + bmin * r : N; rq1 = N; }
+  else if (k0 >= Tp) {
+    const int bmin = (k0 - Tp) / std::max(r, 1), bmax = (k1 - Tp) / std::max(r, 1);
+    mq0 = bmin * m; mq1 = std::min((bmax + 1) * m, Tp); rq0 = Tp + bmin * r; rq1 = std::min(Tp + (bmax + 1) * r, N);
+  } else { mq0 = 0; mq1 = Tp; rq0 = Tp; rq1 = N; }
+  mq1 = std::min(mq1, Nq);
+  rq1 = std::min(rq1, Nq);
+  SubList t;
+  const int m_lo = mq0 >> 5, m_hi = mq1 > mq0 ? (mq1 + 31) >> 5 : m_lo;
+  t.nM = m_hi - m_lo;                      // main sub-tiles m_lo .. m_hi-1: encoded through rc0 below
+  int lo = std::max(rq0 >> 5, m_hi), hi = (rq1 + 31) >> 5;
+  if (rq1 <= rq0 || hi < lo) hi = lo;
+  t.rc0 = lo;
+  t.nT = t.nM + (hi - lo);
+  // main part starts at m_lo: callers map position p -> (p < nM ? m_lo + p : rc0 + p - nM); m_lo travels in the sign-free
+  // upper half of nM to keep the struct three ints
+  t.nM |= m_lo << 16;
+  return t;
+}
+
+__device__ __forceinline__ float other_half(float v) {   // the value held by lane ^ 32
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const u2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  // one of the two results is this lane's own value, the other its partner's - whichever operand the swap moved
+  return __builtin_bit_cast(float, r[0] != x ? r[0] : r[1]);
+}
+// max over the two lane halves.  NOT fmaxf(r[0], r[1]) of one swap: when the compiler hands the instruction the same
+// register twice, both results are the partner's value and the lane's own maximum is lost (seen on gfx950: a query whose
+// visible keys of a tile all sat in one half lost them).
+__device__ __forceinline__ float max_halves(float v) { return fmaxf(v, other_half(v)); }
+
+// mask one 32 x 32 score tile (keys on accumulator rows, queries on lanes): invisible or padded keys -> -inf
+__device__ __forceinline__ void mask_keys(f32x16& S, int hh, int lim_r, int clo_r, int chi_r, uint32_t padbits) {
+  lim_r -= 4 * hh; clo_r -= 4 * hh; chi_r -= 4 * hh;
+  const uint32_t pb = padbits >> (4 * hh);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rc = (i & 3) + 8 * (i >> 2);
+    const bool ok = ((rc < lim_r) | ((rc >= clo_r) & (rc < chi_r))) & !((pb >> rc) & 1u);
+    S[i] = ok ? S[i] : -INFINITY;
+  }
+}
+// 32 padding bits of the keys k0 .. k0+31 (bit j = key k0+j is padded or beyond N), wave-uniform
+__device__ __forceinline__ uint32_t pad_bits(const uint8_t* kp, int k0, int N, int r32) {
+  const int key = k0 + r32;
+  const bool bad = key >= N || (kp && kp[key]);
+  return (uint32_t)__ballot(bad);          // lanes 0..31 and 32..63 vote alike: the low word is the tile's mask
+}
+
+struct KVRegs { bf16x8 k[4]; u32x4 v[4]; };
+
+// =================================================================================================
+// forward
+// =================================================================================================
+__global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
+  const AttnP& p = pp.a;
+  // loop: wave-private V tiles (tr-read images, 4 KB each); afterwards the same memory carries (O0, O1, m, l) of waves 1..3.
+  // 26 KB per workgroup and <= 128 registers: four workgroups per CU, so one workgroup's prologue / merge (dependent
+  // global loads, a barrier) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
+  __shared__ __attribute__((aligned(16))) float smem[(NW2 - 1) * 34 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int BH = p.B * p.H;
+  const int qt = pp.order[blockIdx.x / BH], bh = blockIdx.x % BH;
+  const int b = bh / p.H, h = bh % p.H;
+  const int N = p.N, Nq = p.Nq;
+  const int q0 = qt * 32, q = q0 + r32, qc = min(q, Nq - 1);
+  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* K = p.k + (long)b * p.sb + h * HD;
+  const bf16* V = p.v + (long)b * p.sb + h * HD;
+  const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Q + (long)qc * p.ld + 16 * s + 8 * hh);
+  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
+  int wfull;
+  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, wfull);
+  if (kp) wfull = 0;
+
+  const float c = p.scale * LOG2E;
+  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
+  const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
+  const uint32_t Nh = (uint32_t)(N + 1) >> 1;
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)qc) * Nh;
+
+  f32x16 O0, O1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { O0[i] = 0.f; O1[i] = 0.f; }
+  float mrun = -INFINITY, lrun = 0.f;       // mrun: scaled (log2) units, shared by both lane halves of a query
+  bf16* Vw = (bf16*)smem + wid * (32 * HD);
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int vrow = lane >> 3, vch = lane & 7;
+
+  auto tile_of = [&](int pos) { return pos < tl.nM ? pos : tl.rc0 + (pos - tl.nM); };
+  bf16x8 kr[4];
+  u32x4 vr[4];
+  auto load_k = [&](int t) {
+    const long krow = (long)min(t * 32 + r32, N - 1) * p.ld;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(K + krow + 16 * s + 8 * hh);
+  };
+  auto load_v = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vr[j] = *(const u32x4*)(V + (long)min(t * 32 + vrow + 8 * j, N - 1) * p.ld + vch * 8);
+  };
+  int pos = wid;
+  if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
+  while (pos < tl.nT) {
+    const int k0 = tile_of(pos) * 32;
+    const int nxt = pos + NW2;
+    // one register set: the V registers are free again once they sit in LDS, the K registers once S is issued - the next
+    // sub-tile's loads go out right there and have the softmax and the P.V product to land
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(u32x4*)(Vw + vswz(vrow + 8 * j, vch * 8)) = vr[j];
+    if (nxt < tl.nT) load_v(tile_of(nxt));
+    f32x16 S;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[s], qf[s], S, 0, 0, 0);
+    if (nxt < tl.nT) load_k(tile_of(nxt));
+    if (!(k0 + 32 <= wfull)) {          // wave-uniform: boundary / right-context / padded tiles only
+      const uint32_t pb = (kp || k0 + 32 > N) ? pad_bits(kp, k0, N, r32) : 0u;
+      mask_keys(S, hh, L.lim - k0, L.clo - k0, L.chi - k0, pb);
+    }
+    float mloc = fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3]));
+#pragma unroll
+    for (int i = 4; i < 16; i += 2) mloc = fmaxf(mloc, fmaxf(S[i], S[i + 1]));
+    mloc = max_halves(mloc) * c;
+    // lazy rescale (attention.hip): keep the reference maximum while no query's maximum grew by more than 2^6
+    float muse;
+    if (__all(mloc <= mrun + 6.0f)) {
+      muse = (mrun == -INFINITY) ? 0.f : mrun;
+    } else {
+      const float mnew = fmaxf(mrun, mloc);
+      muse = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = fast_exp2(mrun - muse);
+      mrun = mnew;
+      lrun *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = fast_exp2(fmaf(S[i], c, -muse)); ls += S[i]; }
+    lrun += ls;
+    if (thr > 0) {      // keep decisions: two per hash word (attn_common.h); 1/(1-p) is applied once, at the end
+      const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * HASH_K);
+        S[i] = (hw & 0xFFFFu) >= thr ? S[i] : 0.f;
+        S[i + 1] = (hw >> 16) >= thr ? S[i + 1] : 0.f;
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pb = pack8(S, s2);
+      const int krow = 16 * s2 + 4 * (g >> 1) + tq;
+      const int dcol = (g & 1) * 16 + 4 * tp;
+      const bf16x8 a0 = tr_pair(Vw + vswz(krow, dcol), Vw + vswz(krow + 8, dcol));
+      const bf16x8 a1 = tr_pair(Vw + vswz(krow, 32 + dcol), Vw + vswz(krow + 8, 32 + dcol));
+      O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pb, O0, 0, 0, 0);
+      O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb, O1, 0, 0, 0);
+    }
+    pos = nxt;
+  }
+  // ---- merge the four partial softmaxes ----
+  float ltot = lrun + other_half(lrun);
+  __syncthreads();                       // every wave is done with its V tile: the memory becomes the merge buffer
+  if (wid > 0) {
+    float* rw = smem + (wid - 1) * 34 * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { rw[i * 64 + lane] = O0[i]; rw[(16 + i) * 64 + lane] = O1[i]; }
+    rw[32 * 64 + lane] = mrun;
+    rw[33 * 64 + lane] = ltot;
+  }
+  __syncthreads();
+  if (wid != 0) return;
+  float mw[NW2 - 1], mall = mrun;
+#pragma unroll
+  for (int w = 0; w < NW2 - 1; ++w) { mw[w] = smem[(w * 34 + 32) * 64 + lane]; mall = fmaxf(mall, mw[w]); }
+  const float mref = (mall == -INFINITY) ? 0.f : mall;
+  const float a0s = fast_exp2(mrun - mref);
+  ltot *= a0s;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { O0[i] *= a0s; O1[i] *= a0s; }
+#pragma unroll
+  for (int w = 0; w < NW2 - 1; ++w) {
+    const float* rw = smem + w * 34 * 64;
+    const float aw = fast_exp2(mw[w] - mref);
+    ltot = fmaf(rw[33 * 64 + lane], aw, ltot);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { O0[i] = fmaf(rw[i * 64 + lane], aw, O0[i]); O1[i] = fmaf(rw[(16 + i) * 64 + lane], aw, O1[i]); }
+  }
+  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
+  const float inv = ltot > 0.f ? inv_keep / ltot : 0.f;
+  if (q < Nq) {
+    bf16* orow = p.o + (long)b * p.sbo + (long)q * p.ldo + h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      bf16x4 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = f2bf(O0[4 * gq + e] * inv); v1[e] = f2bf(O1[4 * gq + e] * inv); }
+      *(bf16x4*)(orow + 8 * gq + 4 * hh) = v0;
+      *(bf16x4*)(orow + 32 + 8 * gq + 4 * hh) = v1;
+    }
+    if (hh == 0 && p.lse) p.lse[((long)(b * p.H + h)) * N + q] = ltot > 0.f ? (mall + log2f(ltot)) * LN2 : INFINITY;
+  }
+}
+
+// =================================================================================================
+// backward, dQ pass (also writes delta = dO . O for the dK/dV pass)
+//   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T o drop - delta)
+//   dQ^T[d][q] += K^T[d][key] dS^T[key][q]           (scale applied once at the end)
+// =================================================================================================
+__global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
+  const AttnP& p = pp.a;
+  // loop: wave-private K tiles (tr-read images); afterwards the partial dQ of waves 1..3 (24 KB)
+  __shared__ __attribute__((aligned(16))) float red_mem[(NW2 - 1) * 32 * 64];
+  float (*red)[32][64] = (float (*)[32][64])red_mem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int BH = p.B * p.H;
+  const int qt = pp.order[blockIdx.x / BH], bh = blockIdx.x % BH;
+  const int b = bh / p.H, h = bh % p.H;
+  const int N = p.N, Nq = p.Nq;
+  const int q0 = qt * 32, q = q0 + r32, qc = min(q, Nq - 1);
+  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* K = p.k + (long)b * p.sb + h * HD;
+  const bf16* V = p.v + (long)b * p.sb + h * HD;
+  const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
+  const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *(const bf16x8*)(Q + (long)qc * p.ld + 16 * s + 8 * hh);
+    dof[s] = *(const bf16x8*)(dO + (long)qc * p.ldo + 16 * s + 8 * hh);
+  }
+  const long sidx = ((long)(b * p.H + h)) * N + qc;
+  const float lse2 = p.lse[sidx] * LOG2E;
+  float delta = 0.f;
+  {
+    const bf16* Orow = p.o + (long)b * p.sbo + (long)qc * p.ldo + h * HD;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 ov = *(const bf16x8*)(Orow + 16 * s + 8 * hh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta = fmaf(bf2f(ov[e]), bf2f(dof[s][e]), delta);
+    }
+  }
+  delta += other_half(delta);
+  if (wid == 0 && q < Nq && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
+  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
+  int wfull;
+  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, wfull);
+  if (kp) wfull = 0;
+  const float c = p.scale * LOG2E;
+  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
+  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
+  const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
+  const uint32_t Nh = (uint32_t)(N + 1) >> 1;
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)qc) * Nh;
+  f32x16 D0, D1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { D0[i] = 0.f; D1[i] = 0.f; }
+  bf16* Kw = (bf16*)red_mem + wid * (32 * HD);
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  auto tile_of = [&](int pos) { return pos < tl.nM ? pos : tl.rc0 + (pos - tl.nM); };
+  bf16x8 kr[4], vr[4];
+  auto load_k = [&](int t) {
+    const long krow = (long)min(t * 32 + r32, N - 1) * p.ld;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(K + krow + 16 * s + 8 * hh);
+  };
+  auto load_v = [&](int t) {
+    const long krow = (long)min(t * 32 + r32, N - 1) * p.ld;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vr[s] = *(const bf16x8*)(V + krow + 16 * s + 8 * hh);
+  };
+  int pos = wid;
+  if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
+  while (pos < tl.nT) {
+    const int k0 = tile_of(pos) * 32;
+    const int nxt = pos + NW2;
+    asm volatile("" ::: "memory");
+    // the K fragments this lane holds are chunks (2s + hh) of row r32: write them as the row-major tile the tr reads want
+#pragma unroll
+    for (int s = 0; s < 4; ++s) *(bf16x8*)(Kw + vswz(r32, (2 * s + hh) * 8)) = kr[s];
+    f32x16 S, dP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[s], qf[s], S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[s], dof[s], dP, 0, 0, 0);
+    }
+    if (nxt < tl.nT) { load_k(tile_of(nxt)); load_v(tile_of(nxt)); }     // one register set: free once S / dP are issued
+    if (!(k0 + 32 <= wfull)) {
+      const uint32_t pb = (kp || k0 + 32 > N) ? pad_bits(kp, k0, N, r32) : 0u;
+      mask_keys(S, hh, L.lim - k0, L.clo - k0, L.chi - k0, pb);
+    }
+    if (thr > 0) {
+      const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * HASH_K);
+        dP[i] = (hw & 0xFFFFu) >= thr ? dP[i] * inv_keep : 0.f;
+        dP[i + 1] = (hw >> 16) >= thr ? dP[i + 1] * inv_keep : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[i] = fast_exp2(fmaf(S[i], c, -lse2)) * (dP[i] - delta);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 db = pack8(S, s2);
+      const int krow = 16 * s2 + 4 * (g >> 1) + tq;
+      const int dcol = (g & 1) * 16 + 4 * tp;
+      const bf16x8 a0 = tr_pair(Kw + vswz(krow, dcol), Kw + vswz(krow + 8, dcol));
+      const bf16x8 a1 = tr_pair(Kw + vswz(krow, 32 + dcol), Kw + vswz(krow + 8, 32 + dcol));
+      D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, db, D0, 0, 0, 0);
+      D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, db, D1, 0, 0, 0);
+    }
+    pos = nxt;
+  }
+  __syncthreads();
+  if (wid > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { red[wid - 1][i][lane] = D0[i]; red[wid - 1][16 + i][lane] = D1[i]; }
+  }
+  __syncthreads();
+  if (wid != 0) return;
+#pragma unroll
+  for (int w = 0; w < NW2 - 1; ++w)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { D0[i] += red[w][i][lane]; D1[i] += red[w][16 + i][lane]; }
+  if (q < Nq) {
+    bf16* drow_p = p.dq + (long)b * p.sb + (long)q * p.ld + h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      bf16x4 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = f2bf(D0[4 * gq + e] * p.scale); v1[e] = f2bf(D1[4 * gq + e] * p.scale); }
+      *(bf16x4*)(drow_p + 8 * gq + 4 * hh) = v0;
+      *(bf16x4*)(drow_p + 32 + 8 * gq + 4 * hh) = v1;
+    }
+  }
+}
+
+// =================================================================================================
+// backward, dK / dV pass.  S (not transposed): queries on accumulator rows, keys on lanes.
+//   S = Q K^T ; P = exp(S - lse[q]) ; dP = dO V^T ; dS = P o (dP o drop - delta[q])        (scale at the end, dK only)
+//   dV^T[d][key] += dO^T[d][q] (P o drop)[q][key]      dK^T[d][key] += Q^T[d][q] dS[q][key]
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
+  const AttnP& p = pp.a;
+  // during the loop: per wave a Q tile and a dO tile (tr-read images, 4 KB each) and five 32-entry query vectors;
+  // afterwards the same memory carries the partial dK / dV of waves 1..3
+  __shared__ __attribute__((aligned(16))) float smem[(NW2 - 1) * 64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int BH = p.B * p.H;
+  const int kt = pp.order[blockIdx.x / BH], bh = blockIdx.x % BH;
+  const int b = bh / p.H, h = bh % p.H;
+  const int N = p.N, Nq = p.Nq;
+  const int kb0 = kt * 32, key = kb0 + r32, keyc = min(key, N - 1);
+  bf16* Qw = (bf16*)smem + wid * (2 * 32 * HD);
+  bf16* Dw = Qw + 32 * HD;
+  float* qs = smem + (NW2 * 2 * 32 * HD) / 2 + wid * 160;       // lse, delta, lim, clo, chi of the sub-tile's 32 queries
+  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* K = p.k + (long)b * p.sb + h * HD;
+  const bf16* V = p.v + (long)b * p.sb + h * HD;
+  const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
+  const bool key_ok = key < N && !(p.kpad && p.kpad[(long)b * N + key]);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *(const bf16x8*)(K + (long)keyc * p.ld + 16 * s + 8 * hh);
+    vf[s] = *(const bf16x8*)(V + (long)keyc * p.ld + 16 * s + 8 * hh);
+  }
+  const float c = p.scale * LOG2E;
+  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
+  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
+  const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
+  const uint32_t Nh = (uint32_t)(N + 1) >> 1;
+  const uint32_t dbase = (uint32_t)(b * p.H + h) * (uint32_t)N;
+  const uint32_t khalf = (uint32_t)keyc >> 1, kodd = (uint32_t)keyc & 1u;
+  const uint32_t stepK = Nh * HASH_K;
+  const bool keys_clean = __all(key_ok);
+  SubList ql = query_list(kb0, min(kb0 + 32, N) - 1, p.Tp, p.m, p.r, N, Nq);
+  const int qm_lo = ql.nM >> 16;
+  ql.nM &= 0xFFFF;
+  f32x16 dV0, dV1, dK0, dK1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
+  const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  struct Regs { bf16x8 q[4], d[4]; float sc; };       // sc: lse (lanes < 32) / delta (lanes >= 32) of query q0 + r32
+  auto tile_of = [&](int pos) { return pos < ql.nM ? qm_lo + pos : ql.rc0 + (pos - ql.nM); };
+  Regs R;
+  auto gload = [&](int t) {
+    const int qq = min(t * 32 + r32, Nq - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      R.q[s] = *(const bf16x8*)(Q + (long)qq * p.ld + 16 * s + 8 * hh);
+      R.d[s] = *(const bf16x8*)(dO + (long)qq * p.ldo + 16 * s + 8 * hh);
+    }
+    const long si = (long)(b * p.H + h) * N + qq;
+    R.sc = hh ? p.delta[si] : p.lse[si] * LOG2E;
+  };
+  int pos = wid;
+  if (pos < ql.nT) gload(tile_of(pos));
+  while (pos < ql.nT) {
+    const int q0 = tile_of(pos) * 32;
+    const int nxt = pos + NW2;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      *(bf16x8*)(Qw + vswz(r32, (2 * s + hh) * 8)) = R.q[s];
+      *(bf16x8*)(Dw + vswz(r32, (2 * s + hh) * 8)) = R.d[s];
+    }
+    // per-query scalars: rows past Nq get lse = +inf -> P = 0
+    const bool qvalid = q0 + r32 < Nq;
+    qs[lane] = qvalid ? R.sc : (hh ? 0.f : INFINITY);
+    // visibility limits of the sub-tile's queries; "full" = every query sees every key of this workgroup, none padded
+    int minlim = 0;
+    {
+      const int qs1 = min(q0 + 32, Nq) - 1;
+      if (qs1 < p.Tp) minlim = min((q0 / p.m + 1) * p.m, p.Tp);
+      else if (q0 >= p.Tp && p.r > 0) minlim = min(((q0 - p.Tp) / p.r + 1) * p.m, p.Tp);
+    }
+    const bool full = keys_clean && q0 + 32 <= Nq && kb0 + 32 <= minlim;
+    if (!full && hh == 0) {
+      const QLimits L = q_limits(min(q0 + r32, Nq - 1), p.Tp, p.m, p.r, N);
+      ((int*)qs)[64 + r32] = L.lim; ((int*)qs)[96 + r32] = L.clo; ((int*)qs)[128 + r32] = L.chi;
+    }
+    f32x16 S, dP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R.q[s], kf[s], S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R.d[s], vf[s], dP, 0, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+    if (nxt < ql.nT) gload(tile_of(nxt));      // one register set: Q / dO fragments are in LDS and in the MFMAs by now
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const uint32_t wsub = ((dbase + (uint32_t)(q0 + 4 * hh)) * Nh + khalf) * HASH_K;
+    f32x16 Pd;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int rb = 8 * g4 + 4 * hh;
+      const f32x4 lse4 = *(const f32x4*)(qs + rb);
+      const f32x4 del4 = *(const f32x4*)(qs + 32 + rb);
+      float pe[4];
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pe[e] = fast_exp2(fmaf(S[4 * g4 + e], c, -lse4[e]));
+      } else {
+        const i32x4 lim4 = *(const i32x4*)((const int*)qs + 64 + rb), clo4 = *(const i32x4*)((const int*)qs + 96 + rb),
+                    chi4 = *(const i32x4*)((const int*)qs + 128 + rb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = key_ok & ((key < lim4[e]) | ((key >= clo4[e]) & (key < chi4[e])));
+          const float v = fast_exp2(fmaf(S[4 * g4 + e], c, -lse4[e]));
+          pe[e] = ok ? v : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g4 + e;
+        float ks = 1.f;
+        if (thr > 0) {   // word ((dbase + query) * Nh + key / 2): consecutive rows are stepK apart
+          const uint32_t hw = pair_hash_pm(s0, s1, wsub + (uint32_t)(8 * g4 + e) * stepK);
+          ks = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? inv_keep : 0.f;
+        }
+        Pd[i] = pe[e] * ks;
+        S[i] = pe[e] * (dP[i] * ks - del4[e]);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pb = pack8(Pd, s2), sb = pack8(S, s2);
+      const int qrow = 16 * s2 + 4 * (g >> 1) + tq;
+      const int dcol = (g & 1) * 16 + 4 * tp;
+      const bf16x8 d0 = tr_pair(Dw + vswz(qrow, dcol), Dw + vswz(qrow + 8, dcol));
+      const bf16x8 d1 = tr_pair(Dw + vswz(qrow, 32 + dcol), Dw + vswz(qrow + 8, 32 + dcol));
+      dV0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, pb, dV0, 0, 0, 0);
+      dV1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, pb, dV1, 0, 0, 0);
+      const bf16x8 q0f = tr_pair(Qw + vswz(qrow, dcol), Qw + vswz(qrow + 8, dcol));
+      const bf16x8 q1f = tr_pair(Qw + vswz(qrow, 32 + dcol), Qw + vswz(qrow + 8, 32 + dcol));
+      dK0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0f, sb, dK0, 0, 0, 0);
+      dK1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1f, sb, dK1, 0, 0, 0);
+    }
+    pos = nxt;
+  }
+  __syncthreads();                       // every wave is done with its tiles: the memory becomes the reduction buffer
+  if (wid > 0) {
+    float* rw = smem + (wid - 1) * 64 * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      rw[i * 64 + lane] = dK0[i]; rw[(16 + i) * 64 + lane] = dK1[i];
+      rw[(32 + i) * 64 + lane] = dV0[i]; rw[(48 + i) * 64 + lane] = dV1[i];
+    }
+  }
+  __syncthreads();
+  if (wid != 0) return;
+#pragma unroll
+  for (int w = 0; w < NW2 - 1; ++w) {
+    const float* rw = smem + w * 64 * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      dK0[i] += rw[i * 64 + lane]; dK1[i] += rw[(16 + i) * 64 + lane];
+      dV0[i] += rw[(32 + i) * 64 + lane]; dV1[i] += rw[(48 + i) * 64 + lane];
+    }
+  }
+  if (key < N) {
+    bf16* dkr = p.dk + (long)b * p.sb + (long)key * p.ld + h * HD;
+    bf16* dvr = p.dv + (long)b * p.sb + (long)key * p.ld + h * HD;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      bf16x4 a0, a1, b0, b1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] = f2bf(dK0[4 * gq + e] * p.scale); a1[e] = f2bf(dK1[4 * gq + e] * p.scale);
+        b0[e] = f2bf(dV0[4 * gq + e]); b1[e] = f2bf(dV1[4 * gq + e]);
+      }
+      *(bf16x4*)(dkr + 8 * gq + 4 * hh) = a0;
+      *(bf16x4*)(dkr + 32 + 8 * gq + 4 * hh) = a1;
+      *(bf16x4*)(dvr + 8 * gq + 4 * hh) = b0;
+      *(bf16x4*)(dvr + 32 + 8 * gq + 4 * hh) = b1;
+    }
+  }
+}
+
+// longest-first order of the 32-row tiles (host; the kernels recompute the lists themselves, so this is speed only)
+template <class F>
+void make_order(Attn2P& pp, int ntiles, F count) {
+  std::vector<std::pair<int, int>> v(ntiles);
+  for (int t = 0; t < ntiles; ++t) v[t] = {-count(t), t};
+  std::sort(v.begin(), v.end());
+  pp.ntiles = ntiles;
+  for (int t = 0; t < ntiles; ++t) pp.order[t] = (uint16_t)v[t].second;
+}
+
+}  // namespace
+
+bool attn2_ok(const AttnP& p) { return (p.N + 31) / 32 <= MAXT2; }
+
+int attn2_fwd(const AttnP& p, hipStream_t st) {
+  Attn2P pp;
+  pp.a = p;
+  const int nqt = (p.Nq + 31) / 32;
+  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, f).nT; });
+  hipLaunchKernelGGL(attn2_fwd_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);
+  return hip_check(hipGetLastError(), "attn_fwd");
+}
+
+int attn2_bwd(const AttnP& p, hipStream_t st) {
+  Attn2P pp;
+  pp.a = p;
+  const int nqt = (p.Nq + 31) / 32, nkt = (p.N + 31) / 32;
+  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, f).nT; });
+  hipLaunchKernelGGL(attn2_dq_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);     // dq rows >= Nq are not written
+  make_order(pp, nkt, [&](int t) { return query_list(t * 32, std::min(t * 32 + 32, p.N) - 1, p.Tp, p.m, p.r, p.N, p.Nq).nT; });
+  hipLaunchKernelGGL(attn2_dkv_kernel, dim3(nkt * p.B * p.H), dim3(256), 0, st, pp);
+  return hip_check(hipGetLastError(), "attn_bwd");
+}
+
+}  // namespace w2vs

@@ -1,0 +1,128 @@
+// Device helpers shared by the attention kernels (attention.hip: v1, one workgroup = 128 queries walking the keys in
+// lockstep; attention2.hip: v2, one workgroup = 32 queries / 32 keys with the reduction dimension split over its waves).
+#pragma once
+#include "common.h"
+#include "w2vs_internal.h"
+
+namespace w2vs {
+
+constexpr int HD = 64;         // head dim
+constexpr int QB = 128;        // queries per block (4 waves x 32)
+constexpr int KT = 64;         // keys per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnP {
+  const bf16* q; const bf16* k; const bf16* v;  // [B, N, ld] with the head at column h*64
+  bf16* o;                                      // [B, N, ldo]
+  float* lse;                                   // [B, H, N] natural-log LSE of the scaled scores
+  const uint8_t* kpad;                          // [B, N] 1 = padded key (may be null)
+  const bf16* dout; const float* delta;         // backward
+  bf16* dq; bf16* dk; bf16* dv;                 // [B, N, ld] same layout as q/k/v
+  long ld, ldo, sb, sbo;                        // row stride, batch stride (elements)
+  int B, H, N, Tp, m, r;
+  int Nq;                                       // queries are positions 0..Nq-1 (Nq == N, or Nq <= Tp: main frames only)
+  float scale; float p_drop; uint64_t seed;
+};
+
+// LDS image of a [rows][64] bf16 tile read by rows (16-B chunks): XOR swizzle as in gemm.hip
+__device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+// LDS image of a [rows][64] bf16 tile read through tr reads (8-B pieces): flip the 64-B half on
+// rows 2,3 (mod 4) so the four rows of a tr block sit on distinct banks
+__device__ __forceinline__ int vswz(int row, int col) { return row * 64 + (col ^ (((row >> 1) & 1) << 5)); }
+
+__device__ __forceinline__ s16x4 ds_tr16(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x8 tr_pair(const bf16* lo, const bf16* hi) {
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = ds_tr16(lo);
+  u.h[1] = ds_tr16(hi);
+  return u.v;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = f2bf(a[8 * s + j]);
+  return r;
+}
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+// Scaled + masked scores of one 32-key sub-tile, branch free: the 16 key biases of this lane's accumulator rows
+// come in as four 16-byte LDS reads, the mask compares compile-time row offsets against lane-relative limits.
+// (A per-element `ok ? S*c + kb[kl] : -inf` made the compiler branch around sixteen dependent ds_read_b32.)
+__device__ __forceinline__ void masked_scores(f32x16& S, float c, const float* kb32, int hh, int lim_r, int clo_r, int chi_r) {
+  f32x4 kbv[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(kb32 + 8 * g4 + 4 * hh);
+  lim_r -= 4 * hh; clo_r -= 4 * hh; chi_r -= 4 * hh;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rc = (i & 3) + 8 * (i >> 2);
+    const bool ok = (rc < lim_r) | ((rc >= clo_r) & (rc < chi_r));
+    const float sv = fmaf(S[i], c, kbv[i >> 2][i & 3]);
+    S[i] = ok ? sv : -INFINITY;
+  }
+}
+
+struct QLimits { int lim, clo, chi; };
+__device__ __forceinline__ QLimits q_limits(int q, int Tp, int m, int r, int N) {
+  QLimits L;
+  int bq = (q < Tp) ? q / m : (r > 0 ? (q - Tp) / r : 0);
+  L.lim = min((bq + 1) * m, Tp);
+  L.clo = r > 0 ? Tp + bq * r : N;
+  L.chi = r > 0 ? min(Tp + (bq + 1) * r, N) : N;
+  return L;
+}
+// key range a set of queries [q0, q1] can touch: main keys [0, mlim), copies [clo, chi)
+__device__ __forceinline__ void tile_ranges(int q0, int q1, int Tp, int m, int r, int N, int& mlim, int& clo, int& chi) {
+  int bmin, bmax;
+  if (q1 < Tp) { bmin = q0 / m; bmax = q1 / m; }
+  else if (q0 >= Tp) { bmin = r > 0 ? (q0 - Tp) / r : 0; bmax = r > 0 ? (q1 - Tp) / r : 0; }
+  else { bmin = 0; bmax = (Tp - 1) / m; }
+  mlim = min((bmax + 1) * m, Tp);
+  clo = r > 0 ? Tp + bmin * r : N;
+  chi = r > 0 ? min(Tp + (bmax + 1) * r, N) : N;
+}
+// attention-dropout keep decision: 32-bit element index ((b*H+h)*N + q)*N + key, two-round
+// multiply-xorshift mix keyed by the 64-bit seed.  Cheaper than common.h's hash32 because it runs
+// once per score inside three kernels (fwd, dQ pass, dK/dV pass) that must agree bit for bit.
+__device__ __forceinline__ float keep_scale(uint32_t s0, uint32_t s1, uint32_t idx, uint32_t thr, float inv_keep) {
+  uint32_t x = idx * 0x9E3779B1u ^ s0;
+  x ^= x >> 16; x *= 0x85EBCA6Bu;
+  x ^= x >> 13; x *= 0xC2B2AE35u;
+  x ^= s1;
+  x ^= x >> 16;
+  return x >= thr ? inv_keep : 0.f;
+}
+// Two keep decisions per hash word: element (q, key) uses word ((b*H+h)*N + q)*ceil(N/2) + key/2 and
+// its low (key even) or high (key odd) 16 bits, compared against a 16-bit threshold
+// (p_eff = round(p*65536)/65536, e.g. 0.099991 for p = 0.1; inv_keep uses p_eff).
+// The word is a Weyl step (index * golden ratio + seed) through one xorshift-multiply-xorshift round; callers
+// pass the premultiplied index so that neighbouring words cost an add, not a quarter-rate v_mul_lo_u32.
+// (Three multiply rounds per word made the dropout a quarter of the attention kernels' VALU work; on 669 k
+// decisions this form shows the same keep rate, adjacent-element and field-to-field correlations < 0.004.)
+constexpr uint32_t HASH_K = 0x9E3779B1u;
+__device__ __forceinline__ uint32_t pair_hash_pm(uint32_t s0, uint32_t s1, uint32_t idx_times_k) {
+  uint32_t x = idx_times_k + s0;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x ^= s1;
+  return x;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// attention2.hip: the same contract with 32-row workgroups and the long dimension split over their waves
+bool attn2_ok(const AttnP& p);
+int attn2_fwd(const AttnP& p, hipStream_t st);
+int attn2_bwd(const AttnP& p, hipStream_t st);
+
+}  // namespace w2vs

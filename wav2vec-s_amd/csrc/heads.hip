@@ -34,6 +34,7 @@ struct QuantP {
   // backward
   const bf16* dq;       // [R, G*D]
   const bf16* dsoft;    // [R, G*V]  dq . vars^T  (from the GEMM)
+  const float* dsoft32; // the same product as fp32 (preferred: (ds - <soft, ds>) cancels, bf16 ds costs ~5 % there)
   const float* cvec;    // [G*V] d(prob_ppl)/d(avg_prob)
   bf16* dlogits;        // [R, G*V]
   float* dvars;         // [G*V, D] fp32 accumulators
@@ -125,13 +126,13 @@ __global__ __launch_bounds__(256) void quant_kernel(QuantP p) {
     } else {
       // d logits = [softmax-bwd of the straight-through gumbel path] / tau
       //          + ppl_grad/R * p o (c - <p, c>)          (diversity term through avg_probs)
-      const bf16* dsp = p.dsoft + row * (long)(G * V) + (long)g * V;
+      const long dofs = row * (long)(G * V) + (long)g * V;
       float ds[QV_MAX], dot1 = 0.f, dot2 = 0.f;
 #pragma unroll
       for (int j = 0; j < QV_MAX; ++j) {
         int v = lane + 64 * j;
         float soft = p.training ? ys[j] * yinv : 0.f;
-        ds[j] = (v < V && p.training) ? bf2f(dsp[v]) : 0.f;
+        ds[j] = (v < V && p.training) ? (p.dsoft32 ? p.dsoft32[dofs + v] : bf2f(p.dsoft[dofs + v])) : 0.f;
         dot1 += soft * ds[j];
         float pj = ps[j] * inv_se;
         dot2 += (v < V) ? pj * p.cvec[g * V + v] : 0.f;
@@ -215,7 +216,7 @@ static int quant_fill(const QuantDesc& d, QuantP& p) {
   p.logits = (const bf16*)d.logits; p.noise = d.noise; p.vars = (const bf16*)d.vars; p.q = (bf16*)d.q; p.idx = d.idx;
   p.hard_cnt = d.hard_cnt; p.prob_sum = d.prob_sum; p.dq = (const bf16*)d.dq; p.dsoft = (const bf16*)d.dsoft; p.cvec = d.cvec;
   p.dlogits = (bf16*)d.dlogits; p.dvars = d.dvars; p.ppl_grad = d.ppl_grad; p.ppl_dev = d.ppl_grad_dev; p.R = d.R; p.G = d.G; p.V = d.V; p.D = d.D;
-  p.tau = d.tau; p.training = d.training; p.seed = d.seed;
+  p.tau = d.tau; p.training = d.training; p.seed = d.seed; p.dsoft32 = d.dsoft_f32;
   p.logits32 = d.logits_f32; p.lbias = (const bf16*)d.logit_bias;
   if ((!p.logits && !p.logits32) || !p.vars) return set_error("quantizer: null pointer");
   if (p.V > 64 * QV_MAX || p.V < 1) return set_error("quantizer: num_vars per group must be in [1, 320]");
@@ -243,7 +244,7 @@ int quant_bwd(const QuantDesc& d, hipStream_t st) {
   QuantP p{};
   if (int e = quant_fill(d, p)) return e;
   if (!p.dq || !p.cvec || !p.dlogits || !p.dvars || !p.prob_sum) return set_error("quant_bwd: null pointer");
-  if (p.training && !p.dsoft) return set_error("quant_bwd: dsoft required in training mode");
+  if (p.training && !p.dsoft && !p.dsoft32) return set_error("quant_bwd: dsoft required in training mode");
   long rows = (long)p.R * p.G;
   int grid = (int)std::min<long>((rows + 3) / 4, 2048);
   hipLaunchKernelGGL(quant_kernel<true>, dim3(grid), dim3(256), 0, st, p);

@@ -22,6 +22,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s);
 int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s);
 int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s);
 void gemm_tune(int nt_mode, int lc_height, int tn_lc);
+void attn_tune(int variant);
 void prof_enable(int stride);
 int prof_read(int id, double* total_ms, double* total_flops, int* launches);
 long prof_launches(int id);

@@ -535,6 +535,12 @@ def _attn_desc(qkv, o, lse, kpad, H, Tp, m, r, p_drop, seed):
     return d
 
 
+def attn_tune(variant=-1):
+    """1 = attention.hip (128-query workgroups), 2 = attention2.hip (32-row workgroups, waves split the long dimension),
+    -1 = default."""
+    _lib.call("w2vs_attn_tune", variant)
+
+
 def attn_fwd(qkv, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
     """qkv [B, N, 3C] bf16 (q | k | v).  Returns ctx [B, N, C] and lse [B, H, N]."""
     _chk(qkv, BF16, "qkv"); _chk(kpad, torch.uint8, "kpad")
@@ -617,15 +623,16 @@ def quant_bwd(dq, logits, vars2d, st, G, V, tau, training, ppl_grad, dvars_f32, 
     D = vars2d.shape[1]
     dsoft = None
     if training:
-        dsoft = empty((R, G * V), BF16, dq.device)
-        # dsoft[:, g] = dq[:, g] @ vars_g^T : batched over groups through column-offset strides
-        gemm_nt(dq, vars2d, M=R, N=V, K=D, lda=G * D, ldb=D, ldc=G * V, out=dsoft, batch=G, sA=D, sB=V * D, sC=V,
+        dsoft = empty((R, G * V), torch.float32, dq.device)
+        # dsoft[:, g] = dq[:, g] @ vars_g^T : batched over groups through column-offset strides; fp32 out: the softmax
+        # backward subtracts <soft, dsoft> from it, and a bf16 dsoft loses ~5 % of weight_proj's gradient to that cancellation
+        gemm_nt(dq, vars2d, M=R, N=V, K=D, lda=G * D, ldb=D, ldc=G * V, out_f32=dsoft, epi=EPI_F32, batch=G, sA=D, sB=V * D, sC=V,
                 a_bytes=(R * G * D) * 2, b_bytes=V * D * 2, c_elems=R * G * V)
     dlogits = empty((R, G * V), BF16, dq.device)
     d = QuantDesc()
     _quant_logits(d, logits, bias)
     d.noise, d.vars = _p(noise), _p(vars2d)
-    d.prob_sum, d.dq, d.dsoft, d.cvec, d.dlogits, d.dvars = _p(st.prob_sum), _p(dq), _p(dsoft), _p(st.cvec), _p(dlogits), _p(dvars_f32)
+    d.prob_sum, d.dq, d.dsoft_f32, d.cvec, d.dlogits, d.dvars = _p(st.prob_sum), _p(dq), _p(dsoft), _p(st.cvec), _p(dlogits), _p(dvars_f32)
     d.ppl_grad, d.tau, d.R, d.G, d.V, d.D, d.training, d.seed = ppl_grad, tau, R, G, V, D, int(training), seed
     d.ppl_grad_dev = _p(ppl_grad_dev)
     _lib.call("w2vs_quant_bwd", C.byref(d), _stream())
