@@ -118,6 +118,9 @@ def side_workload(name, no_cpu):
     if name == "data":
         import bench_data
         return bench_data.main([], cpu_baseline=None if no_cpu else _cpu_baseline_data)
+    if name == "caat":
+        import bench_caat
+        return bench_caat.main([])
     import bench_rnnt
     return bench_rnnt.main([], cpu_baseline=None if no_cpu else _cpu_baseline_rnnt)
 
@@ -135,7 +138,7 @@ def main():
     ap.add_argument("--update-freq", type=int, default=1,
                     help="micro-batches per optimizer update (BASELINE configs[2] quotes 8); a timed 'step' stays ONE micro-batch "
                          "pass, so K steps = K micro-batches and K / update_freq updates + gradient exchanges")
-    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "stream", "data", "rnnt"],
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "stream", "data", "rnnt", "caat", "large"],
                     help="pretrain (default) = the headline step; stream / data / rnnt = the SURVEY section 8 rows f1 / f3 / f4 "
                          "measurements (tools/bench_*.py) with their CPU baselines attached here")
     args = ap.parse_args()

@@ -160,6 +160,13 @@ typedef struct w2vs_attn_desc {
   float scale; float p_drop; uint64_t seed;
   int32_t Nq;   /* 0 = N.  Otherwise only positions 0..Nq-1 are queries (Nq <= Tp: the main frames); o / lse / dq rows
                  * past Nq are left untouched - used by the last encoder layer, whose right-context outputs are dead */
+  /* Cross ("group prefix") mode, mq > 0: ExpandMultiheadAttention of the CAAT joiner
+   * (rain/layers/attention_transducer.py:642-715 with the group mask of MHAJointNet._gen_group_mask, :810-824).
+   * The Nq queries live in their own buffer q [B, Nq, ldq] (batch stride sbq), rows ordered (group g, target u) with
+   * mq = U targets per group; keys / values k, v [B, N, ld] are the encoder frames (r must be 0, Tp == N).  Query row
+   * qi belongs to group qi / mq and attends the keys < min((qi / mq + 1) * m, N) that kpad does not mark (m = the
+   * joiner's downsample).  o / dout [B, Nq, ldo], lse / delta [B, H, Nq]; dq in the q layout, dk / dv in the k / v layout. */
+  int32_t mq; int64_t ldq, sbq;
 } w2vs_attn_desc;
 int w2vs_attn_fwd(const w2vs_attn_desc* d, void* stream);
 int w2vs_attn_bwd(const w2vs_attn_desc* d, void* stream);
@@ -264,6 +271,9 @@ int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* s
 /* out[i] = in[i] * keep(seed, i) / (1 - p) : nn.Dropout (dropout_features, wav2vec2.py:571);
  * the backward is the same call on the gradient with the same seed. */
 int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* stream);
+/* out[i] = gate[i] > 0 ? x[i] : 0 (bf16): the ReLU of the CAAT joiner's FFN (rain/layers/attention_transducer.py:772) with
+ * gate == x, and its backward with x = d(out), gate = the forward's output. */
+int w2vs_relu_gate(const void* x, const void* gate, void* out, int64_t n, void* stream);
 /* Fused Adam on flat arrays: fairseq Adam (fs/optim/adam.py:205-229: decoupled weight decay,
  * bias-corrected step) + fp32 master / bf16 working copy (fs/optim/fp16_optimizer.py:205-218).
  * g = fp32 gradient arena; effective gradient = g * scale_host * (scale_dev ? *scale_dev : 1).  */

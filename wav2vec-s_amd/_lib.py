@@ -46,7 +46,7 @@ class AttnDesc(C.Structure):
                 ("dout", vp), ("delta", vp), ("dq", vp), ("dk", vp), ("dv", vp),
                 ("ld", i64), ("ldo", i64), ("sb", i64), ("sbo", i64),
                 ("B", i32), ("H", i32), ("N", i32), ("Tp", i32), ("m", i32), ("r", i32), ("head_dim", i32),
-                ("scale", f32), ("p_drop", f32), ("seed", u64), ("Nq", i32)]
+                ("scale", f32), ("p_drop", f32), ("seed", u64), ("Nq", i32), ("mq", i32), ("ldq", i64), ("sbq", i64)]
 
 
 class QuantDesc(C.Structure):
@@ -122,6 +122,7 @@ _SIGS = {
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],
     "w2vs_colsum": [vp, vp, i64, i32, i64, vp],
     "w2vs_dropout": [vp, vp, i64, f32, u64, vp],
+    "w2vs_relu_gate": [vp, vp, vp, i64, vp],
     "w2vs_adam_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp],
     "w2vs_sumsq": [vp, i64, vp, vp],
     "w2vs_clip_scale": [vp, vp, f32, f32, vp, vp],

@@ -80,6 +80,7 @@ int w2vs_attn_tune(int32_t variant) { attn_tune(variant); return 0; }
 int w2vs_transpose_multi(const w2vs_transpose_item* items, int32_t n, void* s) { return transpose_multi(items, n, ST(s)); }
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* s) { return f32_to_bf16(in, out, n, scale, ST(s)); }
 int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* s) { return dropout(in, out, n, p, seed, ST(s)); }
+int w2vs_relu_gate(const void* x, const void* gate, void* out, int64_t n, void* s) { return relu_gate(x, gate, out, n, ST(s)); }
 int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
                    float wd, int32_t step, const float* scale_dev, float scale_host, void* s) {
   return adam_step(p32, p16, m, v, g, n, lr, b1, b2, eps, wd, step, scale_dev, scale_host, ST(s));

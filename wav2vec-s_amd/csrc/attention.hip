@@ -611,12 +611,20 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
   p.ld = d.ld; p.ldo = d.ldo; p.sb = d.sb; p.sbo = d.sbo; p.B = d.B; p.H = d.H; p.N = d.N; p.Tp = d.Tp; p.m = d.m; p.r = d.r;
   p.Nq = d.Nq > 0 ? d.Nq : d.N;
   p.scale = d.scale; p.p_drop = d.p_drop; p.seed = d.seed;
+  p.mq = d.mq; p.ldq = d.mq > 0 ? d.ldq : d.ld; p.sbq = d.mq > 0 ? d.sbq : d.sb; p.Ns = d.mq > 0 ? p.Nq : d.N;
+  if (d.mq < 0) return set_error("attention: mq must be >= 0");
+  if (d.mq > 0) {
+    if (d.r != 0 || d.Tp != d.N) return set_error("attention (cross mode): needs r == 0 and Tp == N");
+    if (d.Nq <= 0 || (p.ldq % 8) || (p.sbq % 8)) return set_error("attention (cross mode): Nq > 0, ldq and sbq multiples of 8");
+    if (!attn2_ok(p) || (p.Nq + 31) / 32 > 512) return set_error("attention (cross mode): too many tiles");
+    if ((long)p.B * p.H * p.Ns * (long)((p.N + 1) / 2) >= (1L << 32)) return set_error("attention: B*H*Nq*N/2 must be < 2^32 (dropout index)");
+  }
   if (!p.q || !p.k || !p.v || !p.o || !p.lse) return set_error("attention: null pointer");
   if (d.head_dim != HD) return set_error("attention: only head_dim 64 is built");
   if (p.B <= 0 || p.H <= 0 || p.N <= 0) return set_error("attention: bad B/H/N");
   if (p.m <= 0 || p.r < 0 || p.Tp <= 0 || p.Tp > p.N) return set_error("attention: bad block structure (m>0, r>=0, 0<Tp<=N)");
   if (p.N != p.Tp + (p.Tp / p.m) * p.r) return set_error("attention: N must equal Tp + (Tp/m)*r");
-  if (p.Nq != p.N && p.Nq > p.Tp) return set_error("attention: Nq must be N (all queries) or <= Tp (main frames only)");
+  if (p.mq == 0 && p.Nq != p.N && p.Nq > p.Tp) return set_error("attention: Nq must be N (all queries) or <= Tp (main frames only)");
   if ((p.ld % 8) || (p.ldo % 8) || (p.sb % 8) || (p.sbo % 8)) return set_error("attention: strides must be multiples of 8 elements");
   if (p.p_drop < 0.f || p.p_drop >= 1.f) return set_error("attention: dropout must be in [0,1)");
   if ((long)p.B * p.H * p.N * (long)((p.N + 1) / 2) >= (1L << 32)) return set_error("attention: B*H*N*N/2 must be < 2^32 (dropout index)");
@@ -629,7 +637,7 @@ void attn_tune(int variant) { g_attn_variant = variant; }
 static bool use_v2(const AttnP& p) {
   static const bool v1 = [] { const char* e = getenv("W2VS_ATTN_V1"); return e && atoi(e) != 0; }();
   const bool want_v1 = g_attn_variant == 1 || (g_attn_variant < 0 && v1);
-  return !want_v1 && attn2_ok(p);
+  return p.mq > 0 || (!want_v1 && attn2_ok(p));
 }
 
 int attn_fwd(const AttnDesc& d, hipStream_t st) {

@@ -35,10 +35,11 @@ struct Attn2P {
 struct SubList { int nM, rc0, nT; };   // sub-tiles [0, nM) then rc0, rc0 + 1, ... : nT in all
 
 // 32-key sub-tiles the queries [q0, q1] can see
-__device__ __host__ inline void key_ranges_h(int q0, int q1, int Tp, int m, int r, int N, int& mlim, int& clo, int& chi, int& full) {
+__device__ __host__ inline void key_ranges_h(int q0, int q1, int Tp, int m, int r, int N, int mq, int& mlim, int& clo, int& chi, int& full) {
   int bmin, bmax;
   bool mixed = false;
-  if (q1 < Tp) { bmin = q0 / m; bmax = q1 / m; }
+  if (mq > 0) { bmin = q0 / mq; bmax = q1 / mq; r = 0; }
+  else if (q1 < Tp) { bmin = q0 / m; bmax = q1 / m; }
   else if (q0 >= Tp) { bmin = r > 0 ? (q0 - Tp) / r : 0; bmax = r > 0 ? (q1 - Tp) / r : 0; }
   else { bmin = 0; bmax = (Tp - 1) / m; mixed = true; }
   mlim = std::min((bmax + 1) * m, Tp);
@@ -47,9 +48,9 @@ __device__ __host__ inline void key_ranges_h(int q0, int q1, int Tp, int m, int 
   full = std::min((bmin + 1) * m, Tp);      // every query of the range sees the main keys below this
   (void)mixed;
 }
-__device__ __host__ inline SubList key_list(int q0, int q1, int Tp, int m, int r, int N, int& full) {
+__device__ __host__ inline SubList key_list(int q0, int q1, int Tp, int m, int r, int N, int mq, int& full) {
   int mlim, clo, chi;
-  key_ranges_h(q0, q1, Tp, m, r, N, mlim, clo, chi, full);
+  key_ranges_h(q0, q1, Tp, m, r, N, mq, mlim, clo, chi, full);
   SubList t;
   t.nM = (mlim + 31) >> 5;
   int lo = std::max(clo >> 5, t.nM), hi = (chi + 31) >> 5;
@@ -59,9 +60,10 @@ __device__ __host__ inline SubList key_list(int q0, int q1, int Tp, int m, int r
   return t;
 }
 // 32-query sub-tiles that can see the keys [k0, k1]; queries are 0..Nq-1 (Nq == N or Nq <= Tp)
-__device__ __host__ inline SubList query_list(int k0, int k1, int Tp, int m, int r, int N, int Nq) {
+__device__ __host__ inline SubList query_list(int k0, int k1, int Tp, int m, int r, int N, int Nq, int mq) {
   int mq0, mq1, rq0, rq1;
-  if (k1 < Tp) { const int bmin = k0 / m; mq0 = bmin * m; mq1 = Tp; rq0 = r > 0 ? Tp + bmin * r : N; rq1 = N; }
+  if (mq > 0) { mq0 = (k0 / m) * mq; mq1 = Nq; rq0 = rq1 = Nq; }
+  else if (k1 < Tp) { const int bmin = k0 / m; mq0 = bmin * m; mq1 = Tp; rq0 = r > 0 ? Tp + bmin * r : N; rq1 = N; }
   else if (k0 >= Tp) {
     const int bmin = (k0 - Tp) / std::max(r, 1), bmax = (k1 - Tp) / std::max(r, 1);
     mq0 = bmin * m; mq1 = std::min((bmax + 1) * m, Tp); rq0 = Tp + bmin * r; rq1 = std::min(Tp + (bmax + 1) * r, N);
@@ -130,24 +132,24 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   const int b = bh / p.H, h = bh % p.H;
   const int N = p.N, Nq = p.Nq;
   const int q0 = qt * 32, q = q0 + r32, qc = min(q, Nq - 1);
-  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* Q = p.q + (long)b * p.sbq + h * HD;
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
   const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
 
   bf16x8 qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Q + (long)qc * p.ld + 16 * s + 8 * hh);
-  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
+  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Q + (long)qc * p.ldq + 16 * s + 8 * hh);
+  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N, p.mq);
   int wfull;
-  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, wfull);
+  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, p.mq, wfull);
   if (kp) wfull = 0;
 
   const float c = p.scale * LOG2E;
   const uint32_t thr = drop_threshold(p.p_drop) >> 16;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
-  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)qc) * Nh;
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)p.Ns + (uint32_t)qc) * Nh;
 
   f32x16 O0, O1;
 #pragma unroll
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
       *(bf16x4*)(orow + 8 * gq + 4 * hh) = v0;
       *(bf16x4*)(orow + 32 + 8 * gq + 4 * hh) = v1;
     }
-    if (hh == 0 && p.lse) p.lse[((long)(b * p.H + h)) * N + q] = ltot > 0.f ? (mall + log2f(ltot)) * LN2 : INFINITY;
+    if (hh == 0 && p.lse) p.lse[((long)(b * p.H + h)) * p.Ns + q] = ltot > 0.f ? (mall + log2f(ltot)) * LN2 : INFINITY;
   }
 }
 
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   const int b = bh / p.H, h = bh % p.H;
   const int N = p.N, Nq = p.Nq;
   const int q0 = qt * 32, q = q0 + r32, qc = min(q, Nq - 1);
-  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* Q = p.q + (long)b * p.sbq + h * HD;
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
   const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
@@ -303,10 +305,10 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   bf16x8 qf[4], dof[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    qf[s] = *(const bf16x8*)(Q + (long)qc * p.ld + 16 * s + 8 * hh);
+    qf[s] = *(const bf16x8*)(Q + (long)qc * p.ldq + 16 * s + 8 * hh);
     dof[s] = *(const bf16x8*)(dO + (long)qc * p.ldo + 16 * s + 8 * hh);
   }
-  const long sidx = ((long)(b * p.H + h)) * N + qc;
+  const long sidx = ((long)(b * p.H + h)) * p.Ns + qc;
   const float lse2 = p.lse[sidx] * LOG2E;
   float delta = 0.f;
   {
@@ -320,16 +322,16 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   }
   delta += other_half(delta);
   if (wid == 0 && q < Nq && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
-  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N);
+  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N, p.mq);
   int wfull;
-  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, wfull);
+  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, p.mq, wfull);
   if (kp) wfull = 0;
   const float c = p.scale * LOG2E;
   const uint32_t thr = drop_threshold(p.p_drop) >> 16;
   const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
-  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)N + (uint32_t)qc) * Nh;
+  const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)p.Ns + (uint32_t)qc) * Nh;
   f32x16 D0, D1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { D0[i] = 0.f; D1[i] = 0.f; }
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { D0[i] += red[w][i][lane]; D1[i] += red[w][16 + i][lane]; }
   if (q < Nq) {
-    bf16* drow_p = p.dq + (long)b * p.sb + (long)q * p.ld + h * HD;
+    bf16* drow_p = p.dq + (long)b * p.sbq + (long)q * p.ldq + h * HD;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       bf16x4 v0, v1;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   bf16* Qw = (bf16*)smem + wid * (2 * 32 * HD);
   bf16* Dw = Qw + 32 * HD;
   float* qs = smem + (NW2 * 2 * 32 * HD) / 2 + wid * 160;       // lse, delta, lim, clo, chi of the sub-tile's 32 queries
-  const bf16* Q = p.q + (long)b * p.sb + h * HD;
+  const bf16* Q = p.q + (long)b * p.sbq + h * HD;
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
   const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
@@ -454,11 +456,11 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
-  const uint32_t dbase = (uint32_t)(b * p.H + h) * (uint32_t)N;
+  const uint32_t dbase = (uint32_t)(b * p.H + h) * (uint32_t)p.Ns;
   const uint32_t khalf = (uint32_t)keyc >> 1, kodd = (uint32_t)keyc & 1u;
   const uint32_t stepK = Nh * HASH_K;
   const bool keys_clean = __all(key_ok);
-  SubList ql = query_list(kb0, min(kb0 + 32, N) - 1, p.Tp, p.m, p.r, N, Nq);
+  SubList ql = query_list(kb0, min(kb0 + 32, N) - 1, p.Tp, p.m, p.r, N, Nq, p.mq);
   const int qm_lo = ql.nM >> 16;
   ql.nM &= 0xFFFF;
   f32x16 dV0, dV1, dK0, dK1;
@@ -472,10 +474,10 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     const int qq = min(t * 32 + r32, Nq - 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      R.q[s] = *(const bf16x8*)(Q + (long)qq * p.ld + 16 * s + 8 * hh);
+      R.q[s] = *(const bf16x8*)(Q + (long)qq * p.ldq + 16 * s + 8 * hh);
       R.d[s] = *(const bf16x8*)(dO + (long)qq * p.ldo + 16 * s + 8 * hh);
     }
-    const long si = (long)(b * p.H + h) * N + qq;
+    const long si = (long)(b * p.H + h) * p.Ns + qq;
     R.sc = hh ? p.delta[si] : p.lse[si] * LOG2E;
   };
   int pos = wid;
@@ -496,12 +498,13 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     int minlim = 0;
     {
       const int qs1 = min(q0 + 32, Nq) - 1;
-      if (qs1 < p.Tp) minlim = min((q0 / p.m + 1) * p.m, p.Tp);
+      if (p.mq > 0) minlim = min((q0 / p.mq + 1) * p.m, p.Tp);
+      else if (qs1 < p.Tp) minlim = min((q0 / p.m + 1) * p.m, p.Tp);
       else if (q0 >= p.Tp && p.r > 0) minlim = min(((q0 - p.Tp) / p.r + 1) * p.m, p.Tp);
     }
     const bool full = keys_clean && q0 + 32 <= Nq && kb0 + 32 <= minlim;
     if (!full && hh == 0) {
-      const QLimits L = q_limits(min(q0 + r32, Nq - 1), p.Tp, p.m, p.r, N);
+      const QLimits L = q_limits(min(q0 + r32, Nq - 1), p.Tp, p.m, p.r, N, p.mq);
       ((int*)qs)[64 + r32] = L.lim; ((int*)qs)[96 + r32] = L.clo; ((int*)qs)[128 + r32] = L.chi;
     }
     f32x16 S, dP;
@@ -621,7 +624,7 @@ int attn2_fwd(const AttnP& p, hipStream_t st) {
   Attn2P pp;
   pp.a = p;
   const int nqt = (p.Nq + 31) / 32;
-  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, f).nT; });
+  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, f).nT; });
   hipLaunchKernelGGL(attn2_fwd_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);
   return hip_check(hipGetLastError(), "attn_fwd");
 }
@@ -630,9 +633,9 @@ int attn2_bwd(const AttnP& p, hipStream_t st) {
   Attn2P pp;
   pp.a = p;
   const int nqt = (p.Nq + 31) / 32, nkt = (p.N + 31) / 32;
-  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, f).nT; });
+  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, f).nT; });
   hipLaunchKernelGGL(attn2_dq_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);     // dq rows >= Nq are not written
-  make_order(pp, nkt, [&](int t) { return query_list(t * 32, std::min(t * 32 + 32, p.N) - 1, p.Tp, p.m, p.r, p.N, p.Nq).nT; });
+  make_order(pp, nkt, [&](int t) { return query_list(t * 32, std::min(t * 32 + 32, p.N) - 1, p.Tp, p.m, p.r, p.N, p.Nq, p.mq).nT; });
   hipLaunchKernelGGL(attn2_dkv_kernel, dim3(nkt * p.B * p.H), dim3(256), 0, st, pp);
   return hip_check(hipGetLastError(), "attn_bwd");
 }

@@ -23,6 +23,10 @@ struct AttnP {
   int B, H, N, Tp, m, r;
   int Nq;                                       // queries are positions 0..Nq-1 (Nq == N, or Nq <= Tp: main frames only)
   float scale; float p_drop; uint64_t seed;
+  // cross mode (mq > 0; attention2.hip only; r == 0, N == Tp): the Nq queries live in their own buffer (row stride ldq,
+  // batch stride sbq), query q belongs to block q / mq and sees the keys < min((q / mq + 1) * m, N) - the group-prefix
+  // attention of the CAAT joiner (rain/layers/attention_transducer.py:642-715, 810-824).  lse / delta are [B, H, Ns].
+  int mq; long ldq, sbq; int Ns;
 };
 
 // LDS image of a [rows][64] bf16 tile read by rows (16-B chunks): XOR swizzle as in gemm.hip
@@ -65,8 +69,9 @@ __device__ __forceinline__ void masked_scores(f32x16& S, float c, const float* k
 }
 
 struct QLimits { int lim, clo, chi; };
-__device__ __forceinline__ QLimits q_limits(int q, int Tp, int m, int r, int N) {
+__device__ __forceinline__ QLimits q_limits(int q, int Tp, int m, int r, int N, int mq = 0) {
   QLimits L;
+  if (mq > 0) { L.lim = min((q / mq + 1) * m, Tp); L.clo = N; L.chi = N; return L; }
   int bq = (q < Tp) ? q / m : (r > 0 ? (q - Tp) / r : 0);
   L.lim = min((bq + 1) * m, Tp);
   L.clo = r > 0 ? Tp + bq * r : N;

@@ -794,6 +794,24 @@ int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream
   return hip_check(hipGetLastError(), "dropout");
 }
 
+// out = gate > 0 ? x : 0.  ReLU of the CAAT joiner's FFN (rain/layers/attention_transducer.py:772, activation_fn "relu"):
+// forward with gate == x, backward with x = d(out) and gate = the forward's output.
+__global__ void relu_gate_kernel(const bf16* x, const bf16* gate, bf16* out, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  const bf16x8 v = *(const bf16x8*)(x + i), g = *(const bf16x8*)(gate + i);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = bf2f(g[e]) > 0.f ? v[e] : f2bf(0.f);
+  *(bf16x8*)(out + i) = o;
+}
+int relu_gate(const void* x, const void* gate, void* out, long n, hipStream_t st) {
+  if (!x || !gate || !out || n <= 0 || (n % 8)) return set_error("relu_gate: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(relu_gate_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, (const bf16*)x, (const bf16*)gate,
+                     (bf16*)out, n);
+  return hip_check(hipGetLastError(), "relu_gate");
+}
+
 // Fused Adam over flat arrays (fs/optim/adam.py:205-229: decoupled weight decay, bias-corrected
 // step size) with the fp32 master / bf16 working copy split of fs/optim/fp16_optimizer.py:205-218.
 // g is the fp32 gradient arena; grad_scale folds the 1/sample_size (and clip) factor in.

@@ -61,6 +61,7 @@ int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t 
 int transpose_multi(const w2vs_transpose_item* items, int n, hipStream_t st);
 int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st);
 int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream_t st);
+int relu_gate(const void* x, const void* gate, void* out, long n, hipStream_t st);
 // data.hip (row f3)
 int batch_by_size(const int64_t* num_tokens, int64_t n, int64_t max_tokens, int64_t max_sentences, int32_t bsz_mult,
                   int32_t* ends, int32_t* n_batches);

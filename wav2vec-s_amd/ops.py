@@ -566,6 +566,48 @@ def attn_bwd(dout, qkv, o, lse, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
     return dqkv
 
 
+def _cross_desc(q, kv, o, lse, kpad, H, m, U, p_drop, seed):
+    B, Nq, Cq = q.shape
+    _, S, C2 = kv.shape
+    Cc = C2 // 2
+    d = AttnDesc()
+    base = kv.data_ptr()
+    d.q, d.k, d.v = _p(q), C.c_void_p(base), C.c_void_p(base + 2 * Cc)
+    d.o, d.lse, d.kpad = _p(o), _p(lse), _p(kpad)
+    d.ld, d.ldo, d.sb, d.sbo = C2, Cc, S * C2, Nq * Cc
+    d.B, d.H, d.N, d.Tp, d.m, d.r, d.head_dim = B, H, S, S, m, 0, Cc // H
+    d.scale, d.p_drop, d.seed = float(Cc // H) ** -0.5, p_drop, seed
+    d.Nq, d.mq, d.ldq, d.sbq = Nq, U, Cq, Nq * Cq
+    return d
+
+
+def group_attn_fwd(q, kv, H, m, U, kpad=None, p_drop=0.0, seed=0):
+    """Group-prefix cross attention (w2vs_attn_desc cross mode): q [B, G*U, C] rows (g, u); kv [B, S, 2C] (k | v); query
+    row (g, u) attends the keys < min((g + 1) * m, S) not marked in kpad [B, S].  Returns ctx [B, G*U, C], lse [B, H, G*U]."""
+    _chk(q, BF16, "q"); _chk(kv, BF16, "kv"); _chk(kpad, torch.uint8, "kpad")
+    B, Nq, Cc = q.shape
+    o = empty((B, Nq, Cc), BF16, q.device)
+    lse = empty((B, H, Nq), torch.float32, q.device)
+    d = _cross_desc(q, kv, o, lse, kpad, H, m, U, p_drop, seed)
+    _lib.call("w2vs_attn_fwd", C.byref(d), _stream())
+    return o, lse
+
+
+def group_attn_bwd(dout, q, kv, o, lse, H, m, U, kpad=None, p_drop=0.0, seed=0):
+    """Returns dq [B, G*U, C] and dkv [B, S, 2C]."""
+    _chk(dout, BF16, "dout"); _chk(q, BF16, "q"); _chk(kv, BF16, "kv"); _chk(o, BF16, "o")
+    B, Nq, Cc = q.shape
+    dq = empty(q.shape, BF16, q.device)
+    dkv = empty(kv.shape, BF16, q.device)
+    delta = empty((B, H, Nq), torch.float32, q.device)
+    d = _cross_desc(q, kv, o, lse, kpad, H, m, U, p_drop, seed)
+    base = dkv.data_ptr()
+    d.dout, d.delta, d.dq = _p(dout), _p(delta), _p(dq)
+    d.dk, d.dv = C.c_void_p(base), C.c_void_p(base + 2 * Cc)
+    _lib.call("w2vs_attn_bwd", C.byref(d), _stream())
+    return dq, dkv
+
+
 # -------------------------------------------------------------------------------------- quantizer
 class QuantState:
     __slots__ = ("idx", "hard_cnt", "prob_sum", "ppl", "cvec")
@@ -687,6 +729,14 @@ def dropout(x, p, seed):
     _chk(x, BF16, "x")
     out = empty(x.shape, x.dtype, x.device)
     _lib.call("w2vs_dropout", _p(x), _p(out), x.numel(), p, seed, _stream())
+    return out
+
+
+def relu_gate(x, gate):
+    """gate > 0 ? x : 0 (bf16).  relu(x) = relu_gate(x, x); its backward = relu_gate(dy, y)."""
+    _chk(x, BF16, "x"); _chk(gate, BF16, "gate")
+    out = empty(x.shape, x.dtype, x.device)
+    _lib.call("w2vs_relu_gate", _p(x), _p(gate), _p(out), x.numel(), _stream())
     return out
 
 
