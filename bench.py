@@ -38,7 +38,7 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(threads):
+def cpu_baseline(threads, large=False):
     """The oracle (a CPU port of the reference algorithm, fp32) timed on the host cores over a bounded
     sample of the same workload: base model, cfgA = 2 x 160 000 samples (20 audio-seconds; BASELINE configs[0], the
     reference's own CPU-runnable case), fwd+loss+bwd.  The restatement / reference time ratio
@@ -47,8 +47,12 @@ def cpu_baseline(threads):
     import w2vs_oracle as O
     torch.set_num_threads(threads)
     cfg = O.OracleCfg()
-    P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
     Bc, Lc = 2, 160000
+    if large:   # wav2vec-S_large_librivox.yaml:52-70; bounded sample: one 10 s utterance
+        cfg = O.OracleCfg(encoder_layers=24, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
+                          layer_norm_first=True, conv_bias=True, feature_grad_mult=1.0, final_dim=768, loss_weights=(0.1, 0.0))
+        Bc, Lc = 1, 160000
+    P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=1).items()}
     g = torch.Generator().manual_seed(1234)
     src = torch.randn(Bc, Lc, generator=g)
     T = O.conv_out_lengths(Lc, cfg.conv_layers)[-1]
@@ -69,7 +73,8 @@ def cpu_baseline(threads):
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
     return {"value": round(Bc * Lc / SR / t, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": "oracle fp32, base model, cfgA 2 x 160000 samples, fwd+loss+bwd, median of 2 after 1 warm-up, %.2f s/step" % t}
+            "sample": "oracle fp32, %s model, %d x %d samples, fwd+loss+bwd, median of 2 after 1 warm-up, %.2f s/step" % (
+                "large" if large else "base", Bc, Lc, t)}
 
 
 def _cpu_baseline_rnnt(acts1, labels1, T, U, gpu_cost):
@@ -142,8 +147,14 @@ def main():
                     help="pretrain (default) = the headline step; stream / data / rnnt = the SURVEY section 8 rows f1 / f3 / f4 "
                          "measurements (tools/bench_*.py) with their CPU baselines attached here")
     args = ap.parse_args()
-    if args.workload != "pretrain":
+    if args.workload not in ("pretrain", "large"):
         return side_workload(args.workload, args.no_cpu_baseline)
+    large = args.workload == "large"
+    if large:        # BASELINE configs[3]: 3 x 320 000 samples per GPU (max_tokens 1.2 M, wav2vec-S_large_librivox.yaml:16-22)
+        if args.batch == B_PER_GPU:
+            args.batch = 3
+        if args.samples == L_SAMPLES:
+            args.samples = 320000
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -165,16 +176,25 @@ def main():
 
     import wav2vec_s_amd as w
     from wav2vec_s_amd import ops, trainer
-    cfg = w.base_librispeech_config()
+    cfg = w.large_librivox_config() if large else w.base_librispeech_config()
     torch.manual_seed(1)                       # identical replicas on every rank
     model = w.Wav2VecSModel(cfg).to(torch.bfloat16).to(dev).train()
-    crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0], log_keys=["prob_perplexity", "code_perplexity", "temp"])
+    crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 0.0] if large else [0.1, 10.0],
+                              log_keys=["prob_perplexity", "code_perplexity", "temp"])
+    # optimizer section of the yamls: adam (0.9, 0.98), eps 1e-6, wd 0.01, polynomial decay from 5e-4 with 5 000 / 32 000 warm-up
+    # updates to max_update 400 000; the large yaml clips the gradient norm at 25 (wav2vec-S_large_librivox.yaml:38-50)
+    sched = trainer.PolynomialDecayLRSchedule(5e-4, warmup_updates=32000 if large else 5000, total_num_update=400000)
+    sched.step_update(100000)                  # a mid-training rate for the synthetic run (update 0 would apply lr = 0)
     step_fn = trainer.TrainStep(model, crit, world_size=max(world, 2) if force_dist else world,
                                 use_optimizer=not args.no_optimizer, update_freq=args.update_freq,
-                                lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+                                lr=sched.current, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
+                                clip_norm=25.0 if large else 0.0, arena_gib=40.0 if large else 12.0)
     B, L = args.batch, args.samples
     g = torch.Generator().manual_seed(1234 + rank)
-    source = torch.randn(B, L, generator=g).to(torch.bfloat16).to(dev)
+    source = torch.randn(B, L, generator=g)
+    if large:                                   # task.normalize: true (raw_audio_dataset.py:69-72)
+        source = torch.nn.functional.layer_norm(source, (L,))
+    source = source.to(torch.bfloat16).to(dev)
     # host RNG streams are seeded IDENTICALLY on every rank, as the reference does (fairseq_cli/train.py:67-68:
     # np.random.seed(seed); utils.set_torch_seed(seed)): same mask lengths, same LayerDrop decisions and same sampled
     # block contexts everywhere - ranks differ in their audio only, so no rank waits for one that dropped fewer layers
@@ -225,7 +245,7 @@ def main():
     # step level: algorithmic FLOPs of the steps actually run / their time / the bf16 MFMA peak
     ach = step_flops / elapsed / 1e12
     roof["step"] = {"flops_per_step": round(step_flops / args.steps / 1e12, 4), "unit": "TFLOP", "achieved_tflops": round(ach, 1),
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "note": "this run's own draws (sampled contexts, LayerDrop 0.05)"}
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "note": "this run's own draws (sampled contexts%s)" % ("" if large else ", LayerDrop 0.05")}
     st_main = model._last_state
     # HBM-side bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     # of this same command (counters cannot be read in-process).  The newest committed summary is quoted only if it was
@@ -260,13 +280,17 @@ def main():
                                                      "achieved_tflops": round(a2, 1), "frac": round(a2 / PEAK_BF16_TFLOPS, 4)}
     st = st_main
     out = {
-        "metric": "audio-seconds/s/GPU, wav2vec-S base pretrain step, 1/2/4/8 MI355X",
+        "metric": "audio-seconds/s/GPU, wav2vec-S %s pretrain step, 1/2/4/8 MI355X" % ("large" if large else "base"),
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "wav2vec-S base (12L d768, 90.3M params) pretrain step: fwd + InfoNCE/diversity/penalty loss + "
-                               "bwd%s%s; %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, LayerDrop 0.05, sampled "
-                               "block contexts; random-init weights; unread rows of the last encoder layer pruned (exact)" % (
+        "config": {"workload": ("wav2vec-S large (24L d1024 pre-LN, 315M params, BASELINE configs[3]) pretrain step: fwd + InfoNCE/"
+                                "diversity loss + bwd%s%s (clip_norm 25); %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, "
+                                "sampled block contexts; random-init weights; unread rows of the last encoder layer pruned (exact)"
+                                if large else
+                                "wav2vec-S base (12L d768, 90.3M params) pretrain step: fwd + InfoNCE/diversity/penalty loss + "
+                                "bwd%s%s; %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, LayerDrop 0.05, sampled "
+                                "block contexts; random-init weights; unread rows of the last encoder layer pruned (exact)") % (
                                    " + RCCL grad all-reduce" if world > 1 else "",
                                    ("" if args.no_optimizer else " + fused Adam") + (
                                        "" if args.update_freq == 1 else " (update_freq %d: exchange + Adam every %d-th step)" % (
@@ -280,7 +304,7 @@ def main():
         out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg runs at N = 1 only
         threads = min(os.cpu_count() or 1, 16)
-        out["cpu_baseline"] = cpu_baseline(threads)
+        out["cpu_baseline"] = cpu_baseline(threads, large)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -175,7 +175,7 @@ int w2vs_attn_bwd(const w2vs_attn_desc* d, void* stream);
 int w2vs_attn_tune(int32_t variant);
 
 /* ---- composite: one post-LN Transformer encoder layer -------------------------------------------
- * TransformerSentenceEncoderLayer.forward (fs/models/wav2vec/wav2vec2.py:955-976) with the fused QKV
+ * TransformerSentenceEncoderLayer.forward (fs/models/wav2vec/wav2vec2.py:932-976: post-LN :955-976, pre-LN :932-953) with the fused QKV
  * projection, block attention, out_proj, dropout+residual+LayerNorm, fc1+GELU, fc2,
  * dropout+residual+LayerNorm enqueued by ONE call (and the whole backward by one more), so the host
  * issues 2 calls per layer.  R = B*N rows.  Saved activations are written by fwd and read by bwd.
@@ -207,6 +207,12 @@ typedef struct w2vs_layer_desc {
   /* optional fourth [R,E] backward scratch: with it (and without sel_idx) layer_bwd keeps every weight-gradient operand
    * alive to the end of the layer and computes the four weight gradients as ONE w2vs_gemm_tn_group launch */
   void* ws_e3;
+  /* pre-LN form (post_ln = 0, wav2vec-S large: layer_norm_first; wav2vec2.py:932-953): x_in = LN(stream_in) as produced by the
+   * previous layer (x_out of this call is the NEXT layer's x_in), ln1_* = this layer's final_layer_norm, ln2_* = the next norm
+   * (next layer's self_attn_layer_norm, or encoder.layer_norm behind the last layer); s1 / s2 are the stream after the
+   * attention / FFN residual.  bwd: d_out = dL/d x_out, d_stream_out = dL/d s2 (NULL behind the last layer),
+   * d_in = dL/d x_in, d_stream_in = dL/d stream_in. */
+  const void* stream_in; const void* d_stream_out; void* d_stream_in;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

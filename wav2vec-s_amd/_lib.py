@@ -77,7 +77,8 @@ class LayerDesc(C.Structure):
                     "g_wqkv", "g_bqkv", "g_wo", "g_bo", "g_ln1_g", "g_ln1_b", "g_w1", "g_b1", "g_w2", "g_b2",
                     "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta",
                     "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64), ("sel_idx", vp), ("n_sel", i32),
-                                                                            ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp), ("ws_e3", vp)])
+                                                                            ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp), ("ws_e3", vp),
+                                                                            ("stream_in", vp), ("d_stream_out", vp), ("d_stream_in", vp)])
 
 
 class CollateDesc(C.Structure):

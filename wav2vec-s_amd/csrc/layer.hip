@@ -7,6 +7,15 @@
 //     a  = out_proj(attn(qkv(x)))            s1 = x + drop(a)      x1 = LN1(s1)
 //     f  = fc2(gelu(fc1(x1)))                s2 = x1 + drop(f)     y  = LN2(s2)
 // (the buffer called hpre holds gelu'(fc1 pre-activation), written by the forward's own erf evaluation)
+//
+// Pre-LN layer (wav2vec-S large, `layer_norm_first`), wav2vec2.py:932-953, on a residual STREAM s whose normalised image
+// n = LN(s) the previous layer (or a standalone LayerNorm for layer 0) has already produced - every "residual add + next
+// LayerNorm" pair is one fused kernel:
+//     a  = out_proj(attn(qkv(n_in)))         s1 = s_in + drop(a)   x1 = LN_final(s1)            [ln1_* = final_layer_norm]
+//     f  = fc2(gelu(fc1(x1)))                s2 = s1 + drop(f)     y  = LN_next(s2)             [ln2_* = the NEXT norm:
+//                                                                     next layer's self_attn_layer_norm / encoder.layer_norm]
+// x_in = n_in, stream_in = s_in; outputs s2 (the stream) and x_out = y (the next layer's n_in).  Backward takes d_out = dL/dy
+// and d_stream_out = dL/ds2 (NULL for the last layer) and returns d_in = dL/dn_in and d_stream_in = dL/ds_in.
 #include "w2vs_internal.h"
 
 namespace w2vs {
@@ -52,7 +61,7 @@ static GemmDesc wgrad_desc(const void* dy, const void* x, float* dw, float* db, 
 static int layer_check(const w2vs_layer_desc& L) {
   if (L.B <= 0 || L.N <= 0 || L.E <= 0 || L.F <= 0 || L.H <= 0) return set_error("layer: bad dims");
   if (L.E % 8 || L.F % 8 || L.E / L.H != 64) return set_error("layer: need E%8==0, F%8==0, head_dim 64");
-  if (!L.post_ln) return set_error("layer: the composite entry covers the post-LN layer; pre-LN runs per kernel");
+  if (!L.post_ln && !L.stream_in) return set_error("layer: the pre-LN form needs stream_in (the residual stream)");
   if (!L.x_in || !L.wqkv || !L.bqkv || !L.wo || !L.bo || !L.w1 || !L.b1 || !L.w2 || !L.b2 || !L.ln1_g || !L.ln1_b ||
       !L.ln2_g || !L.ln2_b)
     return set_error("layer: null weight/input pointer");
@@ -90,10 +99,10 @@ int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
   if (sel) a.Nq = L.n_q;
   TRY(attn_fwd(a, s));
   const void* ctx = L.ctx;
-  const void* xin = L.x_in;
+  const void* xin = L.post_ln ? L.x_in : L.stream_in;      // what the attention branch is added to
   if (sel) {   // only these token rows of the layer output are read downstream (the masked frames)
     TRY(gather_rows(L.ctx, L.sel_idx, L.ctx_sel, Rt, E, 0, s));
-    TRY(gather_rows(L.x_in, L.sel_idx, L.xin_sel, Rt, E, 0, s));
+    TRY(gather_rows(xin, L.sel_idx, L.xin_sel, Rt, E, 0, s));
     ctx = L.ctx_sel; xin = L.xin_sel;
   }
   TRY(lin_fwd(ctx, L.wo, L.bo, L.tmp, nullptr, Rt, E, E, EPI_BIAS, s));
@@ -104,7 +113,7 @@ int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, Rt, F, E, EPI_BIAS_GELU_SAVEG, s));   // hpre <- gelu'(pre)
   TRY(lin_fwd(L.h, L.w2, L.b2, L.tmp, nullptr, Rt, E, F, EPI_BIAS, s));
   LnFwdDesc n2{};
-  n2.x = L.tmp; n2.res = L.x1; n2.gamma = L.ln2_g; n2.beta = L.ln2_b; n2.y = L.x_out; n2.sum_out = L.s2;
+  n2.x = L.tmp; n2.res = L.post_ln ? L.x1 : L.s1; n2.gamma = L.ln2_g; n2.beta = L.ln2_b; n2.y = L.x_out; n2.sum_out = L.s2;
   n2.mean = L.mean2; n2.rstd = L.rstd2; n2.rows = Rt; n2.C = E; n2.p_drop = L.p_drop; n2.seed = L.seed_drop2;
   TRY(ln_fwd(n2, s));
   return 0;
@@ -114,6 +123,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(layer_check(L));
   TRY(sel_check(L));
   const bool pre_t = L.wqkv_t && L.wo_t && L.w1_t && L.w2_t;
+  if (!L.post_ln && !L.d_stream_in) return set_error("layer_bwd: the pre-LN form needs d_stream_in");
   if (!L.d_out || !L.d_in || (!L.wt_scratch && !pre_t) || !L.ws_e0 || !L.ws_e1 || !L.ws_e2 || !L.ws_f || !L.ws_qkv || !L.delta)
     return set_error("layer_bwd: null scratch pointer");
   if (!L.g_wqkv || !L.g_bqkv || !L.g_wo || !L.g_bo || !L.g_w1 || !L.g_b1 || !L.g_w2 || !L.g_b2 || !L.g_ln1_g ||
@@ -126,6 +136,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   // LN2 backward: d_f = ds2 o dropmask (ws_e0), d_x1a = ds2 (ws_e1)
   LnBwdDesc b2{};
   b2.x = L.s2; b2.gamma = L.ln2_g; b2.beta = L.ln2_b; b2.mean = L.mean2; b2.rstd = L.rstd2; b2.dy = L.d_out;
+  if (!L.post_ln) b2.dsum = L.d_stream_out;            // pre-LN: the stream's own gradient joins here (NULL: last layer)
   b2.dx = L.ws_e0; b2.dres = L.ws_e1; b2.dgamma = L.g_ln2_g; b2.dbeta = L.g_ln2_b; b2.rows = Rt; b2.C = E;
   b2.p_drop = L.p_drop; b2.seed = L.seed_drop2; b2.out_scale = 1.f;
   b2.ws = L.ws_f; b2.ws_bytes = (int64_t)R * F * 2;   // ws_f is not live yet: dgamma/dbeta partial slab
@@ -143,11 +154,14 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   // fc1: wgrad, bias, dgrad + residual branch -> d_x1 (ws_e2)
   if (!defer) TRY(lin_wgrad(L.ws_f, L.x1, L.g_w1, L.g_b1, Rt, F, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.w1, L.wt_scratch, F, E, 1, s));           // [F,E] -> [E,F]
-  TRY(lin_dgrad(L.ws_f, pre_t ? L.w1_t : L.wt_scratch, L.ws_e2, L.ws_e1, Rt, F, E, EPI_ADD, s));
-  // LN1 backward: d_a = ds1 o dropmask, d_xin_a = ds1 (ws_e1)
+  // post-LN: x1 feeds fc1 AND the second residual -> add its branch gradient; pre-LN: x1 = LN(s1) feeds fc1 only
+  TRY(lin_dgrad(L.ws_f, pre_t ? L.w1_t : L.wt_scratch, L.ws_e2, L.post_ln ? L.ws_e1 : nullptr, Rt, F, E,
+                L.post_ln ? EPI_ADD : EPI_NONE, s));
+  // LN1 backward: d_a = ds1 o dropmask, d_xin_a = ds1 (ws_e1); pre-LN: ds1 = LNbwd(d_x1) + d_s1 (ws_e1, from LN2's dres)
   LnBwdDesc b1{};
   b1.x = L.s1; b1.gamma = L.ln1_g; b1.beta = L.ln1_b; b1.mean = L.mean1; b1.rstd = L.rstd1; b1.dy = L.ws_e2;
-  b1.dx = d_a; b1.dres = L.ws_e1; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = Rt; b1.C = E;
+  if (!L.post_ln) b1.dsum = L.ws_e1;
+  b1.dx = d_a; b1.dres = (L.post_ln || sel) ? L.ws_e1 : L.d_stream_in; b1.dgamma = L.g_ln1_g; b1.dbeta = L.g_ln1_b; b1.rows = Rt; b1.C = E;
   b1.p_drop = L.p_drop; b1.seed = L.seed_drop1; b1.out_scale = 1.f;
   if (defer) {                                         // ws_f still holds d_hpre: the partial slab goes to the GEMM scratch
     b1.ws = L.tn_ws; b1.ws_bytes = L.tn_ws_bytes;
@@ -169,6 +183,8 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
     TRY(gather_rows(L.ws_e2, L.sel_idx, L.ws_e0, Rt, E, 1, s));     // ws_e0 (d_a) is dead after the out_proj pair
     TRY(gather_rows(L.ws_e1, L.sel_idx, L.ws_f, Rt, E, 1, s));      // ws_f  (d_hpre, LN slab) is dead too
     d_ctx = L.ws_e0; d_res = L.ws_f;
+    if (!L.post_ln && hipMemcpyAsync(L.d_stream_in, L.ws_f, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return set_error("layer_bwd: copy failed");
     // dq rows past n_q are not written by the attention backward: the QKV GEMMs read them
     if (hipMemsetAsync(L.ws_qkv, 0, (size_t)R * 3 * E * 2, s) != hipSuccess) return set_error("layer_bwd: memset failed");
   }
@@ -183,7 +199,9 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   // fused QKV projection
   if (!defer) TRY(lin_wgrad(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wqkv, L.wt_scratch, 3 * E, E, 1, s));     // [3E,E] -> [E,3E]
-  TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, d_res, R, 3 * E, E, EPI_ADD, s));
+  // post-LN: x_in is also the residual -> + d_res; pre-LN: x_in = LN(s_in) feeds the projection only, d_res went to d_stream_in
+  TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, L.post_ln ? d_res : nullptr, R, 3 * E, E,
+                L.post_ln ? EPI_ADD : EPI_NONE, s));
   if (defer) {
     const GemmDesc g[4] = {
         wgrad_desc(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, L.tn_ws, L.tn_ws_bytes),           // fc1   [F,E]

@@ -266,93 +266,84 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     st.layers = []
     x = x0.view(R, E)
     st.x0 = x
-    if post_ln:
-        F = cfg.encoder_ffn_embed_dim
-        nk = len(st.kept)
-        # one bf16 slab and one fp32 slab hold every saved activation of every kept layer
-        per16 = R * (8 * E + 2 * F)
-        slab16 = ops.empty((max(nk, 1) * per16 + R * E,), BF16, dev)
-        per32 = B * H * N + 4 * R
-        slab32 = ops.empty((max(nk, 1) * per32,), torch.float32, dev)
-        st.tmp = slab16[max(nk, 1) * per16:]
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        kpad_ptr = st.kpad.data_ptr() if st.kpad is not None else None
-        use_sel = SELECT_LAST_LAYER and not features_only and "token_idx" in st.up and nk > 0
-        for j, li in enumerate(st.kept):
-            pre = f"encoder.layers.{li}."
-            d = LayerDesc()
-            d.B, d.N, d.E, d.F, d.H, d.Tp, d.m, d.r, d.post_ln, d.num_cu = B, N, E, F, H, Tp, m_ctx, r_ctx, 1, 256
-            d.p_drop, d.p_attn = p_enc, p_att
-            d.seed_attn, d.seed_drop1, d.seed_drop2 = seed(100 + 4 * li), seed(101 + 4 * li), seed(102 + 4 * li)
-            d.kpad = kpad_ptr
-            wqkv, bqkv = _qkv_pack(W, pre)
-            rec = dict(li=li, wqkv=wqkv, bqkv=bqkv)
-            d.wqkv, d.bqkv = wqkv.data_ptr(), bqkv.data_ptr()
-            for f_, n_ in (("wo", "self_attn.out_proj.weight"), ("bo", "self_attn.out_proj.bias"),
-                           ("ln1_g", "self_attn_layer_norm.weight"), ("ln1_b", "self_attn_layer_norm.bias"),
-                           ("w1", "fc1.weight"), ("b1", "fc1.bias"), ("w2", "fc2.weight"), ("b2", "fc2.bias"),
-                           ("ln2_g", "final_layer_norm.weight"), ("ln2_b", "final_layer_norm.bias")):
-                setattr(d, f_, W[pre + n_].data_ptr())
-            base16 = slab16.data_ptr() + 2 * j * per16
-            o = 0
-            for f_, cols in (("qkv", 3 * E), ("ctx", E), ("s1", E), ("x1", E), ("hpre", F), ("h", F), ("s2", E), ("x_out", E)):
-                setattr(d, f_, base16 + 2 * o)
-                o += R * cols
-            base32 = slab32.data_ptr() + 4 * j * per32
-            d.lse = base32
-            d.mean1, d.rstd1 = base32 + 4 * (B * H * N), base32 + 4 * (B * H * N + R)
-            d.mean2, d.rstd2 = base32 + 4 * (B * H * N + 2 * R), base32 + 4 * (B * H * N + 3 * R)
-            d.x_in = x.data_ptr()
-            d.tmp = st.tmp.data_ptr()
-            sel_last = use_sel and j == nk - 1
-            if sel_last:
-                # only the masked frames of the LAST layer's output are ever read (x[mask_indices], wav2vec2.py:590):
-                # everything behind its attention runs on those B*M rows, the attention on the T' main frames
-                RMs = st.up["token_idx"].numel()
-                rec["sel_bufs"] = (ops.empty((RMs, E), BF16, dev), ops.empty((RMs, E), BF16, dev))
-                d.sel_idx, d.n_sel, d.n_q = st.up["token_idx"].data_ptr(), RMs, Tp
-                d.ctx_sel, d.xin_sel = rec["sel_bufs"][0].data_ptr(), rec["sel_bufs"][1].data_ptr()
-            _lib.call("w2vs_layer_fwd", C.byref(d), stream)
-            rec["desc"] = d
-            st.layers.append(rec)
-            x_off = j * per16 + R * (7 * E + 2 * F)
-            x = slab16[x_off: x_off + (RMs if sel_last else R) * E].view(-1, E)
-        st.slabs = (slab16, slab32)
-        st.enc_is_sel = bool(st.layers) and use_sel
-        enc = x
+    F = cfg.encoder_ffn_embed_dim
+    nk = len(st.kept)
+    # one bf16 slab and one fp32 slab hold every saved activation of every kept layer
+    per16 = R * (8 * E + 2 * F)
+    slab16 = ops.empty((max(nk, 1) * per16 + R * E,), BF16, dev)
+    per32 = B * H * N + 4 * R
+    slab32 = ops.empty((max(nk, 1) * per32,), torch.float32, dev)
+    st.tmp = slab16[max(nk, 1) * per16:]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    kpad_ptr = st.kpad.data_ptr() if st.kpad is not None else None
+    use_sel = SELECT_LAST_LAYER and not features_only and "token_idx" in st.up and nk > 0
+    names = [f"encoder.layers.{li}." for li in st.kept]
+    s_stream = None
+    if not post_ln:
+        # pre-LN (wav2vec2.py:932-953): x is the residual stream; every "residual add + next LayerNorm" pair is one fused
+        # kernel inside the composite layer call, so only the FIRST norm runs on its own
+        s_stream = x
+        if nk > 0:
+            x, _, st.n0_mean, st.n0_rstd = ops.ln_fwd(s_stream, W[names[0] + "self_attn_layer_norm.weight"],
+                                                      W[names[0] + "self_attn_layer_norm.bias"])
+    for j, li in enumerate(st.kept):
+        pre = names[j]
+        d = LayerDesc()
+        d.B, d.N, d.E, d.F, d.H, d.Tp, d.m, d.r, d.post_ln, d.num_cu = B, N, E, F, H, Tp, m_ctx, r_ctx, int(post_ln), 256
+        d.p_drop, d.p_attn = p_enc, p_att
+        d.seed_attn, d.seed_drop1, d.seed_drop2 = seed(100 + 4 * li), seed(101 + 4 * li), seed(102 + 4 * li)
+        d.kpad = kpad_ptr
+        wqkv, bqkv = _qkv_pack(W, pre)
+        rec = dict(li=li, wqkv=wqkv, bqkv=bqkv)
+        d.wqkv, d.bqkv = wqkv.data_ptr(), bqkv.data_ptr()
+        if post_ln:
+            norm_a = (pre + "self_attn_layer_norm.weight", pre + "self_attn_layer_norm.bias")
+            norm_b = (pre + "final_layer_norm.weight", pre + "final_layer_norm.bias")
+        else:      # ln1 = the norm between attention and FFN, ln2 = the NEXT norm (include/w2vs.h, pre-LN form)
+            norm_a = (pre + "final_layer_norm.weight", pre + "final_layer_norm.bias")
+            norm_b = ((names[j + 1] + "self_attn_layer_norm.weight", names[j + 1] + "self_attn_layer_norm.bias")
+                      if j + 1 < nk else ("encoder.layer_norm.weight", "encoder.layer_norm.bias"))
+        rec["norm_a"], rec["norm_b"] = norm_a, norm_b
+        for f_, n_ in (("wo", pre + "self_attn.out_proj.weight"), ("bo", pre + "self_attn.out_proj.bias"),
+                       ("ln1_g", norm_a[0]), ("ln1_b", norm_a[1]), ("w1", pre + "fc1.weight"), ("b1", pre + "fc1.bias"),
+                       ("w2", pre + "fc2.weight"), ("b2", pre + "fc2.bias"), ("ln2_g", norm_b[0]), ("ln2_b", norm_b[1])):
+            setattr(d, f_, W[n_].data_ptr())
+        base16 = slab16.data_ptr() + 2 * j * per16
+        o = 0
+        for f_, cols in (("qkv", 3 * E), ("ctx", E), ("s1", E), ("x1", E), ("hpre", F), ("h", F), ("s2", E), ("x_out", E)):
+            setattr(d, f_, base16 + 2 * o)
+            o += R * cols
+        base32 = slab32.data_ptr() + 4 * j * per32
+        d.lse = base32
+        d.mean1, d.rstd1 = base32 + 4 * (B * H * N), base32 + 4 * (B * H * N + R)
+        d.mean2, d.rstd2 = base32 + 4 * (B * H * N + 2 * R), base32 + 4 * (B * H * N + 3 * R)
+        d.x_in = x.data_ptr()
+        if not post_ln:
+            d.stream_in = s_stream.data_ptr()
+        d.tmp = st.tmp.data_ptr()
+        sel_last = use_sel and j == nk - 1
+        if sel_last:
+            # only the masked frames of the LAST layer's output are ever read (x[mask_indices], wav2vec2.py:590):
+            # everything behind its attention runs on those B*M rows, the attention on the T' main frames
+            RMs = st.up["token_idx"].numel()
+            rec["sel_bufs"] = (ops.empty((RMs, E), BF16, dev), ops.empty((RMs, E), BF16, dev))
+            d.sel_idx, d.n_sel, d.n_q = st.up["token_idx"].data_ptr(), RMs, Tp
+            d.ctx_sel, d.xin_sel = rec["sel_bufs"][0].data_ptr(), rec["sel_bufs"][1].data_ptr()
+        _lib.call("w2vs_layer_fwd", C.byref(d), stream)
+        rec["desc"] = d
+        st.layers.append(rec)
+        rows = RMs if sel_last else R
+        x_off = j * per16 + R * (7 * E + 2 * F)
+        x = slab16[x_off: x_off + rows * E].view(-1, E)
+        if not post_ln:
+            s_off = j * per16 + R * (6 * E + 2 * F)
+            s_stream = slab16[s_off: s_off + rows * E].view(-1, E)
+    st.slabs = (slab16, slab32)
+    st.enc_is_sel = bool(st.layers) and use_sel
+    if post_ln or nk > 0:
+        enc = x                            # pre-LN: the last composite call applied encoder.layer_norm (wav2vec2.py:831-832)
     else:
-        # pre-LN: stream s; every "residual add + next LayerNorm" pair is one fused kernel
-        s = x
-        names = [f"encoder.layers.{li}." for li in st.kept]
-        if st.kept:
-            n1, _, mean1, rstd1 = ops.ln_fwd(s, W[names[0] + "self_attn_layer_norm.weight"],
-                                             W[names[0] + "self_attn_layer_norm.bias"])
-        for j, li in enumerate(st.kept):
-            pre = names[j]
-            rec = dict(li=li, s_in=s, n1=n1, mean1=mean1, rstd1=rstd1)
-            wqkv, bqkv = _qkv_pack(W, pre)
-            qkv = ops.linear_fwd(n1, wqkv, bqkv)
-            ctx, lse = ops.attn_fwd(qkv.view(B, N, 3 * E), H, Tp, m_ctx, r_ctx, kpad=st.kpad, p_drop=p_att,
-                                    seed=seed(100 + 4 * li))
-            a = ops.linear_fwd(ctx.view(R, E), W[pre + "self_attn.out_proj.weight"], W[pre + "self_attn.out_proj.bias"])
-            n2, s_mid, mean2, rstd2 = ops.ln_fwd(a, W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
-                                                 res=s, want_sum=True, p_drop=p_enc, seed=seed(101 + 4 * li))
-            h, hpre = ops.linear_fwd(n2, W[pre + "fc1.weight"], W[pre + "fc1.bias"], gelu=True, save_pre=True)
-            f = ops.linear_fwd(h, W[pre + "fc2.weight"], W[pre + "fc2.bias"])
-            if j + 1 < len(st.kept):
-                nxt_w, nxt_b = W[names[j + 1] + "self_attn_layer_norm.weight"], W[names[j + 1] + "self_attn_layer_norm.bias"]
-            else:
-                nxt_w, nxt_b = W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"]
-            n1, s_out, mean1, rstd1 = ops.ln_fwd(f, nxt_w, nxt_b, res=s_mid, want_sum=True, p_drop=p_enc,
-                                                 seed=seed(102 + 4 * li))
-            rec.update(qkv=qkv, ctx=ctx, lse=lse, s_mid=s_mid, n2=n2, mean2=mean2, rstd2=rstd2, h=h, hpre=hpre,
-                       s_out=s_out, mean_o=mean1, rstd_o=rstd1)
-            st.layers.append(rec)
-            s = s_out
-        if st.kept:
-            enc = n1                      # encoder.layer_norm(stream), wav2vec2.py:831-832
-        else:
-            enc, _, st.fin_mean, st.fin_rstd = ops.ln_fwd(s, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"])
+        enc, _, st.fin_mean, st.fin_rstd = ops.ln_fwd(s_stream, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"])
     st.enc = enc                           # [B*N, E]
 
     if features_only:
@@ -531,105 +522,95 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
     ready(milestone_offset(A, "quantizer.") if "quantizer.weight_proj.weight" in A else A.numel)   # heads done
     # ------------------------------------------------------------------ encoder layers, reversed
     post_ln = not cfg.layer_norm_first
-    if post_ln:
-        F = cfg.encoder_ffn_embed_dim
-        dx = d_enc
-        if st.layers:
-            ws = ops.empty((R * (3 * E + F + 3 * E + E) + max(3 * E * E, E * F),), BF16, dev)
-            delta = ops.empty((B * H * N,), torch.float32, dev)
-            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            wp = ws.data_ptr()
-            offs = {}
-            o = 0
-            for f_, n_ in (("ws_e0", R * E), ("ws_e1", R * E), ("ws_e2", R * E), ("ws_f", R * F), ("ws_qkv", R * 3 * E),
-                           ("d_in_a", R * E), ("wt_scratch", max(3 * E * E, E * F))):
-                offs[f_] = wp + 2 * o
-                o += n_
-            d_in_bufs = [offs["d_in_a"], None]
-            e3 = ops.empty((R, E), BF16, dev) if GROUP_WGRADS else None    # fourth [R,E] scratch: grouped weight gradients
-            alt = ops.empty((R, E), BF16, dev)
-            d_in_bufs[1] = alt.data_ptr()
-            cur = dx
-            # every layer's four weights are transposed for the dgrad GEMMs in ONE launch (was 4 launches per layer)
-            per_t = 3 * E * E + E * E + 2 * E * F
-            wt_all = ops.empty((len(st.layers) * per_t,), BF16, dev)
-            items = []
-            for j_, rec in enumerate(st.layers):
-                d = rec["desc"]
-                base = wt_all.data_ptr() + 2 * j_ * per_t
-                d.wqkv_t, d.wo_t = base, base + 2 * 3 * E * E
-                d.w1_t, d.w2_t = base + 2 * 4 * E * E, base + 2 * (4 * E * E + E * F)
-                items += [(d.wqkv, d.wqkv_t, 3 * E, E), (d.wo, d.wo_t, E, E), (d.w1, d.w1_t, F, E), (d.w2, d.w2_t, E, F)]
-            st._dgrad_w = {}
-            for ci_ in range(1, len(cfg.conv_layers)):        # conv dgrad operands ride in the same launch
-                _, ck, cs = cfg.conv_layers[ci_]
-                buf, its = ops.conv_dgrad_weight_items((id(A), ci_), st.packed[ci_], ck, cs)
-                st._dgrad_w[ci_] = buf
-                items += its
-            ops.transpose_multi(items)
-            st._wt_all = wt_all
-            tn_ws = ops.tn_workspace(dev)
-            for rec in st.layers:
-                rec["desc"].tn_ws, rec["desc"].tn_ws_bytes = tn_ws.data_ptr(), tn_ws.numel() * 4
-            for jj, rec in enumerate(reversed(st.layers)):
-                li = rec["li"]
-                pre = f"encoder.layers.{li}."
-                d = rec["desc"]
-                d.d_out = cur.data_ptr()
-                tgt = d_in_bufs[jj & 1]
-                d.d_in = tgt
-                for f_ in ("ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch"):
-                    setattr(d, f_, offs[f_])
-                d.delta = delta.data_ptr()
-                d.ws_e3 = e3.data_ptr() if e3 is not None else None
-                off_w = A.offsets[pre + "self_attn.q_proj.weight"][0]
-                off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
-                fp = A.flat.data_ptr()
-                d.g_wqkv, d.g_bqkv = fp + 4 * off_w, fp + 4 * off_b
-                for f_, n_ in (("g_wo", "self_attn.out_proj.weight"), ("g_bo", "self_attn.out_proj.bias"),
-                               ("g_ln1_g", "self_attn_layer_norm.weight"), ("g_ln1_b", "self_attn_layer_norm.bias"),
-                               ("g_w1", "fc1.weight"), ("g_b1", "fc1.bias"), ("g_w2", "fc2.weight"), ("g_b2", "fc2.bias"),
-                               ("g_ln2_g", "final_layer_norm.weight"), ("g_ln2_b", "final_layer_norm.bias")):
-                    setattr(d, f_, fp + 4 * A.offsets[pre + n_][0])
-                _lib.call("w2vs_layer_bwd", C.byref(d), stream)
-                ready(milestone_offset(A, pre))
-                if jj & 1:
-                    cur = alt
-                else:
-                    cur = ws[(3 * R * E + R * F + 3 * R * E):(3 * R * E + R * F + 3 * R * E) + R * E].view(R, E)
-            dx = cur
-            st._bwd_ws = (ws, alt, delta, e3)
-        d_x0 = dx
-    else:
-        d_s = None
-        d_n = d_enc                        # grad wrt encoder.layer_norm output
-        if not st.layers:
-            d_x0, _ = ops.ln_bwd(st.x0, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], st.fin_mean,
-                                 st.fin_rstd, A.view("encoder.layer_norm.weight"), A.view("encoder.layer_norm.bias"), dy=d_n)
-        names = [f"encoder.layers.{r['li']}." for r in st.layers]
-        for j in range(len(st.layers) - 1, -1, -1):
-            rec = st.layers[j]
+    F = cfg.encoder_ffn_embed_dim
+    dx = d_enc
+    d_stream = None                        # pre-LN: gradient of the residual stream (None behind the last layer)
+    if st.layers:
+        ws = ops.empty((R * (3 * E + F + 3 * E + E) + max(3 * E * E, E * F),), BF16, dev)
+        delta = ops.empty((B * H * N,), torch.float32, dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wp = ws.data_ptr()
+        offs = {}
+        o = 0
+        for f_, n_ in (("ws_e0", R * E), ("ws_e1", R * E), ("ws_e2", R * E), ("ws_f", R * F), ("ws_qkv", R * 3 * E),
+                       ("d_in_a", R * E), ("wt_scratch", max(3 * E * E, E * F))):
+            offs[f_] = wp + 2 * o
+            o += n_
+        d_in_bufs = [offs["d_in_a"], None]
+        e3 = ops.empty((R, E), BF16, dev) if GROUP_WGRADS else None    # fourth [R,E] scratch: grouped weight gradients
+        alt = ops.empty((R, E), BF16, dev)
+        d_in_bufs[1] = alt.data_ptr()
+        ds_bufs = [ops.empty((R, E), BF16, dev), ops.empty((R, E), BF16, dev)] if not post_ln else None
+        cur = dx
+        # every layer's four weights are transposed for the dgrad GEMMs in ONE launch (was 4 launches per layer)
+        per_t = 3 * E * E + E * E + 2 * E * F
+        wt_all = ops.empty((len(st.layers) * per_t,), BF16, dev)
+        items = []
+        for j_, rec in enumerate(st.layers):
+            d = rec["desc"]
+            base = wt_all.data_ptr() + 2 * j_ * per_t
+            d.wqkv_t, d.wo_t = base, base + 2 * 3 * E * E
+            d.w1_t, d.w2_t = base + 2 * 4 * E * E, base + 2 * (4 * E * E + E * F)
+            items += [(d.wqkv, d.wqkv_t, 3 * E, E), (d.wo, d.wo_t, E, E), (d.w1, d.w1_t, F, E), (d.w2, d.w2_t, E, F)]
+        st._dgrad_w = {}
+        for ci_ in range(1, len(cfg.conv_layers)):        # conv dgrad operands ride in the same launch
+            _, ck, cs = cfg.conv_layers[ci_]
+            buf, its = ops.conv_dgrad_weight_items((id(A), ci_), st.packed[ci_], ck, cs)
+            st._dgrad_w[ci_] = buf
+            items += its
+        ops.transpose_multi(items)
+        st._wt_all = wt_all
+        tn_ws = ops.tn_workspace(dev)
+        for rec in st.layers:
+            rec["desc"].tn_ws, rec["desc"].tn_ws_bytes = tn_ws.data_ptr(), tn_ws.numel() * 4
+        for jj, rec in enumerate(reversed(st.layers)):
             li = rec["li"]
-            pre = names[j]
-            if j + 1 < len(st.layers):
-                gw, gb = names[j + 1] + "self_attn_layer_norm.weight", names[j + 1] + "self_attn_layer_norm.bias"
+            pre = f"encoder.layers.{li}."
+            d = rec["desc"]
+            d.d_out = cur.data_ptr()
+            tgt = d_in_bufs[jj & 1]
+            d.d_in = tgt
+            if not post_ln:
+                d.d_stream_out = d_stream.data_ptr() if d_stream is not None else None
+                d.d_stream_in = ds_bufs[jj & 1].data_ptr()
+            for f_ in ("ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch"):
+                setattr(d, f_, offs[f_])
+            d.delta = delta.data_ptr()
+            d.ws_e3 = e3.data_ptr() if e3 is not None else None
+            off_w = A.offsets[pre + "self_attn.q_proj.weight"][0]
+            off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
+            fp = A.flat.data_ptr()
+            d.g_wqkv, d.g_bqkv = fp + 4 * off_w, fp + 4 * off_b
+            na, nb = rec["norm_a"], rec["norm_b"]
+            for f_, n_ in (("g_wo", pre + "self_attn.out_proj.weight"), ("g_bo", pre + "self_attn.out_proj.bias"),
+                           ("g_ln1_g", na[0]), ("g_ln1_b", na[1]), ("g_w1", pre + "fc1.weight"), ("g_b1", pre + "fc1.bias"),
+                           ("g_w2", pre + "fc2.weight"), ("g_b2", pre + "fc2.bias"), ("g_ln2_g", nb[0]), ("g_ln2_b", nb[1])):
+                setattr(d, f_, fp + 4 * A.offsets[n_][0])
+            _lib.call("w2vs_layer_bwd", C.byref(d), stream)
+            # pre-LN: this call also finalised the NEXT norm's gradient (layer li+1's self_attn_layer_norm), so the arena
+            # is final from that layer's start only once this one is done - report one layer late
+            if post_ln:
+                ready(milestone_offset(A, pre))
+            elif jj > 0:
+                ready(milestone_offset(A, f"encoder.layers.{st.layers[len(st.layers) - jj]['li']}."))
+            if jj & 1:
+                cur = alt
             else:
-                gw, gb = "encoder.layer_norm.weight", "encoder.layer_norm.bias"
-            d_f, d_smid = ops.ln_bwd(rec["s_out"], W[gw], W[gb], rec["mean_o"], rec["rstd_o"], A.view(gw), A.view(gb),
-                                     dy=d_n, dsum=d_s, want_dres=True, p_drop=p_enc, seed=seed(102 + 4 * li))
-            d_hpre = _linear_bwd(d_f, rec["h"], pre + "fc2.weight", pre + "fc2.bias", W, A, dgelu_aux=rec["hpre"])
-            d_n2 = _linear_bwd(d_hpre, rec["n2"], pre + "fc1.weight", pre + "fc1.bias", W, A)
-            d_a, d_sin = ops.ln_bwd(rec["s_mid"], W[pre + "final_layer_norm.weight"], W[pre + "final_layer_norm.bias"],
-                                    rec["mean2"], rec["rstd2"], A.view(pre + "final_layer_norm.weight"),
-                                    A.view(pre + "final_layer_norm.bias"), dy=d_n2, dsum=d_smid, want_dres=True,
-                                    p_drop=p_enc, seed=seed(101 + 4 * li))
-            d_n = _attn_block_bwd(st, rec, pre, d_a, rec["n1"], None, A)
-            d_s = d_sin
-        if st.layers:
-            pre = names[0]
-            d_x0, _ = ops.ln_bwd(st.x0, W[pre + "self_attn_layer_norm.weight"], W[pre + "self_attn_layer_norm.bias"],
-                                 st.layers[0]["mean1"], st.layers[0]["rstd1"], A.view(pre + "self_attn_layer_norm.weight"),
-                                 A.view(pre + "self_attn_layer_norm.bias"), dy=d_n, dsum=d_s)
+                cur = ws[(3 * R * E + R * F + 3 * R * E):(3 * R * E + R * F + 3 * R * E) + R * E].view(R, E)
+            if not post_ln:
+                d_stream = ds_bufs[jj & 1]
+        dx = cur
+        st._bwd_ws = (ws, alt, delta, e3, ds_bufs)
+    if post_ln:
+        d_x0 = dx
+    elif st.layers:
+        pre = f"encoder.layers.{st.layers[0]['li']}."
+        d_x0, _ = ops.ln_bwd(st.x0, W[pre + "self_attn_layer_norm.weight"], W[pre + "self_attn_layer_norm.bias"],
+                             st.n0_mean, st.n0_rstd, A.view(pre + "self_attn_layer_norm.weight"),
+                             A.view(pre + "self_attn_layer_norm.bias"), dy=dx, dsum=d_stream)
+    else:
+        d_x0, _ = ops.ln_bwd(st.x0, W["encoder.layer_norm.weight"], W["encoder.layer_norm.bias"], st.fin_mean,
+                             st.fin_rstd, A.view("encoder.layer_norm.weight"), A.view("encoder.layer_norm.bias"), dy=d_enc)
 
     ready(milestone_offset(A, "encoder.layers.0."))
     # ------------------------------------------------------------------ prologue
