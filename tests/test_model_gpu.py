@@ -75,9 +75,12 @@ def _grad_group(n):
     return "enc_misc"        # post_extract_proj, mask_emb, encoder.layer_norm
 
 
-# measured on MI355X (gpurun_out/parity_*.json, round 2): worst relative error per family, base / cfgA / cfgB / large
-GRAD_BARS = {"extractor_conv": 0.06, "extractor_norm": 0.12, "feature_ln": 0.10, "quant_proj": 0.06, "heads": 0.05,
-             "enc_weight": 0.045, "enc_bias": 0.06, "enc_ln": 0.06, "enc_misc": 0.06}
+# Worst relative error per family measured on MI355X in round 2 (gpurun_out/parity_{base,cfgA,cfgB}.json), base model:
+#   enc_misc .025  extractor_conv .046  extractor_norm .030  heads .033  quant_proj .058  enc_weight .029  enc_bias .033
+#   enc_ln .025  feature_ln .061      (large, 24 layers of bf16: x1.4-2.4 of these, hence bar_scale=1.7 there)
+# quant_proj / feature_ln are cancellation-dominated sums (sum of +- terms much larger than the result).  Bars = ~1.8 x.
+GRAD_BARS = {"enc_misc": 0.045, "extractor_conv": 0.08, "extractor_norm": 0.055, "heads": 0.06, "quant_proj": 0.10,
+             "enc_weight": 0.055, "enc_bias": 0.06, "enc_ln": 0.045, "feature_ln": 0.11}
 
 
 def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
@@ -150,6 +153,7 @@ def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
             continue            # analytically zero (softmax shift invariance)
         by[_grad_group(n)] = max(by.get(_grad_group(n), 0.0), e)
     rep["grad_by_group"] = by
+    rep["grad_nonfinite"] = [n for n, e in grads.items() if not np.isfinite(e)]
     rep["grad_median"] = float(np.median(list(grads.values())))
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, f"parity_{tag}.json"), "w") as f:
@@ -164,7 +168,7 @@ def test_base_model_step_matches_oracle():
     assert rep["logits_maxabs"] < 0.08, rep        # logits are cos/0.1 in [-10, 10]; measured 0.022
 
 
-def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, grad=0.08, median=3e-2):
+def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, bar_scale=1.0, median=3e-2):
     assert rep["loss_rel"] < loss, rep
     if loss_free is not None:
         assert rep["loss_rel_unpinned"] < loss_free, rep
@@ -175,9 +179,8 @@ def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, grad=0.08
     # argmaxes sit closer than that and may flip.  Every disagreement must be such a near-tie in the ORACLE's logits.
     assert rep["code_idx_equal"] >= 0.975, rep
     assert rep["code_flip_margin_max"] < 0.03 * rep["code_logit_std"], rep
-    bad = {n: e for n, e in grads.items() if e > grad and "k_proj.bias" not in n}
-    assert not bad, bad
-    over = {g: e for g, e in rep["grad_by_group"].items() if e > GRAD_BARS[g] * (grad / 0.08)}
+    assert not rep["grad_nonfinite"], rep["grad_nonfinite"]
+    over = {g: e for g, e in rep["grad_by_group"].items() if not e <= GRAD_BARS[g] * bar_scale}
     assert not over, (over, rep["grad_worst"])
     assert rep["grad_median"] < median, rep
 
@@ -201,7 +204,7 @@ def test_large_full_width_step_matches_oracle():
     kw = dict(BASE, encoder_layers=24, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
               layer_norm_first=True, conv_bias=True, feature_grad_mult=1.0, final_dim=768)
     rep, grads = _run_both(kw, B=3, L=32000, seed=13, m_ctx=16, r_ctx=8, loss_weights=(0.1, 0.0), tag="large_full")
-    _assert_parity(rep, grads, loss=1e-3, loss_free=1e-3, act=2e-2, grad=0.10, median=4e-2)
+    _assert_parity(rep, grads, loss=1e-3, loss_free=1e-3, act=2e-2, bar_scale=1.7, median=4e-2)
 
 
 def test_large_style_model_step_matches_oracle():
@@ -210,10 +213,7 @@ def test_large_style_model_step_matches_oracle():
               layer_norm_first=True, conv_bias=True, feature_grad_mult=1.0, final_dim=128, latent_vars=40,
               num_negatives=20, conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
     rep, grads = _run_both(kw, B=3, L=16400, seed=2, m_ctx=8, r_ctx=4, loss_weights=(0.1, 0.0), tag="large_style")
-    assert rep["loss_rel"] < 2e-3, rep
-    assert rep["enc_out"] < 2e-2 and rep["features"] < 2e-2, rep
-    bad = {n: e for n, e in grads.items() if e > 0.1 and "k_proj.bias" not in n}
-    assert not bad, bad
+    _assert_parity(rep, grads, loss_free=1e-3)       # measured: loss 5e-5, families <= .032
 
 
 def test_groupnorm_extractor_model_step_matches_oracle():
@@ -222,10 +222,7 @@ def test_groupnorm_extractor_model_step_matches_oracle():
               encoder_attention_heads=2, final_dim=128, latent_vars=40, num_negatives=20,
               conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2")
     rep, grads = _run_both(kw, B=2, L=16000, seed=5, m_ctx=8, r_ctx=4, loss_weights=(0.1, 10.0), tag="groupnorm")
-    assert rep["loss_rel"] < 2e-3, rep
-    assert rep["conv0"] < 1e-2 and rep["enc_out"] < 2e-2, rep
-    bad = {n: e for n, e in grads.items() if e > 0.1 and "k_proj.bias" not in n}
-    assert not bad, bad
+    _assert_parity(rep, grads, loss_free=2e-3)       # measured: families <= .034
 
 
 def test_layerdrop_and_sampled_context_draw_order():

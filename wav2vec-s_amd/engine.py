@@ -286,6 +286,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         if nk > 0:
             x, _, st.n0_mean, st.n0_rstd = ops.ln_fwd(s_stream, W[names[0] + "self_attn_layer_norm.weight"],
                                                       W[names[0] + "self_attn_layer_norm.bias"])
+            st.n0 = x                     # layer 0's descriptor holds the raw pointer: keep the buffer alive for the backward
     for j, li in enumerate(st.kept):
         pre = names[j]
         d = LayerDesc()
