@@ -206,3 +206,20 @@ def test_integration_doc_attn_desc_mirror_matches_library():
     lib = _lib.load()
     assert lib.w2vs_sizeof(4) == C.sizeof(ns["AttnDesc"]) == C.sizeof(_lib.AttnDesc)
     assert [f[0] for f in ns["AttnDesc"]._fields_] == [f[0] for f in _lib.AttnDesc._fields_]
+
+
+def test_criterion_reduce_metrics_known_answers():
+    """fs/criterions/wav2vec_criterion.py:158-212: aggregation keys, weights and rounding (hand-computed)."""
+    import math
+    from wav2vec_s_amd.criterion import Wav2vecCriterion
+    logs = [{"loss": 100.0, "ntokens": 10, "nsentences": 2, "sample_size": 10, "correct": 4, "count": 10.0, "loss_0": 80.0,
+             "loss_1": 20.0, "prob_perplexity": 300.0, "temp": 2.0},
+            {"loss": 60.0, "ntokens": 6, "nsentences": 1, "sample_size": 6, "correct": 3, "count": 6.0, "loss_0": 50.0,
+             "loss_1": 10.0, "prob_perplexity": 320.0, "temp": 2.0}]
+    m = Wav2vecCriterion.reduce_metrics(logs)
+    assert m.get("loss") == round(160.0 / 16 / math.log(2), 3)
+    assert m.get("ntokens") == 16 and m.get("nsentences") == 3
+    assert m.get("accuracy") == round(7 / 16, 5)
+    assert m.get("loss_0") == round(130.0 / 16 / math.log(2), 3) and m.get("loss_1") == round(30.0 / 16 / math.log(2), 3)
+    assert m.get("prob_perplexity") == 310.0 and m.get("temp") == 2.0
+    assert Wav2vecCriterion(infonce=True).logging_outputs_can_be_summed() is False

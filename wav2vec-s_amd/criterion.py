@@ -2,9 +2,42 @@
 InfoNCE configuration wav2vec-S trains with: same constructor arguments, same
 ``forward(model, sample) -> (loss, sample_size, logging_output)`` contract and logging keys.
 The cross entropy and the accuracy counters run in one HIP kernel (w2vs_ce_rows)."""
+import math
+
 import torch
 
 from . import ops
+
+
+class _Meters:
+    """Minimal stand-in for ``fairseq.metrics`` (the logging registry is outside SURVEY section 8): ``log_scalar`` keeps
+    weighted sums, ``log_derived`` a function of them; ``reduce_metrics`` writes into one of these when the caller passes
+    none of its own.  ``get(k)`` = the weighted average (or plain sum for weight 0), as fairseq's AverageMeter reports it."""
+
+    def __init__(self):
+        self.sums, self.weights, self.rounds, self.derived = {}, {}, {}, {}
+
+    def log_scalar(self, key, value, weight=1, round=None, priority=10):
+        self.sums[key] = self.sums.get(key, 0.0) + float(value) * (weight if weight else 1)
+        self.weights[key] = self.weights.get(key, 0.0) + (weight if weight else 0)
+        self.rounds[key] = round
+
+    def log_derived(self, key, fn, priority=20):
+        self.derived[key] = fn
+
+    def get(self, key):
+        if key in self.derived:
+            class _M:          # what the derived lambdas read: meters[k].sum
+                def __init__(s_, v): s_.sum = v
+            return self.derived[key]({k: _M(v) for k, v in self.sums.items()})
+        w = self.weights.get(key, 0.0)
+        v = self.sums[key] / w if w else self.sums[key]
+        r = self.rounds.get(key)
+        return round(v, r) if r is not None else v
+
+
+def _safe_round(x, nd):
+    return round(float(x), nd)
 
 
 class _CrossEntropyTarget0(torch.autograd.Function):
@@ -72,3 +105,35 @@ class Wav2vecCriterion:
             logging_output["correct"] = (out3[1] - out3[2]).detach()
         logging_output["count"] = float(sample_size)
         return loss, sample_size, logging_output
+
+    @staticmethod
+    def reduce_metrics(logging_outputs, metrics=None):
+        """fs/criterions/wav2vec_criterion.py:158-212: aggregate the logging outputs of the data-parallel workers / the
+        micro-batches of an update.  Same keys, weights and rounding; ``metrics`` is any object with fairseq's
+        ``log_scalar`` / ``log_derived`` (``fairseq.metrics`` itself when present) - a private meter set is returned otherwise."""
+        m = metrics if metrics is not None else _Meters()
+        item = lambda v: float(v.item()) if torch.is_tensor(v) else float(v)      # noqa: E731  (utils.item)
+        tot = lambda k: sum(item(log.get(k, 0)) for log in logging_outputs)        # noqa: E731
+        loss_sum, ntokens, nsentences, sample_size = tot("loss"), tot("ntokens"), tot("nsentences"), tot("sample_size")
+        m.log_scalar("loss", loss_sum / (sample_size or 1) / math.log(2), sample_size, round=3)
+        m.log_scalar("ntokens", ntokens)
+        m.log_scalar("nsentences", nsentences)
+        correct, total = tot("correct"), tot("count")
+        m.log_scalar("_correct", correct)
+        m.log_scalar("_total", total)
+        if total > 0:
+            m.log_derived("accuracy", lambda meters: _safe_round(meters["_correct"].sum / meters["_total"].sum, 5)
+                          if meters["_total"].sum > 0 else float("nan"))
+        builtin = {"loss", "ntokens", "nsentences", "sample_size", "correct", "count"}
+        for k in logging_outputs[0]:
+            if k not in builtin:
+                val = tot(k)
+                if k.startswith("loss"):
+                    m.log_scalar(k, val / (sample_size or 1) / math.log(2), sample_size, round=3)
+                else:
+                    m.log_scalar(k, val / len(logging_outputs), round=3)
+        return m
+
+    def logging_outputs_can_be_summed(self) -> bool:
+        """:215-223 returns ``self.xla``; there is no XLA device here."""
+        return False

@@ -383,6 +383,80 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     return st
 
 
+def conv_features(conv_layers, mode, ln_num, W, source):
+    """The extractor alone, forward only (ConvFeatureExtractionModel.forward, wav2vec2.py:773-781): source [B, L] bf16 ->
+    [B, T, C] channel-last post-GELU features.  Same kernels as the training forward."""
+    group_norm = mode == "default"
+    dim0, k0, s0 = conv_layers[0]
+    w0 = W[_pname(0, "0.weight")]
+    if group_norm:
+        x, _ = ops.conv0_gn_fwd(source, w0, W[_pname(0, "2.weight")], W[_pname(0, "2.bias")], k0, s0,
+                                conv_bias=W.get(_pname(0, "0.bias")))
+    else:
+        x, _, _ = ops.conv0_fwd(source, w0, W[_pname(0, "2.1.weight")], W[_pname(0, "2.1.bias")], k0, s0,
+                                conv_bias=W.get(_pname(0, "0.bias")))
+    for i in range(1, len(conv_layers)):
+        _, k, s = conv_layers[i]
+        w2 = ops.conv_pack_weight(W[_pname(i, "0.weight")])
+        bias = W.get(_pname(i, "0.bias"))
+        if not group_norm and i < ln_num:
+            c = ops.conv_cl_fwd(x, w2, k, s, bias, gelu=False, save_pre=False)
+            x, _, _, _ = ops.ln_fwd(c, W[_pname(i, "2.1.weight")], W[_pname(i, "2.1.bias")], gelu=True)
+        else:
+            x = ops.conv_cl_fwd(x, w2, k, s, bias, gelu=True, save_pre=False)
+    return x
+
+
+def single_layer_forward(layer, x, padding_mask=None):
+    """One encoder layer on its own (TransformerSentenceEncoderLayer.forward, wav2vec2.py:921-978): x [T, B, C] ->
+    [T, B, C], full attention (one block of T keys), eval semantics.  One w2vs_layer_fwd call."""
+    T, B, E = x.shape
+    dev = x.device
+    dt = x.dtype
+    par = {n: (p if p.dtype == BF16 else p.to(BF16)).contiguous() for n, p in layer.named_parameters()}
+    H = layer.self_attn.num_heads
+    F = layer.fc1.out_features
+    idx = (torch.arange(B, device=dev, dtype=torch.int32).view(B, 1) + torch.arange(T, device=dev, dtype=torch.int32).view(1, T) * B)
+    xb = ops.gather_rows(x.to(BF16).reshape(T * B, E).contiguous(), idx.reshape(-1).contiguous(), B * T)      # [B*T, E]
+    R = B * T
+    wqkv = torch.cat([par["self_attn.q_proj.weight"], par["self_attn.k_proj.weight"], par["self_attn.v_proj.weight"]], 0)
+    bqkv = torch.cat([par["self_attn.q_proj.bias"], par["self_attn.k_proj.bias"], par["self_attn.v_proj.bias"]], 0)
+    d = LayerDesc()
+    d.B, d.N, d.E, d.F, d.H, d.Tp, d.m, d.r, d.num_cu = B, T, E, F, H, T, T, 0, 256
+    pre_ln = bool(getattr(layer, "layer_norm_first", False))
+    d.post_ln = int(not pre_ln)
+    kp = padding_mask.to(torch.uint8).contiguous() if padding_mask is not None else None
+    d.kpad = kp.data_ptr() if kp is not None else None
+    d.wqkv, d.bqkv = wqkv.data_ptr(), bqkv.data_ptr()
+    ident_g, ident_b = torch.ones(E, dtype=BF16, device=dev), torch.zeros(E, dtype=BF16, device=dev)
+    if pre_ln:      # ln1 = final_layer_norm; the "next norm" does not exist for a lone layer: identity statistics are discarded
+        n_in, _, _, _ = ops.ln_fwd(xb, par["self_attn_layer_norm.weight"], par["self_attn_layer_norm.bias"])
+        la, lb = (par["final_layer_norm.weight"], par["final_layer_norm.bias"]), (ident_g, ident_b)
+        d.x_in, d.stream_in = n_in.data_ptr(), xb.data_ptr()
+    else:
+        la = (par["self_attn_layer_norm.weight"], par["self_attn_layer_norm.bias"])
+        lb = (par["final_layer_norm.weight"], par["final_layer_norm.bias"])
+        d.x_in = xb.data_ptr()
+    for f_, t_ in (("wo", par["self_attn.out_proj.weight"]), ("bo", par["self_attn.out_proj.bias"]), ("ln1_g", la[0]),
+                   ("ln1_b", la[1]), ("w1", par["fc1.weight"]), ("b1", par["fc1.bias"]), ("w2", par["fc2.weight"]),
+                   ("b2", par["fc2.bias"]), ("ln2_g", lb[0]), ("ln2_b", lb[1])):
+        setattr(d, f_, t_.data_ptr())
+    bufs = {}
+    for f_, cols in (("qkv", 3 * E), ("ctx", E), ("s1", E), ("x1", E), ("hpre", F), ("h", F), ("s2", E), ("x_out", E), ("tmp", E)):
+        bufs[f_] = torch.empty(R, cols, dtype=BF16, device=dev)
+        setattr(d, f_, bufs[f_].data_ptr())
+    f32 = torch.empty(B * H * T + 4 * R, dtype=torch.float32, device=dev)
+    base = f32.data_ptr()
+    d.lse = base
+    d.mean1, d.rstd1 = base + 4 * (B * H * T), base + 4 * (B * H * T + R)
+    d.mean2, d.rstd2 = base + 4 * (B * H * T + 2 * R), base + 4 * (B * H * T + 3 * R)
+    _lib.call("w2vs_layer_fwd", C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    out = bufs["s2"] if pre_ln else bufs["x_out"]         # pre-LN: the layer's output is the stream itself
+    res = torch.empty(T * B, E, dtype=BF16, device=dev)
+    ops.gather_rows(out, idx.reshape(-1).contiguous(), B * T, scatter=True, out=res)
+    return res.view(T, B, E).to(dt)
+
+
 # The last encoder layer of a pre-training step computes only what the loss reads (masked frames); tests switch it off
 # to compare the full encoder output.
 SELECT_LAST_LAYER = True

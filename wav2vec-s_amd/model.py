@@ -48,8 +48,16 @@ class ConvFeatureExtractionModel(nn.Module):
             in_d = dim
 
     def forward(self, x):
-        """B x T waveform -> B x C x T' features (inference helper; training goes through the engine)."""
-        raise W2vsError("call the owning Wav2VecSModel: the extractor runs inside the fused HIP step")
+        """fs/models/wav2vec/wav2vec2.py:773-781: B x T waveform -> B x C x T' features, on the HIP kernels (conv0 + LayerNorm /
+        GroupNorm + GELU, conv1-6 as channel-last GEMMs).  Forward only: a training step differentiates the extractor inside
+        the fused path (engine.backward), this entry serves callers that use the module on its own."""
+        if not x.is_cuda:
+            raise W2vsError("ConvFeatureExtractionModel runs on an MI355X only (there is no CPU path)")
+        with torch.no_grad():
+            W = {"feature_extractor.conv_layers." + n: (p if p.dtype == BF16 else p.to(BF16)).contiguous()
+                 for n, p in self.conv_layers.named_parameters()}
+            y = engine.conv_features(self.spec, self.mode, self.layer_norm_num, W, x.to(BF16).contiguous())   # [B, T', C]
+            return ops.transpose2d(y, batch=y.shape[0]).to(x.dtype)                                            # [B, C, T']
 
 
 class _PosHolder(nn.Module):
@@ -72,7 +80,7 @@ class MultiheadAttention(nn.Module):
 
 
 class TransformerSentenceEncoderLayer(nn.Module):
-    """fs/models/wav2vec/wav2vec2.py:874-919 (parameters only)."""
+    """fs/models/wav2vec/wav2vec2.py:874-978.  Parameters, plus a forward for callers that use a layer on its own."""
 
     def __init__(self, embedding_dim=768, ffn_embedding_dim=3072, num_attention_heads=8, dropout=0.1,
                  attention_dropout=0.1, activation_dropout=0.1, activation_fn="relu", layer_norm_first=False):
@@ -82,6 +90,19 @@ class TransformerSentenceEncoderLayer(nn.Module):
         self.fc1 = nn.Linear(embedding_dim, ffn_embedding_dim)
         self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
         self.final_layer_norm = nn.LayerNorm(embedding_dim)
+        self.layer_norm_first = layer_norm_first
+
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_weights=False, att_args=None):
+        """wav2vec2.py:921-978, eval semantics (no dropout), forward only, one composite HIP call (w2vs_layer_fwd).
+        x: T x B x C.  ``self_attn_mask`` must be None (full attention; block masks are the encoder's business and are
+        derived from (T', m, r) there, never materialised); ``self_attn_padding_mask`` B x T bool.  Returns (x, None)."""
+        if self_attn_mask is not None or need_weights:
+            raise W2vsError("TransformerSentenceEncoderLayer.forward: additive masks / attention weights are not built; "
+                            "the block-causal encoder passes (T', m, r) to the attention kernel instead")
+        if not x.is_cuda:
+            raise W2vsError("TransformerSentenceEncoderLayer runs on an MI355X only (there is no CPU path)")
+        with torch.no_grad():
+            return engine.single_layer_forward(self, x, self_attn_padding_mask), None
 
 
 def init_bert_params(module):
@@ -347,7 +368,37 @@ class Wav2Vec2Model(nn.Module):
 
     # ---- the reference's helper methods, same names ------------------------------------------------
     def sample_negatives(self, y, num):
-        raise W2vsError("negatives are gathered inside the fused InfoNCE kernel; use host_rng.sample_negative_indices")
+        """wav2vec2.py:472-526 for the wav2vec-S setting (negatives from the same utterance).  y: B x T x C.  Returns
+        (negs [N_neg, B, T, C], neg_idxs [B, N_neg * T]) like the reference; the training step never calls this - its
+        InfoNCE kernel gathers by index - it exists for callers of the helper."""
+        if self.n_negatives == 0:
+            return y.new(0), None
+        bsz, tsz, fsz = y.shape
+        neg_idxs = host_rng.sample_negative_indices(bsz, num, self.n_negatives)            # same torch.randint draws
+        flat = y.reshape(-1, fsz)
+        if flat.is_cuda and flat.dtype == BF16:
+            negs = ops.gather_rows(flat.contiguous(), neg_idxs.view(-1).to(torch.int32).to(y.device), neg_idxs.numel())
+        else:
+            negs = flat[neg_idxs.view(-1).to(y.device)]
+        negs = negs.view(bsz, num, self.n_negatives, fsz).permute(2, 0, 1, 3)                # to NxBxTxC
+        return negs, neg_idxs
+
+    def quantize(self, x):
+        """wav2vec2.py:660-665: waveform -> (quantized features B x T x vq_dim, code indices B x T x G), eval semantics."""
+        assert self.quantizer is not None
+        if not x.is_cuda:
+            raise W2vsError("quantize runs on an MI355X only (there is no CPU path)")
+        with torch.no_grad():
+            W = {n: (p if p.dtype == BF16 else p.to(BF16)).contiguous() for n, p in self.named_parameters()}
+            y = engine.conv_features(self.cfg.conv_layers, self.cfg.extractor_mode, self.cfg.layer_norm_num, W,
+                                     x.to(BF16).contiguous())                                # [B, T, C0]
+            B, T, C0 = y.shape
+            feats, _, _, _ = ops.ln_fwd(y, W["layer_norm.weight"], W["layer_norm.bias"])
+            G, V = self.cfg.latent_groups, self.cfg.latent_vars
+            logits = ops.linear_fwd_f32(feats.view(B * T, C0), W["quantizer.weight_proj.weight"])
+            q, qst = ops.quant_fwd(logits, W["quantizer.vars"].view(G * V, -1), G, V, 1.0, False,
+                                   bias=W["quantizer.weight_proj.bias"])
+            return q.view(B, T, -1), qst.idx.view(B, T, G).long()
 
     def forward(self, source, padding_mask=None, mask=True, features_only=False):
         if not source.is_cuda:
