@@ -167,12 +167,19 @@ typedef struct w2vs_attn_desc {
    * qi belongs to group qi / mq and attends the keys < min((qi / mq + 1) * m, N) that kpad does not mark (m = the
    * joiner's downsample).  o / dout [B, Nq, ldo], lse / delta [B, H, Nq]; dq in the q layout, dk / dv in the k / v layout. */
   int32_t mq; int64_t ldq, sbq;
+  /* Optional keep-mask store for the attention dropout (32-row kernels only): w2vs_attn_drop_bits_bytes(B, H, N, Nq) bytes.
+   * With p_drop > 0 the forward records its keep decisions there (one bit per visible (query, key) pair, 128 bytes per
+   * 32 x 32 block) and w2vs_attn_bwd, given the same buffer, reads them instead of re-evaluating the counter hash per
+   * score - the same decisions either way; NULL on both calls = recompute.  Scratch owned by the caller between the calls. */
+  void* drop_bits;
 } w2vs_attn_desc;
 int w2vs_attn_fwd(const w2vs_attn_desc* d, void* stream);
 int w2vs_attn_bwd(const w2vs_attn_desc* d, void* stream);
 /* tests / A-B runs: 1 = the 128-query-workgroup kernels (csrc/attention.hip), 2 = the 32-row split kernels (csrc/attention2.hip,
  * default), -1 = default again */
 int w2vs_attn_tune(int32_t variant);
+/* size of w2vs_attn_desc.drop_bits for a call with these dimensions (Nq = 0 means N) */
+int64_t w2vs_attn_drop_bits_bytes(int32_t B, int32_t H, int32_t N, int32_t Nq);
 
 /* ---- composite: one post-LN Transformer encoder layer -------------------------------------------
  * TransformerSentenceEncoderLayer.forward (fs/models/wav2vec/wav2vec2.py:932-976: post-LN :955-976, pre-LN :932-953) with the fused QKV
@@ -213,6 +220,7 @@ typedef struct w2vs_layer_desc {
    * attention / FFN residual.  bwd: d_out = dL/d x_out, d_stream_out = dL/d s2 (NULL behind the last layer),
    * d_in = dL/d x_in, d_stream_in = dL/d stream_in. */
   const void* stream_in; const void* d_stream_out; void* d_stream_in;
+  void* drop_bits;   /* optional: w2vs_attn_desc.drop_bits of this layer's attention (written by fwd, read by bwd) */
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

@@ -323,6 +323,26 @@ def test_block_attention(ops, Tp, m, r, H):
         assert e < 1.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("Tp,m,r,H,nq", [(130, 32, 16, 2, 0), (546, 16, 8, 3, 0), (300, 24, 6, 2, 300)])
+def test_attention_stored_keep_masks_equal_rehash(ops, Tp, m, r, H, nq):
+    """w2vs_attn_desc.drop_bits: the forward parks its dropout decisions as bits, the backward reads them instead of
+    re-hashing - same decisions, so every gradient must equal the recompute path's bit for bit (the formulas are shared)."""
+    B = 2
+    N = Tp + (Tp // m) * r
+    qkv = dev(rnd(B, N, 3 * H * 64, seed=Tp))
+    dout = dev(rnd(B, N, H * 64, seed=9))
+    o1, lse1 = ops.attn_fwd(qkv, H, Tp, m, r, p_drop=0.2, seed=77)
+    g1 = ops.attn_bwd(dout, qkv, o1, lse1, H, Tp, m, r, p_drop=0.2, seed=77)
+    bits = ops.attn_drop_bits(B, H, N)
+    bits.fill_(0x5A5A5A5A)                     # stale garbage must not matter: every block that is read was written
+    o2, lse2 = ops.attn_fwd(qkv, H, Tp, m, r, p_drop=0.2, seed=77, drop_bits=bits)
+    g2 = ops.attn_bwd(dout, qkv, o2, lse2, H, Tp, m, r, p_drop=0.2, seed=77, drop_bits=bits)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    assert torch.equal(g1, g2)
+    g3 = ops.attn_bwd(dout, qkv, o2, lse2, H, Tp, m, r, p_drop=0.2, seed=78, drop_bits=bits)   # the seed is not consulted
+    assert torch.equal(g2, g3)
+
+
 def test_attention_dropout_consistency(ops):
     """fwd and the two bwd passes regenerate the same keep-mask: finite-difference style check
     through linearity in V (O is linear in V for a fixed mask) and dV == P_drop^T dO."""

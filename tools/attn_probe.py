@@ -32,11 +32,12 @@ def run(tag, B, H, Tp, m, r, p):
     E = 64 * H
     qkv = (torch.randn(B, N, 3 * E, device=dev)).to(BF)
     dout = torch.randn(B, N, E, device=dev).to(BF)
-    o, lse = ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=5)
+    bits = ops.attn_drop_bits(B, H, N) if p > 0 else None          # the training step passes the keep-mask store
+    o, lse = ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=5, drop_bits=bits)
     pairs = flops.attention_pairs(Tp, m, r)
     f = 4.0 * pairs * 64 * H * B
-    tf = t_us(lambda: ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=5))
-    tb = t_us(lambda: ops.attn_bwd(dout, qkv, o, lse, H, Tp, m, r, p_drop=p, seed=5))
+    tf = t_us(lambda: ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=5, drop_bits=bits))
+    tb = t_us(lambda: ops.attn_bwd(dout, qkv, o, lse, H, Tp, m, r, p_drop=p, seed=5, drop_bits=bits))
     print("%-34s N=%4d pairs=%7d  fwd %6.1f us (%6.1f TF/s)   bwd(dq+dkv) %6.1f us (%6.1f TF/s)" % (
         tag, N, pairs, tf, f / tf / 1e6, tb, 2.5 * f / tb / 1e6), flush=True)
 

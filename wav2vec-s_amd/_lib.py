@@ -46,7 +46,7 @@ class AttnDesc(C.Structure):
                 ("dout", vp), ("delta", vp), ("dq", vp), ("dk", vp), ("dv", vp),
                 ("ld", i64), ("ldo", i64), ("sb", i64), ("sbo", i64),
                 ("B", i32), ("H", i32), ("N", i32), ("Tp", i32), ("m", i32), ("r", i32), ("head_dim", i32),
-                ("scale", f32), ("p_drop", f32), ("seed", u64), ("Nq", i32), ("mq", i32), ("ldq", i64), ("sbq", i64)]
+                ("scale", f32), ("p_drop", f32), ("seed", u64), ("Nq", i32), ("mq", i32), ("ldq", i64), ("sbq", i64), ("drop_bits", vp)]
 
 
 class QuantDesc(C.Structure):
@@ -78,7 +78,7 @@ class LayerDesc(C.Structure):
                     "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta",
                     "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64), ("sel_idx", vp), ("n_sel", i32),
                                                                             ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp), ("ws_e3", vp),
-                                                                            ("stream_in", vp), ("d_stream_out", vp), ("d_stream_in", vp)])
+                                                                            ("stream_in", vp), ("d_stream_out", vp), ("d_stream_in", vp), ("drop_bits", vp)])
 
 
 class CollateDesc(C.Structure):
@@ -118,6 +118,7 @@ _SIGS = {
     "w2vs_gather_rows": [vp, vp, vp, i64, i32, i32, vp],
     "w2vs_gemm_tune": [i32, i32, i32],
     "w2vs_attn_tune": [i32],
+    "w2vs_attn_drop_bits_bytes": [i32, i32, i32, i32],     # returns a byte count (read through load())
     "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],
     "w2vs_transpose_multi": [vp, i32, vp],
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],

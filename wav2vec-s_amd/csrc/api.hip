@@ -77,6 +77,10 @@ int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, 
 int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* s) { return transpose2d(in, out, R, C, batch, ST(s)); }
 int w2vs_gemm_tune(int32_t nt_mode, int32_t lc_height, int32_t tn_lc) { gemm_tune(nt_mode, lc_height, tn_lc); return 0; }
 int w2vs_attn_tune(int32_t variant) { attn_tune(variant); return 0; }
+int64_t w2vs_attn_drop_bits_bytes(int32_t B, int32_t H, int32_t N, int32_t Nq) {
+  const int64_t nq = ((Nq > 0 ? Nq : N) + 31) / 32, nk = (N + 31) / 32;
+  return (int64_t)B * H * nq * nk * 128;
+}
 int w2vs_transpose_multi(const w2vs_transpose_item* items, int32_t n, void* s) { return transpose_multi(items, n, ST(s)); }
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* s) { return f32_to_bf16(in, out, n, scale, ST(s)); }
 int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* s) { return dropout(in, out, n, p, seed, ST(s)); }

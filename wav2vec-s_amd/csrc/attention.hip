@@ -611,6 +611,7 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
   p.ld = d.ld; p.ldo = d.ldo; p.sb = d.sb; p.sbo = d.sbo; p.B = d.B; p.H = d.H; p.N = d.N; p.Tp = d.Tp; p.m = d.m; p.r = d.r;
   p.Nq = d.Nq > 0 ? d.Nq : d.N;
   p.scale = d.scale; p.p_drop = d.p_drop; p.seed = d.seed;
+  p.drop_bits = (uint32_t*)d.drop_bits;
   p.mq = d.mq; p.ldq = d.mq > 0 ? d.ldq : d.ld; p.sbq = d.mq > 0 ? d.sbq : d.sb; p.Ns = d.mq > 0 ? p.Nq : d.N;
   if (d.mq < 0) return set_error("attention: mq must be >= 0");
   if (d.mq > 0) {

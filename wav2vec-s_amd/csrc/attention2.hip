@@ -115,6 +115,36 @@ __device__ __forceinline__ uint32_t pad_bits(const uint8_t* kp, int k0, int N, i
 
 struct KVRegs { bf16x8 k[4]; u32x4 v[4]; };
 
+// v = mask[lane] ? v : 0 with the 64-bit lane mask in an SGPR pair (one VALU op; the mask comes from a stored ballot)
+__device__ __forceinline__ float keep_by_mask(uint64_t mask, float v) {
+  float r;
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask));
+  return r;
+}
+// lanes L .. L+3 of the result take four wave-uniform values, the other lanes keep `old` (v_writelane_b32).  The values are
+// fresh compare masks: a VALU write of an SGPR / VCC needs wait states before v_writelane may read it, and hipcc does not
+// insert them around inline asm (seen: the records of every second key pair came out stale) - hence the s_nop.
+template <int L>
+__device__ __forceinline__ uint32_t write_lanes4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t old) {
+  asm("s_nop 4\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8"
+      : "+v"(old) : "s"(a), "s"(b), "s"(c), "s"(d), "n"(L), "n"(L + 1), "n"(L + 2), "n"(L + 3));
+  return old;
+}
+// the 32 dwords of a keep-mask record as scalars (two s_load_dwordx16 from a wave-uniform address, waited for here)
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload_record(const uint32_t* ptr, u32x16& a, u32x16& b) {
+  const uint64_t up = (uint64_t)ptr;
+  // readfirstlane returns a SIGNED int: without the uint32_t casts a low word with bit 31 set sign-extends into the high
+  // word and the scalar load faults (it did, address-dependently)
+  const uint64_t sp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(up >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)up);
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b) : "s"(sp) : "memory");
+}
+__device__ __forceinline__ uint32_t* bits_block(const AttnP& p, int bh, int qt, int kt) {
+  return p.drop_bits + ((((long)bh * p.nQT + qt) * p.nKT + kt) << 5);
+}
+
 // =================================================================================================
 // forward
 // =================================================================================================
@@ -215,12 +245,22 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
     lrun += ls;
     if (thr > 0) {      // keep decisions: two per hash word (attn_common.h); 1/(1-p) is applied once, at the end
       const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * HASH_K);
-        S[i] = (hw & 0xFFFFu) >= thr ? S[i] : 0.f;
-        S[i + 1] = (hw >> 16) >= thr ? S[i + 1] : 0.f;
+      uint32_t packed = 0;   // lane j < 32 collects dword j of this block's keep-mask record (AttnP::drop_bits)
+#define W2VS_DROP_PAIR(i)                                                                                              \
+      {                                                                                                                  \
+        const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)((((i) & 3) >> 1) + 4 * ((i) >> 2)) * HASH_K);         \
+        const bool ka = (hw & 0xFFFFu) >= thr, kb = (hw >> 16) >= thr;                                                    \
+        S[i] = ka ? S[i] : 0.f;                                                                                           \
+        S[(i) + 1] = kb ? S[(i) + 1] : 0.f;                                                                               \
+        if (p.drop_bits) { /* the compare results ARE 64-lane masks: park them, one dword per lane */                     \
+          const uint64_t ma = __ballot(ka), mb = __ballot(kb);                                                            \
+          packed = write_lanes4<2 * (i)>((uint32_t)ma, (uint32_t)(ma >> 32), (uint32_t)mb, (uint32_t)(mb >> 32), packed);     \
+        }                                                                                                                 \
       }
+      W2VS_DROP_PAIR(0) W2VS_DROP_PAIR(2) W2VS_DROP_PAIR(4) W2VS_DROP_PAIR(6)
+      W2VS_DROP_PAIR(8) W2VS_DROP_PAIR(10) W2VS_DROP_PAIR(12) W2VS_DROP_PAIR(14)
+#undef W2VS_DROP_PAIR
+      if (p.drop_bits && lane < 32) bits_block(p, bh, qt, k0 >> 5)[lane] = packed;
     }
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -372,16 +412,26 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
       mask_keys(S, hh, L.lim - k0, L.clo - k0, L.chi - k0, pb);
     }
     if (thr > 0) {
-      const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
+      if (p.drop_bits) {   // the forward's decisions, one scalar pair + one v_cndmask per element (no hash)
+        u32x16 ra, rb;
+        sload_record(bits_block(p, bh, qt, k0 >> 5), ra, rb);
 #pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * HASH_K);
-        dP[i] = (hw & 0xFFFFu) >= thr ? dP[i] * inv_keep : 0.f;
-        dP[i + 1] = (hw >> 16) >= thr ? dP[i + 1] * inv_keep : 0.f;
+        for (int i = 0; i < 8; ++i) {
+          dP[i] = keep_by_mask(((uint64_t)ra[2 * i + 1] << 32) | (uint64_t)ra[2 * i], dP[i]);
+          dP[8 + i] = keep_by_mask(((uint64_t)rb[2 * i + 1] << 32) | (uint64_t)rb[2 * i], dP[8 + i]);
+        }
+      } else {
+        const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const uint32_t hw = pair_hash_pm(s0, s1, wbase + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * HASH_K);
+          dP[i] = (hw & 0xFFFFu) >= thr ? dP[i] : 0.f;
+          dP[i + 1] = (hw >> 16) >= thr ? dP[i + 1] : 0.f;
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) S[i] = fast_exp2(fmaf(S[i], c, -lse2)) * (dP[i] - delta);
+    for (int i = 0; i < 16; ++i) S[i] = fast_exp2(fmaf(S[i], c, -lse2)) * fmaf(dP[i], inv_keep, -delta);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -467,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  struct Regs { bf16x8 q[4], d[4]; float sc; };       // sc: lse (lanes < 32) / delta (lanes >= 32) of query q0 + r32
+  struct Regs { bf16x8 q[4], d[4]; float sc; uint32_t bits; };   // sc: lse (lanes < 32) / delta (lanes >= 32) of query q0 + r32
   auto tile_of = [&](int pos) { return pos < ql.nM ? qm_lo + pos : ql.rc0 + (pos - ql.nM); };
   Regs R;
   auto gload = [&](int t) {
@@ -479,6 +529,8 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     }
     const long si = (long)(b * p.H + h) * p.Ns + qq;
     R.sc = hh ? p.delta[si] : p.lse[si] * LOG2E;
+    // this lane's key row of the block's keep-mask record: dword 2i + w with key = (i&3) + 8(i>>2) + 4w
+    R.bits = (p.drop_bits && thr > 0) ? bits_block(p, bh, t, kt)[2 * (r32 & 3) + 8 * (r32 >> 3) + ((r32 >> 2) & 1)] : 0u;
   };
   int pos = wid;
   if (pos < ql.nT) gload(tile_of(pos));
@@ -516,6 +568,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
       dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R.d[s], vf[s], dP, 0, 0, 0);
     }
     asm volatile("" ::: "memory");
+    const uint32_t wbits = R.bits >> (4 * hh);        // bit (i&3) + 8(i>>2) = query row of accumulator element i
     if (nxt < ql.nT) gload(tile_of(nxt));      // one register set: Q / dO fragments are in LDS and in the MFMAs by now
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     const uint32_t wsub = ((dbase + (uint32_t)(q0 + 4 * hh)) * Nh + khalf) * HASH_K;
@@ -542,13 +595,18 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g4 + e;
-        float ks = 1.f;
-        if (thr > 0) {   // word ((dbase + query) * Nh + key / 2): consecutive rows are stepK apart
-          const uint32_t hw = pair_hash_pm(s0, s1, wsub + (uint32_t)(8 * g4 + e) * stepK);
-          ks = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? inv_keep : 0.f;
+        int km = -1;                                   // non-zero = keep
+        if (thr > 0) {
+          if (p.drop_bits) km = (int)(wbits & (1u << ((i & 3) + 8 * (i >> 2))));
+          else {           // word ((dbase + query) * Nh + key / 2): consecutive rows are stepK apart
+            const uint32_t hw = pair_hash_pm(s0, s1, wsub + (uint32_t)(8 * g4 + e) * stepK);
+            km = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? -1 : 0;
+          }
         }
-        Pd[i] = pe[e] * ks;
-        S[i] = pe[e] * (dP[i] * ks - del4[e]);
+        // 1/(1-p) multiplies dV once at the end; inside dS it rides in the fma
+        const bool kp = km != 0;       // (selects, not integer ANDs on the float bits: that form miscompiled dS on ROCm 7.2)
+        Pd[i] = kp ? pe[e] : 0.f;
+        S[i] = pe[e] * fmaf(kp ? dP[i] : 0.f, inv_keep, -del4[e]);
       }
     }
 #pragma unroll
@@ -596,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         a0[e] = f2bf(dK0[4 * gq + e] * p.scale); a1[e] = f2bf(dK1[4 * gq + e] * p.scale);
-        b0[e] = f2bf(dV0[4 * gq + e]); b1[e] = f2bf(dV1[4 * gq + e]);
+        b0[e] = f2bf(dV0[4 * gq + e] * inv_keep); b1[e] = f2bf(dV1[4 * gq + e] * inv_keep);
       }
       *(bf16x4*)(dkr + 8 * gq + 4 * hh) = a0;
       *(bf16x4*)(dkr + 32 + 8 * gq + 4 * hh) = a1;
@@ -623,6 +681,7 @@ bool attn2_ok(const AttnP& p) { return (p.N + 31) / 32 <= MAXT2; }
 int attn2_fwd(const AttnP& p, hipStream_t st) {
   Attn2P pp;
   pp.a = p;
+  pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32;
   make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, f).nT; });
   hipLaunchKernelGGL(attn2_fwd_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);
@@ -632,6 +691,7 @@ int attn2_fwd(const AttnP& p, hipStream_t st) {
 int attn2_bwd(const AttnP& p, hipStream_t st) {
   Attn2P pp;
   pp.a = p;
+  pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32, nkt = (p.N + 31) / 32;
   make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, f).nT; });
   hipLaunchKernelGGL(attn2_dq_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);     // dq rows >= Nq are not written

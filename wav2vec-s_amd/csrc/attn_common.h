@@ -27,6 +27,11 @@ struct AttnP {
   // batch stride sbq), query q belongs to block q / mq and sees the keys < min((q / mq + 1) * m, N) - the group-prefix
   // attention of the CAAT joiner (rain/layers/attention_transducer.py:642-715, 810-824).  lse / delta are [B, H, Ns].
   int mq; long ldq, sbq; int Ns;
+  // optional keep-mask store (attention2.hip): the forward writes the attention-dropout decisions of every visible 32 x 32
+  // (query tile, key tile) block as 32 dwords - dword 2i + w = the 32 query bits of key row (i&3) + 8(i>>2) + 4w, i.e. the
+  // pair (2i, 2i+1) is the 64-lane mask of accumulator element i - and the two backward passes read them back instead of
+  // re-hashing (the hash was 60 % of their VALU work).  [B*H][nQT][nKT][32] uint32.
+  uint32_t* drop_bits; int nQT, nKT;
 };
 
 // LDS image of a [rows][64] bf16 tile read by rows (16-B chunks): XOR swizzle as in gemm.hip

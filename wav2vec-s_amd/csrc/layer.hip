@@ -77,7 +77,7 @@ static void fill_attn(const w2vs_layer_desc& L, AttnDesc& a) {
   a.o = L.ctx; a.lse = L.lse; a.kpad = L.kpad;
   a.ld = 3 * E; a.ldo = E; a.sb = (long)L.N * 3 * E; a.sbo = (long)L.N * E;
   a.B = L.B; a.H = L.H; a.N = L.N; a.Tp = L.Tp; a.m = L.m; a.r = L.r; a.head_dim = 64;
-  a.scale = 0.125f; a.p_drop = L.p_attn; a.seed = L.seed_attn;
+  a.scale = 0.125f; a.p_drop = L.p_attn; a.seed = L.seed_attn; a.drop_bits = L.drop_bits;
 }
 
 static int sel_check(const w2vs_layer_desc& L) {

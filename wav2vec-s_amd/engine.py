@@ -271,7 +271,11 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     # one bf16 slab and one fp32 slab hold every saved activation of every kept layer
     per16 = R * (8 * E + 2 * F)
     slab16 = ops.empty((max(nk, 1) * per16 + R * E,), BF16, dev)
-    per32 = B * H * N + 4 * R
+    # attention-dropout keep masks (w2vs_attn_desc.drop_bits): written by each layer's forward, read by its backward.
+    # OFF by default: measured on MI355X at the cfgB shape the backward gains 3 us per layer (131.7 vs 134.6 us: its two
+    # kernels are latency-, not hash-bound) while the forward pays 5 us for parking the masks (40.9 vs 36.1 us).
+    nbits = B * H * ((N + 31) // 32) ** 2 * 32 if (p_att > 0 and KEEP_MASK_STORE) else 0
+    per32 = B * H * N + 4 * R + nbits
     slab32 = ops.empty((max(nk, 1) * per32,), torch.float32, dev)
     st.tmp = slab16[max(nk, 1) * per16:]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -318,6 +322,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         d.lse = base32
         d.mean1, d.rstd1 = base32 + 4 * (B * H * N), base32 + 4 * (B * H * N + R)
         d.mean2, d.rstd2 = base32 + 4 * (B * H * N + 2 * R), base32 + 4 * (B * H * N + 3 * R)
+        d.drop_bits = base32 + 4 * (B * H * N + 4 * R) if nbits else None
         d.x_in = x.data_ptr()
         if not post_ln:
             d.stream_in = s_stream.data_ptr()
@@ -460,6 +465,8 @@ def single_layer_forward(layer, x, padding_mask=None):
 # The last encoder layer of a pre-training step computes only what the loss reads (masked frames); tests switch it off
 # to compare the full encoder output.
 SELECT_LAST_LAYER = True
+# W2VS_ATTN_KEEP_BITS=1: park the attention-dropout decisions as bits in the forward, read them in the backward
+KEEP_MASK_STORE = os.environ.get("W2VS_ATTN_KEEP_BITS", "0") == "1"
 # the four weight gradients of a post-LN layer as one grouped launch (w2vs_gemm_tn_group); W2VS_GROUP_WGRADS=0 disables
 GROUP_WGRADS = os.environ.get("W2VS_GROUP_WGRADS", "1") != "0"
 

@@ -541,18 +541,26 @@ def attn_tune(variant=-1):
     _lib.call("w2vs_attn_tune", variant)
 
 
-def attn_fwd(qkv, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
+def attn_drop_bits(B, H, N, Nq=0, device="cuda"):
+    """Scratch for the attention-dropout keep masks (w2vs_attn_desc.drop_bits): pass the same tensor to attn_fwd and attn_bwd."""
+    lib = _lib.load()
+    lib.w2vs_attn_drop_bits_bytes.restype = C.c_int64
+    return empty((int(lib.w2vs_attn_drop_bits_bytes(B, H, N, Nq)) // 4,), torch.int32, device)
+
+
+def attn_fwd(qkv, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0, drop_bits=None):
     """qkv [B, N, 3C] bf16 (q | k | v).  Returns ctx [B, N, C] and lse [B, H, N]."""
-    _chk(qkv, BF16, "qkv"); _chk(kpad, torch.uint8, "kpad")
+    _chk(qkv, BF16, "qkv"); _chk(kpad, torch.uint8, "kpad"); _chk(drop_bits, torch.int32, "drop_bits")
     B, N, C3 = qkv.shape
     o = empty((B, N, C3 // 3), BF16, qkv.device)
     lse = empty((B, H, N), torch.float32, qkv.device)
     d = _attn_desc(qkv, o, lse, kpad, H, Tp, m, r, p_drop, seed)
+    d.drop_bits = _p(drop_bits)
     _lib.call("w2vs_attn_fwd", C.byref(d), _stream())
     return o, lse
 
 
-def attn_bwd(dout, qkv, o, lse, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
+def attn_bwd(dout, qkv, o, lse, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0, drop_bits=None):
     _chk(dout, BF16, "dout"); _chk(qkv, BF16, "qkv"); _chk(o, BF16, "o")
     B, N, C3 = qkv.shape
     Cc = C3 // 3
@@ -562,6 +570,7 @@ def attn_bwd(dout, qkv, o, lse, H, Tp, m, r, kpad=None, p_drop=0.0, seed=0):
     base = dqkv.data_ptr()
     d.dout, d.delta = _p(dout), _p(delta)
     d.dq, d.dk, d.dv = C.c_void_p(base), C.c_void_p(base + 2 * Cc), C.c_void_p(base + 4 * Cc)
+    d.drop_bits = _p(drop_bits)
     _lib.call("w2vs_attn_bwd", C.byref(d), _stream())
     return dqkv
 
