@@ -230,3 +230,32 @@ def test_step_arena_is_scoped_to_the_step():
     assert torch.equal(x, keep)
     assert not ops.ARENA.active
     ops.ARENA.deactivate()
+
+
+@pytest.mark.parametrize("update_freq", [1, 2])
+def test_streamed_adam_equals_single_launch(update_freq):
+    """TrainStep(overlap_adam=True) enqueues the Adam update of every gradient range on a side stream as soon as the
+    backward reports it final; the result must equal the one-launch update bit for bit (same kernel, same operands), and the
+    next step must see the updated weights."""
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    res = []
+    for overlap in (False, True):
+        w, cfg, model, crit = _build(SMALL)
+        step = trainer.TrainStep(model, crit, lr=1e-3, update_freq=update_freq, arena_gib=1.0, overlap_adam=overlap)
+        mk = _draws(cfg, B, L, [True, True, False, True])
+        losses = []
+        for _ in range(2 * update_freq):              # two updates: the second forward runs on the updated weights
+            model.inject_draws(mk())
+            losses.append(float(step({"net_input": {"source": src}})))
+        torch.cuda.synchronize()
+        assert step.flat.step == 2
+        res.append((step.flat.p32.clone(), step.flat.m.clone(), step.flat.v.clone(), step.flat.p16.clone(), losses))
+        ops.ARENA.deactivate()
+    (p1, m1, v1, q1, l1), (p2, m2, v2, q2, l2) = res
+    # the first update is bitwise identical; the second differs only through fp32-atomic ordering in the weight gradients
+    assert l1[:update_freq] == l2[:update_freq]
+    assert float((p1.double() - p2.double()).abs().max()) < 2e-5
+    assert float((m1.double() - m2.double()).norm() / m1.double().norm()) < 2e-4
+    assert abs(l1[-1] - l2[-1]) / abs(l1[-1]) < 1e-4

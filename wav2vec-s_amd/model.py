@@ -226,6 +226,8 @@ class _HotPath(torch.autograd.Function):
                             packed=packed)
         ctx.st = st
         ctx.model = model
+        if model._after_forward is not None and not features_only:
+            model._after_forward(st.B * st.M)      # sample_size = number of masked frames: a host integer, known here
         ctx.param_dtypes = [p.dtype for p in params]
         ctx.param_shapes = [tuple(p.shape) for p in params]
         model._last_state = st
@@ -328,6 +330,7 @@ class Wav2Vec2Model(nn.Module):
         self._rng_counter = 0
         self._flat = None                    # trainer.FlatParams when flat storage is active
         self._on_grad_ready = None           # trainer.GradExchange hook: overlap all-reduce with backward
+        self._after_forward = None           # trainer.TrainStep hook: called with sample_size once the forward is enqueued
         self._last_state = None
         self._draws = None
         self.load_pretrained_model(cfg)

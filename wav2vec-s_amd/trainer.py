@@ -94,6 +94,7 @@ class GradExchange:
 
     def __init__(self, flat: torch.Tensor, dist_module, bucket_elems: int = 16 << 20, group=None, flush_at: int = -1):
         self.flat, self.dist, self.bucket, self.group = flat, dist_module, int(bucket_elems), group
+        self.on_launch = None   # optional callback(lo, hi, work): TrainStep chains the optimizer update of a range behind it
         # flush_at: once a milestone reaches this offset, everything pending goes out even if it is less than a bucket.
         # TrainStep sets it to the start of the encoder's parameters: what is final when only the conv extractor's
         # backward (~2 ms) remains then travels DURING that backward, and the collective left for after the backward is
@@ -127,6 +128,8 @@ class GradExchange:
         w = self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.works.append(w)
         self.launched.append((lo, hi))
+        if self.on_launch is not None:
+            self.on_launch(lo, hi, w)
 
     def finish(self):
         """Flush what is left and make the current stream wait for every collective."""
@@ -173,7 +176,8 @@ class TrainStep:
     and ranks inside the fused Adam.  update_freq = 1 (default) is the bench's step."""
 
     def __init__(self, model, criterion, world_size=1, use_optimizer=True, lr=5e-4, betas=(0.9, 0.98), eps=1e-6,
-                 weight_decay=0.01, clip_norm=0.0, arena_gib=12.0, update_freq=1, lr_scheduler=None, group=None):
+                 weight_decay=0.01, clip_norm=0.0, arena_gib=12.0, update_freq=1, lr_scheduler=None, group=None,
+                 overlap_adam=True):
         self.model, self.criterion, self.world = model, criterion, world_size
         self.flat = FlatParams(model)
         self.use_optimizer = use_optimizer
@@ -194,6 +198,12 @@ class TrainStep:
             self.exchange = GradExchange(self.flat.arena.flat, dist, group=group,
                                          flush_at=tail if tail < self.flat.arena.numel else -1)
         dev = self.flat.p16.device
+        # Streamed optimizer: Adam is HBM-bound (30 B per parameter), the backward MFMA-bound.  As soon as a suffix of the
+        # gradient arena is final (and, with N > 1, all-reduced) its Adam update is enqueued on a side stream, under the
+        # rest of the backward.  Not with clip_norm (the norm needs every gradient first) and not for partial updates.
+        self.overlap_adam = bool(overlap_adam) and dev.type == "cuda"
+        self.opt_stream = torch.cuda.Stream(device=dev) if self.overlap_adam else None
+        self._adam = None
         self.norm_buf = torch.zeros(1, device=dev, dtype=torch.float32)
         self.clip_out = torch.zeros(3, device=dev, dtype=torch.float32)   # [grad scale, gnorm, non-finite flag]
         # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB.  It hands out
@@ -227,11 +237,25 @@ class TrainStep:
                 self.exchange.begin_step()
         # only the closing micro-batch reports gradient milestones: earlier ones would all-reduce partial sums
         self.model._on_grad_ready = self.exchange.on_ready if (self.exchange is not None and last) else None
+        streamed = last and self.use_optimizer and self.overlap_adam and not self.clip > 0
+        if streamed:
+            self.model._on_grad_ready = self._ready_streamed
+        self.model._after_forward = (lambda ss: self._begin_streamed_adam(self.ss_acc + ss)) if streamed else None
         loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
-        loss.backward()                           # milestones inside launch the bucketed all-reduces
+        if streamed and self._adam is None:       # a model without the hook: start here (sample_size is a host int)
+            self._begin_streamed_adam(self.ss_acc + sample_size)
+        loss.backward()                           # milestones inside launch the bucketed all-reduces (and Adam ranges)
         self.ss_acc += sample_size
         self.micro = 0 if last else self.micro + 1
         if not last:
+            return loss.detach()
+        if streamed:
+            if self.exchange is not None:
+                self.exchange.finish()            # launches what is left; every launch chains its Adam range
+            self._ready_streamed(0)
+            torch.cuda.current_stream().wait_stream(self.opt_stream)    # the next forward reads the updated bf16 image
+            self.last_lr = self._adam["lr"]
+            self._adam = None
             return loss.detach()
         total = self.ss_acc
         if self.exchange is not None:
@@ -262,3 +286,45 @@ class TrainStep:
                           eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale, scale_dev=scale_dev)
             self.last_lr = lr
         return loss.detach()
+
+    # ---- streamed optimizer -------------------------------------------------------------------------------------
+    def _begin_streamed_adam(self, total_ss):
+        """Called right after the forward of the closing micro-batch: the update's sample_size is known (on the host),
+        so the 1 / sample_size factor - summed over ranks by ONE scalar all-reduce issued before any gradient bucket - and
+        the learning rate are fixed before the first gradient range becomes final."""
+        if self._adam is not None:
+            return
+        f = self.flat
+        lr = self.lr_scheduler.step_update(f.step) if self.lr_scheduler is not None else self.lr
+        f.step += 1
+        st = dict(lr=lr, hi=f.arena.numel, scale=1.0 / float(total_ss), scale_dev=None)
+        if self.exchange is not None:
+            ss = torch.full((1,), float(total_ss), device=f.p16.device, dtype=torch.float32)
+            self.dist.all_reduce(ss, group=self.group)
+            st["scale"], st["scale_dev"] = 1.0, ss.reciprocal_()
+            self.exchange.on_launch = lambda lo, hi, work: self._adam_range(lo, hi, work)
+        self._adam = st
+
+    def _ready_streamed(self, offset):
+        """Backward milestone: arena elements >= offset are final."""
+        if self.exchange is not None:
+            self.exchange.on_ready(offset)        # buckets; each launched bucket calls _adam_range through on_launch
+            return
+        st = self._adam
+        offset = max(0, min(int(offset), st["hi"]))
+        if st["hi"] - offset >= (4 << 20) or offset == 0:      # >= 4 M parameters per launch (a layer is 7 M)
+            self._adam_range(offset, st["hi"], None)
+            st["hi"] = offset
+
+    def _adam_range(self, lo, hi, work):
+        if hi <= lo:
+            return
+        f, st = self.flat, self._adam
+        main = torch.cuda.current_stream()
+        self.opt_stream.wait_stream(main)         # everything that wrote this range was issued on the main stream before now
+        with torch.cuda.stream(self.opt_stream):
+            if work is not None:
+                work.wait()                       # the range's all-reduce (runs on RCCL's stream); blocks opt_stream only
+            ops.adam_step(f.p32[lo:hi], f.p16[lo:hi], f.m[lo:hi], f.v[lo:hi], f.arena.flat[lo:hi], lr=st["lr"],
+                          beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=f.step,
+                          scale_host=st["scale"], scale_dev=st["scale_dev"])
