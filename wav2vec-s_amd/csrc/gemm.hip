@@ -389,7 +389,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcnt(N) needs an immediate
-  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -403,18 +404,22 @@ template <int N> __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcn
 // buffer_load...lds: the issuing wave is stuck ~100+ cycles per 1-KiB piece), and the two hardly overlap while
 // the SAME waves do both.  A loader wave can sit in the issue queue all the time; the consumers never do.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int WM, int MI>   // consumers: WM x 2 waves of (16 MI) x 64; tile (WM * MI * 16) x 128
-__global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) {
-  constexpr int NLOAD = 4, NC = 2 * WM;
-  constexpr int TBM = WM * MI * 16, TBN = 128, NST = 3;
+// WN = 4 (round 2): 160 x 256 tiles for the N = 3072 outputs (fc1 forward, fc2 dgrad): 41 x 12 = 492 workgroups = 1.92 rounds
+// of the 256 CUs where 128 x 128 tiles need 2.44 -> 3, at 98 instead of 64 FLOP per staged byte; three stages of 52 KiB use
+// the whole 160 KiB of LDS, so the bf16 epilogue goes out in two 128-column halves.
+template <int EPI, int WM, int MI, int WN = 2>   // consumers: WM x WN waves of (16 MI) x 64; tile (WM * MI * 16) x (WN * 64)
+__global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) {
+  constexpr int NLOAD = 4, NC = WN * WM;
+  constexpr int TBM = WM * MI * 16, TBN = WN * 64, NST = 3;
   constexpr int A_EL = TBM * BK, B_EL = TBN * BK, STAGE_EL = A_EL + B_EL;   // 48 KiB per stage
   constexpr int NTHR = (NC + NLOAD) * 64;
-  constexpr int APIECES = TBM / 8, LP = (APIECES + 16) / NLOAD;            // pieces per loader wave and stage
-  static_assert((APIECES + 16) % NLOAD == 0, "pieces must divide over the loaders");
-  __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];         // 144 KiB; the epilogue reuses it
+  constexpr int APIECES = TBM / 8, BPIECES = TBN / 8, LP = (APIECES + BPIECES) / NLOAD;   // pieces per loader wave and stage
+  static_assert((APIECES + BPIECES) % NLOAD == 0, "pieces must divide over the loaders");
+  static_assert(NST * STAGE_EL * 2 <= 160 * 1024, "three stages must fit the 160 KiB of LDS");
+  __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];         // 144 KiB (156 KiB at WN = 4); the epilogue reuses it
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool loader = wid >= NC;
-  const int wm = (wid >> 1) % WM, wn = wid & 1;
+  const int wm = (wid / WN) % WM, wn = wid % WN;
   int tm_, tn_;
   tile_order(blockIdx.y * gridDim.x + blockIdx.x, gridDim.y, gridDim.x, 4, tm_, tn_);
   const int m0 = tm_ * TBM, n0 = tn_ * TBN;
@@ -520,56 +525,60 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p) 
   constexpr int CP = 136;
   bf16* st = lds;                 // TBM * 136 * 2 bytes (69632 for 256 rows)
   bf16* st2 = lds + TBM * CP;     // pre-activation tile
-  if (!loader) {
+#pragma unroll 1
+  for (int half = 0; half < WN / 2; ++half) {      // 128 output columns per pass through the staging tile(s)
+    if (half > 0) __syncthreads();
+    if (!loader && (wn >> 1) == half) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int col = n0 + wn * 64 + j * 16 + fr;
-      float bv = 0.f;
-      if (epi_has_bias(EPI))
-        if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
+      for (int j = 0; j < 4; ++j) {
+        int col = n0 + wn * 64 + j * 16 + fr;
+        float bv = 0.f;
+        if (epi_has_bias(EPI))
+          if (p.bias != nullptr && col < p.N) bv = bf2f(p.bias[col]);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int lr = wm * (MI * 16) + i * 16 + fq * 4 + r, lc = wn * 64 + j * 16 + fr;
-          float v = acc[i][j][r] + bv;
-          if (epi_is_gelu(EPI)) {
-            bf16 pre = f2bf(v);
-            if (epi_is_save(EPI)) v = bf2f(pre);  // the activation is taken of the value that is actually saved
-            float gv, dv;
-            gelu_pair(v, gv, dv);
-            if (EPI == EPI_BIAS_GELU_SAVEG) pre = f2bf(dv);
-            if (epi_is_save(EPI)) st2[lr * CP + lc] = pre;
-            v = gv;
+          for (int r = 0; r < 4; ++r) {
+            int lr = wm * (MI * 16) + i * 16 + fq * 4 + r, lc = (wn & 1) * 64 + j * 16 + fr;
+            float v = acc[i][j][r] + bv;
+            if (epi_is_gelu(EPI)) {
+              bf16 pre = f2bf(v);
+              if (epi_is_save(EPI)) v = bf2f(pre);  // the activation is taken of the value that is actually saved
+              float gv, dv;
+              gelu_pair(v, gv, dv);
+              if (EPI == EPI_BIAS_GELU_SAVEG) pre = f2bf(dv);
+              if (epi_is_save(EPI)) st2[lr * CP + lc] = pre;
+              v = gv;
+            }
+            st[lr * CP + lc] = f2bf(v);
           }
-          st[lr * CP + lc] = f2bf(v);
-        }
+      }
     }
-  }
-  __syncthreads();
-  // 256 rows x 16 chunks of 16 B = 4096 chunks over all threads
-  for (int c = tid; c < TBM * 16; c += NTHR) {
-    int lr = c >> 4, cc = c & 15;
-    int row = m0 + lr, col = n0 + cc * 8;
-    long o = (long)row * p.ldc + col;
-    if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
-      if (epi_is_dact(EPI)) {
-        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
-        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
-        bf16x8 outv;
+    __syncthreads();
+    // TBM rows x 16 chunks of 16 B over all threads
+    for (int c = tid; c < TBM * 16; c += NTHR) {
+      int lr = c >> 4, cc = c & 15;
+      int row = m0 + lr, col = n0 + half * 128 + cc * 8;
+      long o = (long)row * p.ldc + col;
+      if (row < p.M && col < p.N && o + 8 <= p.c_elems) {
+        if (epi_is_dact(EPI)) {
+          bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+          bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+          bf16x8 outv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
-        *(bf16x8*)(Cb + o) = outv;
-      } else if (EPI == EPI_ADD) {
-        bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
-        bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
-        bf16x8 outv;
+          for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
+          *(bf16x8*)(Cb + o) = outv;
+        } else if (EPI == EPI_ADD) {
+          bf16x8 g = *(const bf16x8*)(st + lr * CP + cc * 8);
+          bf16x8 a = *(const bf16x8*)(p.aux + (long)bz * p.sC + o);
+          bf16x8 outv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) + bf2f(a[e]));
-        *(bf16x8*)(Cb + o) = outv;
-      } else {
-        *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
-        if (epi_is_save(EPI)) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+          for (int e = 0; e < 8; ++e) outv[e] = f2bf(bf2f(g[e]) + bf2f(a[e]));
+          *(bf16x8*)(Cb + o) = outv;
+        } else {
+          *(u32x4*)(Cb + o) = *(const u32x4*)(st + lr * CP + cc * 8);
+          if (epi_is_save(EPI)) *(u32x4*)(p.C2 + (long)bz * p.sC + o) = *(const u32x4*)(st2 + lr * CP + cc * 8);
+        }
       }
     }
   }
@@ -602,17 +611,18 @@ struct TileIter {   // tiles of one workgroup, in XCD-aware order: round r cover
   }
 };
 
-template <int EPI, int WM, int MI>
-__global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, int ntm, int ntn, int total_tiles) {
-  constexpr int NLOAD = 4, NC = 2 * WM;
-  constexpr int TBM = WM * MI * 16, TBN = 128, NST = 3;
+template <int EPI, int WM, int MI, int WN = 2>     // WN = 4: (WM * MI * 16) x 256 tiles (round 2, the N = 3072 / 2304 encoder outputs)
+__global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, int ntm, int ntn, int total_tiles) {
+  constexpr int NLOAD = 4, NC = WN * WM;
+  constexpr int TBM = WM * MI * 16, TBN = WN * 64, NST = 3;
   constexpr int A_EL = TBM * BK, B_EL = TBN * BK, STAGE_EL = A_EL + B_EL;
-  constexpr int APIECES = TBM / 8, LP = (APIECES + 16) / NLOAD;
-  static_assert((APIECES + 16) % NLOAD == 0, "pieces must divide over the loaders");
+  constexpr int APIECES = TBM / 8, BPIECES = TBN / 8, LP = (APIECES + BPIECES) / NLOAD;
+  static_assert((APIECES + BPIECES) % NLOAD == 0, "pieces must divide over the loaders");
+  static_assert(NST * STAGE_EL * 2 <= 160 * 1024, "three stages must fit the 160 KiB of LDS");
   __shared__ __attribute__((aligned(16))) bf16 lds[NST * STAGE_EL];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool loader = wid >= NC;
-  const int wm = (wid >> 1) % WM, wn = wid & 1;
+  const int wm = (wid / WN) % WM, wn = wid % WN;
   const int nk = (p.K + BK - 1) / BK;
   TileIter it;
   it.G = gridDim.x; it.total = total_tiles; it.ntm = ntm; it.ntn = ntn;
@@ -653,7 +663,7 @@ __global__ __launch_bounds__((2 * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, i
           // B rows are stored PERMUTED: LDS row (w*64 + jj*16 + f) <- B row w*64 + (jj>>1)*32 + (f>>2)*8 + (jj&1)*4 + (f&3),
           // so that a consumer lane ends up with 8 consecutive output columns in the accumulators of tiles 2u, 2u+1
           const int f = row & 15, jj = (row >> 4) & 3;
-          const int srow = (row & 64) + (jj >> 1) * 32 + (f >> 2) * 8 + (jj & 1) * 4 + (f & 3);
+          const int srow = (row & ~63) + (jj >> 1) * 32 + (f >> 2) * 8 + (jj & 1) * 4 + (f & 3);
           d_ok[j] = live && n0 + srow < p.N;
           d_off[j] = (uint32_t)(((long)(n0 + srow) * p.ldb + c * 8) * 2);
         }
@@ -1242,7 +1252,25 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   const bool p_ok = (d.N % 8) == 0 && (d.ldc % 8) == 0 && d.epi != EPI_F32 && ((uintptr_t)d.C % 16) == 0 &&
                     ((uintptr_t)d.C2 % 16) == 0 && ((uintptr_t)d.aux % 16) == 0 && (d.sC % 8) == 0;
   static const int conv_p_env = [] { const char* e = getenv("W2VS_CONV_PERSIST"); return e ? atoi(e) : 1; }();
+  bool wide_auto = false;
   if (mode == 1 && p_ok && conv_p_env) {
+    mode = 5;
+  } else if (mode == 2 && p_ok && conv_p_env && ntiles >= 256 && d.N >= 256) {
+    // Round 2: at least a chip's worth of output -> the PERSISTENT loader/consumer kernel (register-direct epilogue, the DMA ring
+    // keeps running across tile boundaries) with the tile shape that minimises rounds x (rows + columns) - the staged bytes per
+    // K step set the step time (~36 GB/s per CU with every CU streaming), the rounds of 256 workgroups the number of K loops.
+    // Measured at R = 6544 (tools/gemm_probe.py, us, bias / GELU+save / x aux):
+    //   N 3072, K 768: 160x256 tiles 36 / 44 / 44   against 43 / 61 / 56 for the round-1 choice (128^2, 2 per CU)
+    //   N 2304, K 768: 256x128 tiles 30 / 38 / 34   against 33 / 41 / 36
+    //   N  768, K 3072: 160x128 tiles 33 / 36 / 34  against 33 / 39 / 35
+    const long nbz = d.batch > 0 ? d.batch : 1;
+    const int hs[4] = {256, 192, 160, 160}, ws[4] = {128, 128, 128, 256};
+    long best = -1;
+    for (int c = 0; c < 4; ++c) {
+      const long t8 = (long)((d.N + ws[c] - 1) / ws[c]) * ((d.M + hs[c] - 1) / hs[c]) * nbz;
+      const long cost = ((t8 + 255) / 256) * (hs[c] + ws[c]);
+      if (best < 0 || cost < best) { best = cost; lc_h = hs[c]; wide_auto = ws[c] == 256; }
+    }
     mode = 5;
   } else if (mode == 2) {
     const double nkt = (d.K + BK - 1) / BK;
@@ -1262,17 +1290,22 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   static const int lc_env = [] { const char* e = getenv("W2VS_LC_H"); return e ? atoi(e) : 0; }();
   if (lc_env > 0) lc_h = lc_env;
   if (g_force_lc_h > 0) lc_h = g_force_lc_h;
+  // lc_h = 1160 selects the 160 x 256 loader/consumer tile (WN = 4)
+  const bool wide = (lc_h == 1160) || (wide_auto && lc_h == 160 && lc_env <= 0 && g_force_lc_h <= 0 && mode_env < 0 && g_force_nt_mode < 0);
+  if (wide) { lc_h = 160; if (mode != 3 && mode != 5 && mode != 6) return set_error("gemm_nt: the 160 x 256 tile exists for the loader/consumer kernels only"); }
   if (lc_h != 256 && lc_h != 192 && lc_h != 160) return set_error("gemm_nt: tile height must be 256, 192 or 160");
-  const dim3 grid8((d.N + 127) / 128, (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
+  const dim3 grid8((d.N + (wide ? 255 : 127)) / (wide ? 256 : 128), (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
     if (mode == 5 || mode == 6) {   /* 6: the same kernel with one workgroup per tile */       \
       const int ntm_ = grid8.y, ntn_ = grid8.x, tot_ = ntm_ * ntn_ * (int)grid8.z;            \
       const dim3 gp(mode == 6 ? tot_ : std::min(tot_, 256));                                  \
-      if (lc_h == 256) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 4, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_);      \
+      if (wide) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_);          \
+      else if (lc_h == 256) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 4, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_); \
       else if (lc_h == 192) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 3, 4>), gp, dim3(640), 0, s, p, ntm_, ntn_, tot_); \
       else hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5>), gp, dim3(512), 0, s, p, ntm_, ntn_, tot_);                  \
-    } else if (mode == 3 && lc_h == 256) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4, 4>), grid8, dim3(768), 0, s, p); \
+    } else if (mode == 3 && wide) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 2, 5, 4>), grid8, dim3(768), 0, s, p); \
+    else if (mode == 3 && lc_h == 256) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4, 4>), grid8, dim3(768), 0, s, p); \
     else if (mode == 3 && lc_h == 192) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 3, 4>), grid8, dim3(640), 0, s, p); \
     else if (mode == 3) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 2, 5>), grid8, dim3(512), 0, s, p); \
     else if (mode == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, s, p);     \
