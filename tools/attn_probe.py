@@ -32,7 +32,8 @@ def run(tag, B, H, Tp, m, r, p):
     E = 64 * H
     qkv = (torch.randn(B, N, 3 * E, device=dev)).to(BF)
     dout = torch.randn(B, N, E, device=dev).to(BF)
-    bits = ops.attn_drop_bits(B, H, N) if p > 0 else None          # the training step passes the keep-mask store
+    keep = os.environ.get("W2VS_ATTN_KEEP_BITS", "0") == "1"         # as the engine: the keep-mask store is off by default
+    bits = ops.attn_drop_bits(B, H, N) if (p > 0 and keep) else None
     o, lse = ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=5, drop_bits=bits)
     pairs = flops.attention_pairs(Tp, m, r)
     f = 4.0 * pairs * 64 * H * B

@@ -24,12 +24,16 @@ namespace w2vs {
 namespace {
 
 constexpr int NW2 = 4;       // waves per workgroup
-constexpr int MAXT2 = 512;   // 32-row tiles per sequence (N <= 16384)
+constexpr int MAXT2 = 256;   // 32-row tiles per sequence (N <= 8192; longer sequences take attention.hip)
 
+// One record per workgroup row of the launch, longest first, made on the host (make_table): the tile and its list of
+// visible sub-tiles.  In-kernel this was ~10 integer divisions per workgroup before the first load could be issued -
+// measured with s_memtime at the cfgB shape: 4.7 k of a workgroup's 18 k cycles, on SIMDs shared with other waves' loops.
+//   bits 0-9 tile | 10-19 nT | 20-29 nM | 30-39 rc0 | 40-49 aux (fwd/dq: key tiles every query sees in full; dkv: m_lo)
 struct Attn2P {
   AttnP a;
   int ntiles;                 // query tiles (fwd, dq) or key tiles (dkv)
-  uint16_t order[MAXT2];      // tile ids, longest first
+  uint64_t rec[MAXT2];
 };
 
 struct SubList { int nM, rc0, nT; };   // sub-tiles [0, nM) then rc0, rc0 + 1, ... : nT in all
@@ -113,6 +117,7 @@ __device__ __forceinline__ uint32_t pad_bits(const uint8_t* kp, int k0, int N, i
   return (uint32_t)__ballot(bad);          // lanes 0..31 and 32..63 vote alike: the low word is the tile's mask
 }
 
+
 struct KVRegs { bf16x8 k[4]; u32x4 v[4]; };
 
 // v = mask[lane] ? v : 0 with the 64-bit lane mask in an SGPR pair (one VALU op; the mask comes from a stored ballot)
@@ -148,6 +153,7 @@ __device__ __forceinline__ uint32_t* bits_block(const AttnP& p, int bh, int qt, 
 // =================================================================================================
 // forward
 // =================================================================================================
+template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
 __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   const AttnP& p = pp.a;
   // loop: wave-private V tiles (tr-read images, 4 KB each); afterwards the same memory carries (O0, O1, m, l) of waves 1..3.
@@ -157,9 +163,9 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
-  const int BH = p.B * p.H;
-  const int qt = pp.order[blockIdx.x / BH], bh = blockIdx.x % BH;
-  const int b = bh / p.H, h = bh % p.H;
+  const uint64_t rec = pp.rec[blockIdx.y];       // grid (B*H, tiles): x runs fastest, rows are dispatched longest first
+  const int qt = (int)(rec & 1023), bh = blockIdx.x;
+  const int b = fdiv(bh, p.mg_H), h = bh - b * p.H;
   const int N = p.N, Nq = p.Nq;
   const int q0 = qt * 32, q = q0 + r32, qc = min(q, Nq - 1);
   const bf16* Q = p.q + (long)b * p.sbq + h * HD;
@@ -170,13 +176,13 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Q + (long)qc * p.ldq + 16 * s + 8 * hh);
-  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N, p.mq);
-  int wfull;
-  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, p.mq, wfull);
-  if (kp) wfull = 0;
+  const QLimits L = q_limits_mg(qc, p);
+  SubList tl;
+  tl.nT = (int)(rec >> 10) & 1023; tl.nM = (int)(rec >> 20) & 1023; tl.rc0 = (int)(rec >> 30) & 1023;
+  const int wfull = kp ? 0 : ((int)(rec >> 40) & 1023) * 32;     // keys [0, wfull) are visible to all 32 queries
 
   const float c = p.scale * LOG2E;
-  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
+  const uint32_t thr = DM ? drop_threshold(p.p_drop) >> 16 : 0u;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
   const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)p.Ns + (uint32_t)qc) * Nh;
@@ -222,18 +228,19 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
       const uint32_t pb = (kp || k0 + 32 > N) ? pad_bits(kp, k0, N, r32) : 0u;
       mask_keys(S, hh, L.lim - k0, L.clo - k0, L.chi - k0, pb);
     }
-    float mloc = fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3]));
+    float mloc = fmaxf(S[0], S[1]);
 #pragma unroll
-    for (int i = 4; i < 16; i += 2) mloc = fmaxf(mloc, fmaxf(S[i], S[i + 1]));
+    for (int i = 2; i < 16; i += 2) mloc = fmaxf(fmaxf(mloc, S[i]), S[i + 1]);
     mloc = max_halves(mloc) * c;
-    // lazy rescale (attention.hip): keep the reference maximum while no query's maximum grew by more than 2^6
+    // lazy rescale (attention.hip): keep the reference maximum while no query's maximum grew by more than 2^6.  The
+    // multiply by alpha (1 in the common case) is unconditional on purpose: with it inside a branch the compiler carried
+    // the accumulators in two register sets and paid 40 v_mov_b64 per sub-tile to move between them.
     float muse;
-    if (__all(mloc <= mrun + 6.0f)) {
-      muse = (mrun == -INFINITY) ? 0.f : mrun;
-    } else {
-      const float mnew = fmaxf(mrun, mloc);
+    {
+      const bool keep = __all(mloc <= mrun + 6.0f);
+      const float mnew = keep ? mrun : fmaxf(mrun, mloc);
       muse = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = fast_exp2(mrun - muse);
+      const float alpha = keep ? 1.f : fast_exp2(mrun - muse);
       mrun = mnew;
       lrun *= alpha;
 #pragma unroll
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { S[i] = fast_exp2(fmaf(S[i], c, -muse)); ls += S[i]; }
     lrun += ls;
-    if (thr > 0) {      // keep decisions: two per hash word (attn_common.h); 1/(1-p) is applied once, at the end
+    if (DM) {           // keep decisions: two per hash word (attn_common.h); 1/(1-p) is applied once, at the end
       const uint32_t wbase = (drow + (uint32_t)((k0 >> 1) + 2 * hh)) * HASH_K;
       uint32_t packed = 0;   // lane j < 32 collects dword j of this block's keep-mask record (AttnP::drop_bits)
 #define W2VS_DROP_PAIR(i)                                                                                              \
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
         const bool ka = (hw & 0xFFFFu) >= thr, kb = (hw >> 16) >= thr;                                                    \
         S[i] = ka ? S[i] : 0.f;                                                                                           \
         S[(i) + 1] = kb ? S[(i) + 1] : 0.f;                                                                               \
-        if (p.drop_bits) { /* the compare results ARE 64-lane masks: park them, one dword per lane */                     \
+        if (DM == 2) { /* the compare results ARE 64-lane masks: park them, one dword per lane */                         \
           const uint64_t ma = __ballot(ka), mb = __ballot(kb);                                                            \
           packed = write_lanes4<2 * (i)>((uint32_t)ma, (uint32_t)(ma >> 32), (uint32_t)mb, (uint32_t)(mb >> 32), packed);     \
         }                                                                                                                 \
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
       W2VS_DROP_PAIR(0) W2VS_DROP_PAIR(2) W2VS_DROP_PAIR(4) W2VS_DROP_PAIR(6)
       W2VS_DROP_PAIR(8) W2VS_DROP_PAIR(10) W2VS_DROP_PAIR(12) W2VS_DROP_PAIR(14)
 #undef W2VS_DROP_PAIR
-      if (p.drop_bits && lane < 32) bits_block(p, bh, qt, k0 >> 5)[lane] = packed;
+      if (DM == 2 && lane < 32) bits_block(p, bh, qt, k0 >> 5)[lane] = packed;
     }
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { O0[i] = fmaf(rw[i * 64 + lane], aw, O0[i]); O1[i] = fmaf(rw[(16 + i) * 64 + lane], aw, O1[i]); }
   }
-  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
+  const float inv_keep = DM ? 65536.f / (65536.f - (float)thr) : 1.f;
   const float inv = ltot > 0.f ? inv_keep / ltot : 0.f;
   if (q < Nq) {
     bf16* orow = p.o + (long)b * p.sbo + (long)q * p.ldo + h * HD;
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
 //   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T o drop - delta)
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]           (scale applied once at the end)
 // =================================================================================================
+template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
 __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   const AttnP& p = pp.a;
   // loop: wave-private K tiles (tr-read images); afterwards the partial dQ of waves 1..3 (24 KB)
@@ -332,9 +340,9 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
-  const int BH = p.B * p.H;
-  const int qt = pp.order[blockIdx.x / BH], bh = blockIdx.x % BH;
-  const int b = bh / p.H, h = bh % p.H;
+  const uint64_t rec = pp.rec[blockIdx.y];       // grid (B*H, tiles): x runs fastest, rows are dispatched longest first
+  const int qt = (int)(rec & 1023), bh = blockIdx.x;
+  const int b = fdiv(bh, p.mg_H), h = bh - b * p.H;
   const int N = p.N, Nq = p.Nq;
   const int q0 = qt * 32, q = q0 + r32, qc = min(q, Nq - 1);
   const bf16* Q = p.q + (long)b * p.sbq + h * HD;
@@ -362,13 +370,13 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   }
   delta += other_half(delta);
   if (wid == 0 && q < Nq && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
-  const QLimits L = q_limits(qc, p.Tp, p.m, p.r, N, p.mq);
-  int wfull;
-  const SubList tl = key_list(q0, min(q0 + 32, Nq) - 1, p.Tp, p.m, p.r, N, p.mq, wfull);
-  if (kp) wfull = 0;
+  const QLimits L = q_limits_mg(qc, p);
+  SubList tl;
+  tl.nT = (int)(rec >> 10) & 1023; tl.nM = (int)(rec >> 20) & 1023; tl.rc0 = (int)(rec >> 30) & 1023;
+  const int wfull = kp ? 0 : ((int)(rec >> 40) & 1023) * 32;     // keys [0, wfull) are visible to all 32 queries
   const float c = p.scale * LOG2E;
-  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
-  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
+  const uint32_t thr = DM ? drop_threshold(p.p_drop) >> 16 : 0u;
+  const float inv_keep = DM ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
   const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)p.Ns + (uint32_t)qc) * Nh;
@@ -411,8 +419,8 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
       const uint32_t pb = (kp || k0 + 32 > N) ? pad_bits(kp, k0, N, r32) : 0u;
       mask_keys(S, hh, L.lim - k0, L.clo - k0, L.chi - k0, pb);
     }
-    if (thr > 0) {
-      if (p.drop_bits) {   // the forward's decisions, one scalar pair + one v_cndmask per element (no hash)
+    if (DM) {
+      if (DM == 2) {       // the forward's decisions, one scalar pair + one v_cndmask per element (no hash)
         u32x16 ra, rb;
         sload_record(bits_block(p, bh, qt, k0 >> 5), ra, rb);
 #pragma unroll
@@ -474,6 +482,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
 //   S = Q K^T ; P = exp(S - lse[q]) ; dP = dO V^T ; dS = P o (dP o drop - delta[q])        (scale at the end, dK only)
 //   dV^T[d][key] += dO^T[d][q] (P o drop)[q][key]      dK^T[d][key] += Q^T[d][q] dS[q][key]
 // =================================================================================================
+template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
 __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   const AttnP& p = pp.a;
   // during the loop: per wave a Q tile and a dO tile (tr-read images, 4 KB each) and five 32-entry query vectors;
@@ -482,9 +491,9 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
-  const int BH = p.B * p.H;
-  const int kt = pp.order[blockIdx.x / BH], bh = blockIdx.x % BH;
-  const int b = bh / p.H, h = bh % p.H;
+  const uint64_t rec = pp.rec[blockIdx.y];
+  const int kt = (int)(rec & 1023), bh = blockIdx.x;
+  const int b = fdiv(bh, p.mg_H), h = bh - b * p.H;
   const int N = p.N, Nq = p.Nq;
   const int kb0 = kt * 32, key = kb0 + r32, keyc = min(key, N - 1);
   bf16* Qw = (bf16*)smem + wid * (2 * 32 * HD);
@@ -502,17 +511,17 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     vf[s] = *(const bf16x8*)(V + (long)keyc * p.ld + 16 * s + 8 * hh);
   }
   const float c = p.scale * LOG2E;
-  const uint32_t thr = drop_threshold(p.p_drop) >> 16;
-  const float inv_keep = thr > 0 ? 65536.f / (65536.f - (float)thr) : 1.f;
+  const uint32_t thr = DM ? drop_threshold(p.p_drop) >> 16 : 0u;
+  const float inv_keep = DM ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
   const uint32_t dbase = (uint32_t)(b * p.H + h) * (uint32_t)p.Ns;
   const uint32_t khalf = (uint32_t)keyc >> 1, kodd = (uint32_t)keyc & 1u;
   const uint32_t stepK = Nh * HASH_K;
   const bool keys_clean = __all(key_ok);
-  SubList ql = query_list(kb0, min(kb0 + 32, N) - 1, p.Tp, p.m, p.r, N, Nq, p.mq);
-  const int qm_lo = ql.nM >> 16;
-  ql.nM &= 0xFFFF;
+  SubList ql;
+  ql.nT = (int)(rec >> 10) & 1023; ql.nM = (int)(rec >> 20) & 1023; ql.rc0 = (int)(rec >> 30) & 1023;
+  const int qm_lo = (int)(rec >> 40) & 1023;
   f32x16 dV0, dV1, dK0, dK1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dV0[i] = dV1[i] = dK0[i] = dK1[i] = 0.f; }
@@ -530,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     const long si = (long)(b * p.H + h) * p.Ns + qq;
     R.sc = hh ? p.delta[si] : p.lse[si] * LOG2E;
     // this lane's key row of the block's keep-mask record: dword 2i + w with key = (i&3) + 8(i>>2) + 4w
-    R.bits = (p.drop_bits && thr > 0) ? bits_block(p, bh, t, kt)[2 * (r32 & 3) + 8 * (r32 >> 3) + ((r32 >> 2) & 1)] : 0u;
+    R.bits = DM == 2 ? bits_block(p, bh, t, kt)[2 * (r32 & 3) + 8 * (r32 >> 3) + ((r32 >> 2) & 1)] : 0u;
   };
   int pos = wid;
   if (pos < ql.nT) gload(tile_of(pos));
@@ -550,13 +559,13 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     int minlim = 0;
     {
       const int qs1 = min(q0 + 32, Nq) - 1;
-      if (p.mq > 0) minlim = min((q0 / p.mq + 1) * p.m, p.Tp);
-      else if (qs1 < p.Tp) minlim = min((q0 / p.m + 1) * p.m, p.Tp);
-      else if (q0 >= p.Tp && p.r > 0) minlim = min(((q0 - p.Tp) / p.r + 1) * p.m, p.Tp);
+      if (p.mq > 0) minlim = min((fdiv(q0, p.mg_mq) + 1) * p.m, p.Tp);
+      else if (qs1 < p.Tp) minlim = min((fdiv(q0, p.mg_m) + 1) * p.m, p.Tp);
+      else if (q0 >= p.Tp && p.r > 0) minlim = min((fdiv(q0 - p.Tp, p.mg_r) + 1) * p.m, p.Tp);
     }
     const bool full = keys_clean && q0 + 32 <= Nq && kb0 + 32 <= minlim;
     if (!full && hh == 0) {
-      const QLimits L = q_limits(min(q0 + r32, Nq - 1), p.Tp, p.m, p.r, N, p.mq);
+      const QLimits L = q_limits_mg(min(q0 + r32, Nq - 1), p);
       ((int*)qs)[64 + r32] = L.lim; ((int*)qs)[96 + r32] = L.clo; ((int*)qs)[128 + r32] = L.chi;
     }
     f32x16 S, dP;
@@ -596,8 +605,8 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g4 + e;
         int km = -1;                                   // non-zero = keep
-        if (thr > 0) {
-          if (p.drop_bits) km = (int)(wbits & (1u << ((i & 3) + 8 * (i >> 2))));
+        if (DM) {
+          if (DM == 2) km = (int)(wbits & (1u << ((i & 3) + 8 * (i >> 2))));
           else {           // word ((dbase + query) * Nh + key / 2): consecutive rows are stepK apart
             const uint32_t hw = pair_hash_pm(s0, s1, wsub + (uint32_t)(8 * g4 + e) * stepK);
             km = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? -1 : 0;
@@ -664,27 +673,62 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   }
 }
 
-// longest-first order of the 32-row tiles (host; the kernels recompute the lists themselves, so this is speed only)
+// the launch's record table (host): one record per 32-row tile with its visible sub-tile list, longest list first - the
+// tail of the launch is then made of the short workgroups
 template <class F>
-void make_order(Attn2P& pp, int ntiles, F count) {
-  std::vector<std::pair<int, int>> v(ntiles);
-  for (int t = 0; t < ntiles; ++t) v[t] = {-count(t), t};
-  std::sort(v.begin(), v.end());
+void make_table(Attn2P& pp, int ntiles, F list) {      // list(t, aux) -> SubList of tile t (nM without packed extras)
+  struct E { int nT, t, nM, rc0, aux; };
+  std::vector<E> v(ntiles);
+  for (int t = 0; t < ntiles; ++t) {
+    int aux = 0;
+    const SubList l = list(t, aux);
+    v[t] = {l.nT, t, l.nM, l.rc0, aux};
+  }
+  std::stable_sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.nT > b.nT; });
   pp.ntiles = ntiles;
-  for (int t = 0; t < ntiles; ++t) pp.order[t] = (uint16_t)v[t].second;
+  for (int i = 0; i < ntiles; ++i)
+    pp.rec[i] = (uint64_t)v[i].t | ((uint64_t)v[i].nT << 10) | ((uint64_t)v[i].nM << 20) | ((uint64_t)v[i].rc0 << 30) |
+                ((uint64_t)v[i].aux << 40);
+}
+static void query_tile_table(Attn2P& pp, const AttnP& p, int nqt) {
+  make_table(pp, nqt, [&](int t, int& aux) {
+    int full;
+    const SubList l = key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, full);
+    aux = full >> 5;
+    return l;
+  });
+}
+static void key_tile_table(Attn2P& pp, const AttnP& p, int nkt) {
+  make_table(pp, nkt, [&](int t, int& aux) {
+    SubList l = query_list(t * 32, std::min(t * 32 + 32, p.N) - 1, p.Tp, p.m, p.r, p.N, p.Nq, p.mq);
+    aux = l.nM >> 16;
+    l.nM &= 0xFFFF;
+    return l;
+  });
 }
 
 }  // namespace
 
-bool attn2_ok(const AttnP& p) { return (p.N + 31) / 32 <= MAXT2; }
+// dropout mode of a launch: the kernels are compiled once per mode, so the no-dropout loop carries neither the hash nor
+// the branches around it
+static inline int drop_mode(const AttnP& p) { return (drop_threshold(p.p_drop) >> 16) == 0 ? 0 : (p.drop_bits ? 2 : 1); }
+#define W2VS_LAUNCH_DM(kern, tiles)                                                                   \
+  switch (drop_mode(p)) {                                                                              \
+    case 0: hipLaunchKernelGGL(kern<0>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;         \
+    case 1: hipLaunchKernelGGL(kern<1>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;         \
+    default: hipLaunchKernelGGL(kern<2>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;        \
+  }
+
+// (the multiply-high divisions are exact below 65536: positions, and the (batch, head) index)
+bool attn2_ok(const AttnP& p) { return (p.N + 31) / 32 <= MAXT2 && (long)p.B * p.H < 65536 && p.m < 65536 && p.r < 65536 && p.mq < 65536; }
 
 int attn2_fwd(const AttnP& p, hipStream_t st) {
   Attn2P pp;
   pp.a = p;
   pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32;
-  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, f).nT; });
-  hipLaunchKernelGGL(attn2_fwd_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);
+  query_tile_table(pp, p, nqt);
+  W2VS_LAUNCH_DM(attn2_fwd_kernel, nqt)
   return hip_check(hipGetLastError(), "attn_fwd");
 }
 
@@ -693,10 +737,10 @@ int attn2_bwd(const AttnP& p, hipStream_t st) {
   pp.a = p;
   pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32, nkt = (p.N + 31) / 32;
-  make_order(pp, nqt, [&](int t) { int f; return key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, f).nT; });
-  hipLaunchKernelGGL(attn2_dq_kernel, dim3(nqt * p.B * p.H), dim3(256), 0, st, pp);     // dq rows >= Nq are not written
-  make_order(pp, nkt, [&](int t) { return query_list(t * 32, std::min(t * 32 + 32, p.N) - 1, p.Tp, p.m, p.r, p.N, p.Nq, p.mq).nT; });
-  hipLaunchKernelGGL(attn2_dkv_kernel, dim3(nkt * p.B * p.H), dim3(256), 0, st, pp);
+  query_tile_table(pp, p, nqt);
+  W2VS_LAUNCH_DM(attn2_dq_kernel, nqt)     // dq rows >= Nq are not written
+  key_tile_table(pp, p, nkt);
+  W2VS_LAUNCH_DM(attn2_dkv_kernel, nkt)
   return hip_check(hipGetLastError(), "attn_bwd");
 }
 

@@ -32,7 +32,17 @@ struct AttnP {
   // pair (2i, 2i+1) is the 64-lane mask of accumulator element i - and the two backward passes read them back instead of
   // re-hashing (the hash was 60 % of their VALU work).  [B*H][nQT][nKT][32] uint32.
   uint32_t* drop_bits; int nQT, nKT;
+  // multiply-high magics of the divisors m, r, mq, H (div_magic; attention2.hip divides without a division)
+  uint32_t mg_m, mg_r, mg_mq, mg_H;
 };
+
+// exact x / d for 0 <= x < 65536 and 1 <= d < 65536 as one multiply-high: magic = ceil(2^32 / d), and 0 stands for d == 1.
+// (error x * (magic - 2^32/d) / 2^32 < 2^-16 <= 1/d never carries the quotient over an integer.)  An integer division
+// costs ~35 VALU instructions; the kernels of attention2.hip ran ten of them per workgroup before their first load.
+__device__ __host__ inline uint32_t div_magic(int d) {
+  return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u;
+}
+__device__ __forceinline__ int fdiv(int x, uint32_t mg) { return mg ? (int)__umulhi((uint32_t)x, mg) : x; }
 
 // LDS image of a [rows][64] bf16 tile read by rows (16-B chunks): XOR swizzle as in gemm.hip
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -81,6 +91,16 @@ __device__ __forceinline__ QLimits q_limits(int q, int Tp, int m, int r, int N, 
   L.lim = min((bq + 1) * m, Tp);
   L.clo = r > 0 ? Tp + bq * r : N;
   L.chi = r > 0 ? min(Tp + (bq + 1) * r, N) : N;
+  return L;
+}
+// the same through the magics (q < 65536)
+__device__ __forceinline__ QLimits q_limits_mg(int q, const AttnP& p) {
+  QLimits L;
+  if (p.mq > 0) { L.lim = min((fdiv(q, p.mg_mq) + 1) * p.m, p.Tp); L.clo = p.N; L.chi = p.N; return L; }
+  const int bq = (q < p.Tp) ? fdiv(q, p.mg_m) : (p.r > 0 ? fdiv(q - p.Tp, p.mg_r) : 0);
+  L.lim = min((bq + 1) * p.m, p.Tp);
+  L.clo = p.r > 0 ? p.Tp + bq * p.r : p.N;
+  L.chi = p.r > 0 ? min(p.Tp + (bq + 1) * p.r, p.N) : p.N;
   return L;
 }
 // key range a set of queries [q0, q1] can touch: main keys [0, mlim), copies [clo, chi)
