@@ -614,6 +614,7 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
   p.drop_bits = (uint32_t*)d.drop_bits;
   p.mq = d.mq; p.ldq = d.mq > 0 ? d.ldq : d.ld; p.sbq = d.mq > 0 ? d.sbq : d.sb; p.Ns = d.mq > 0 ? p.Nq : d.N;
   p.mg_m = div_magic(d.m); p.mg_r = div_magic(d.r); p.mg_mq = div_magic(d.mq); p.mg_H = div_magic(d.H);
+  p.thr16 = drop_threshold(d.p_drop) >> 16;
   if (d.mq < 0) return set_error("attention: mq must be >= 0");
   if (d.mq > 0) {
     if (d.r != 0 || d.Tp != d.N) return set_error("attention (cross mode): needs r == 0 and Tp == N");

@@ -155,7 +155,8 @@ __device__ __forceinline__ uint32_t* bits_block(const AttnP& p, int bh, int qt, 
 // =================================================================================================
 template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
 __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
-  const AttnP& p = pp.a;
+  AttnP p = pp.a;
+  W2VS_PIN_ATTNP(p);
   // loop: wave-private V tiles (tr-read images, 4 KB each); afterwards the same memory carries (O0, O1, m, l) of waves 1..3.
   // 26 KB per workgroup and <= 128 registers: four workgroups per CU, so one workgroup's prologue / merge (dependent
   // global loads, a barrier) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   const int wfull = kp ? 0 : ((int)(rec >> 40) & 1023) * 32;     // keys [0, wfull) are visible to all 32 queries
 
   const float c = p.scale * LOG2E;
-  const uint32_t thr = DM ? drop_threshold(p.p_drop) >> 16 : 0u;
+  const uint32_t thr = DM ? p.thr16 : 0u;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
   const uint32_t drow = ((uint32_t)(b * p.H + h) * (uint32_t)p.Ns + (uint32_t)qc) * Nh;
@@ -333,7 +334,9 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
 // =================================================================================================
 template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
 __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
-  const AttnP& p = pp.a;
+  AttnP p = pp.a;
+  W2VS_PIN_ATTNP(p);
+  W2VS_PIN_ATTNP_BWD(p);
   // loop: wave-private K tiles (tr-read images); afterwards the partial dQ of waves 1..3 (24 KB)
   __shared__ __attribute__((aligned(16))) float red_mem[(NW2 - 1) * 32 * 64];
   float (*red)[32][64] = (float (*)[32][64])red_mem;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   tl.nT = (int)(rec >> 10) & 1023; tl.nM = (int)(rec >> 20) & 1023; tl.rc0 = (int)(rec >> 30) & 1023;
   const int wfull = kp ? 0 : ((int)(rec >> 40) & 1023) * 32;     // keys [0, wfull) are visible to all 32 queries
   const float c = p.scale * LOG2E;
-  const uint32_t thr = DM ? drop_threshold(p.p_drop) >> 16 : 0u;
+  const uint32_t thr = DM ? p.thr16 : 0u;
   const float inv_keep = DM ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
@@ -484,7 +487,9 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
 // =================================================================================================
 template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
 __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
-  const AttnP& p = pp.a;
+  AttnP p = pp.a;
+  W2VS_PIN_ATTNP(p);
+  W2VS_PIN_ATTNP_BWD(p);
   // during the loop: per wave a Q tile and a dO tile (tr-read images, 4 KB each) and five 32-entry query vectors;
   // afterwards the same memory carries the partial dK / dV of waves 1..3
   __shared__ __attribute__((aligned(16))) float smem[(NW2 - 1) * 64 * 64];
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     vf[s] = *(const bf16x8*)(V + (long)keyc * p.ld + 16 * s + 8 * hh);
   }
   const float c = p.scale * LOG2E;
-  const uint32_t thr = DM ? drop_threshold(p.p_drop) >> 16 : 0u;
+  const uint32_t thr = DM ? p.thr16 : 0u;
   const float inv_keep = DM ? 65536.f / (65536.f - (float)thr) : 1.f;
   const uint32_t s0 = (uint32_t)p.seed, s1 = (uint32_t)(p.seed >> 32);
   const uint32_t Nh = (uint32_t)(N + 1) >> 1;
@@ -711,7 +716,7 @@ static void key_tile_table(Attn2P& pp, const AttnP& p, int nkt) {
 
 // dropout mode of a launch: the kernels are compiled once per mode, so the no-dropout loop carries neither the hash nor
 // the branches around it
-static inline int drop_mode(const AttnP& p) { return (drop_threshold(p.p_drop) >> 16) == 0 ? 0 : (p.drop_bits ? 2 : 1); }
+static inline int drop_mode(const AttnP& p) { return p.thr16 == 0 ? 0 : (p.drop_bits ? 2 : 1); }
 #define W2VS_LAUNCH_DM(kern, tiles)                                                                   \
   switch (drop_mode(p)) {                                                                              \
     case 0: hipLaunchKernelGGL(kern<0>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;         \

@@ -34,6 +34,7 @@ struct AttnP {
   uint32_t* drop_bits; int nQT, nKT;
   // multiply-high magics of the divisors m, r, mq, H (div_magic; attention2.hip divides without a division)
   uint32_t mg_m, mg_r, mg_mq, mg_H;
+  uint32_t thr16;                               // drop_threshold(p_drop) >> 16, made on the host
 };
 
 // exact x / d for 0 <= x < 65536 and 1 <= d < 65536 as one multiply-high: magic = ceil(2^32 / d), and 0 stands for d == 1.
@@ -43,6 +44,21 @@ __device__ __host__ inline uint32_t div_magic(int d) {
   return d > 1 ? (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d) : 0u;
 }
 __device__ __forceinline__ int fdiv(int x, uint32_t mg) { return mg ? (int)__umulhi((uint32_t)x, mg) : x; }
+// Pull the launch parameters a kernel uses into SGPRs in its entry block and keep them there.  Left alone the compiler
+// fetches each field of the by-value argument where it is first needed - one s_load_dword + s_waitcnt lgkmcnt(0) round
+// trip per field, 13 of them in a row before the first K / V load of attention2.hip's forward (about 4 k cycles per
+// workgroup, measured with s_memtime).  The "+s" makes each value opaque: a plain kernarg load is rematerialisable and the
+// register allocator happily re-issues it (with its wait) further down instead of keeping the register.
+#define W2VS_PIN_S(x) asm volatile("" : "+s"(x))
+#define W2VS_PIN_ATTNP(p)                                                                                              \
+  W2VS_PIN_S((p).q); W2VS_PIN_S((p).k); W2VS_PIN_S((p).v); W2VS_PIN_S((p).o); W2VS_PIN_S((p).lse); W2VS_PIN_S((p).kpad); \
+  W2VS_PIN_S((p).ld); W2VS_PIN_S((p).ldo); W2VS_PIN_S((p).sb); W2VS_PIN_S((p).sbo); W2VS_PIN_S((p).H); W2VS_PIN_S((p).N); \
+  W2VS_PIN_S((p).Tp); W2VS_PIN_S((p).m); W2VS_PIN_S((p).r); W2VS_PIN_S((p).Nq); W2VS_PIN_S((p).scale);                  \
+  W2VS_PIN_S((p).seed); W2VS_PIN_S((p).mq); W2VS_PIN_S((p).ldq); W2VS_PIN_S((p).sbq); W2VS_PIN_S((p).Ns);               \
+  W2VS_PIN_S((p).mg_m); W2VS_PIN_S((p).mg_r); W2VS_PIN_S((p).mg_mq); W2VS_PIN_S((p).mg_H); W2VS_PIN_S((p).thr16);       \
+  W2VS_PIN_S((p).drop_bits); W2VS_PIN_S((p).nQT); W2VS_PIN_S((p).nKT)
+#define W2VS_PIN_ATTNP_BWD(p)                                                                                          \
+  W2VS_PIN_S((p).dout); W2VS_PIN_S((p).delta); W2VS_PIN_S((p).dq); W2VS_PIN_S((p).dk); W2VS_PIN_S((p).dv)
 
 // LDS image of a [rows][64] bf16 tile read by rows (16-B chunks): XOR swizzle as in gemm.hip
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
