@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
   const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
+  const uint32_t ld24 = (uint32_t)p.ld;
 
   bf16x8 qf[4];
 #pragma unroll
@@ -200,13 +201,13 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   bf16x8 kr[4];
   u32x4 vr[4];
   auto load_k = [&](int t) {
-    const long krow = (long)min(t * 32 + r32, N - 1) * p.ld;
+    const bf16* krow = row_at(K, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(K + krow + 16 * s + 8 * hh);
+    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(krow + 16 * s);
   };
   auto load_v = [&](int t) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vr[j] = *(const u32x4*)(V + (long)min(t * 32 + vrow + 8 * j, N - 1) * p.ld + vch * 8);
+    for (int j = 0; j < 4; ++j) vr[j] = *(const u32x4*)(row_at(V, min(t * 32 + vrow + 8 * j, N - 1), ld24) + vch * 8);
   };
   int pos = wid;
   if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   const bf16* V = p.v + (long)b * p.sb + h * HD;
   const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
   const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
+  const uint32_t ld24 = (uint32_t)p.ld;
   bf16x8 qf[4], dof[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -391,14 +393,14 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   auto tile_of = [&](int pos) { return pos < tl.nM ? pos : tl.rc0 + (pos - tl.nM); };
   bf16x8 kr[4], vr[4];
   auto load_k = [&](int t) {
-    const long krow = (long)min(t * 32 + r32, N - 1) * p.ld;
+    const bf16* krow = row_at(K, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(K + krow + 16 * s + 8 * hh);
+    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(krow + 16 * s);
   };
   auto load_v = [&](int t) {
-    const long krow = (long)min(t * 32 + r32, N - 1) * p.ld;
+    const bf16* vrow_p = row_at(V, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) vr[s] = *(const bf16x8*)(V + krow + 16 * s + 8 * hh);
+    for (int s = 0; s < 4; ++s) vr[s] = *(const bf16x8*)(vrow_p + 16 * s);
   };
   int pos = wid;
   if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
     asm volatile("" ::: "memory");
     // the K fragments this lane holds are chunks (2s + hh) of row r32: write them as the row-major tile the tr reads want
 #pragma unroll
-    for (int s = 0; s < 4; ++s) *(bf16x8*)(Kw + vswz(r32, (2 * s + hh) * 8)) = kr[s];
+    for (int s = 0; s < 4; ++s) *(bf16x8*)(Kw + uswz(r32, (2 * s + hh) * 8)) = kr[s];
     f32x16 S, dP;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
@@ -449,8 +451,8 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
       const bf16x8 db = pack8(S, s2);
       const int krow = 16 * s2 + 4 * (g >> 1) + tq;
       const int dcol = (g & 1) * 16 + 4 * tp;
-      const bf16x8 a0 = tr_pair(Kw + vswz(krow, dcol), Kw + vswz(krow + 8, dcol));
-      const bf16x8 a1 = tr_pair(Kw + vswz(krow, 32 + dcol), Kw + vswz(krow + 8, 32 + dcol));
+      const bf16x8 a0 = tr_pair(Kw + uswz(krow, dcol), Kw + uswz(krow + 8, dcol));
+      const bf16x8 a1 = tr_pair(Kw + uswz(krow, 32 + dcol), Kw + uswz(krow + 8, 32 + dcol));
       D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, db, D0, 0, 0, 0);
       D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, db, D1, 0, 0, 0);
     }
@@ -508,6 +510,8 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
   const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
+  const float* lse_bh = p.lse + (long)bh * p.Ns;
+  const float* delta_bh = p.delta + (long)bh * p.Ns;
   const bool key_ok = key < N && !(p.kpad && p.kpad[(long)b * N + key]);
   bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -536,13 +540,14 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   Regs R;
   auto gload = [&](int t) {
     const int qq = min(t * 32 + r32, Nq - 1);
+    const bf16* qrow_p = row_at(Q, qq, (uint32_t)p.ldq) + 8 * hh;
+    const bf16* drow_p = row_at(dO, qq, (uint32_t)p.ldo) + 8 * hh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      R.q[s] = *(const bf16x8*)(Q + (long)qq * p.ldq + 16 * s + 8 * hh);
-      R.d[s] = *(const bf16x8*)(dO + (long)qq * p.ldo + 16 * s + 8 * hh);
+      R.q[s] = *(const bf16x8*)(qrow_p + 16 * s);
+      R.d[s] = *(const bf16x8*)(drow_p + 16 * s);
     }
-    const long si = (long)(b * p.H + h) * p.Ns + qq;
-    R.sc = hh ? p.delta[si] : p.lse[si] * LOG2E;
+    R.sc = hh ? delta_bh[qq] : lse_bh[qq] * LOG2E;
     // this lane's key row of the block's keep-mask record: dword 2i + w with key = (i&3) + 8(i>>2) + 4w
     R.bits = DM == 2 ? bits_block(p, bh, t, kt)[2 * (r32 & 3) + 8 * (r32 >> 3) + ((r32 >> 2) & 1)] : 0u;
   };
@@ -554,8 +559,8 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      *(bf16x8*)(Qw + vswz(r32, (2 * s + hh) * 8)) = R.q[s];
-      *(bf16x8*)(Dw + vswz(r32, (2 * s + hh) * 8)) = R.d[s];
+      *(bf16x8*)(Qw + uswz(r32, (2 * s + hh) * 8)) = R.q[s];
+      *(bf16x8*)(Dw + uswz(r32, (2 * s + hh) * 8)) = R.d[s];
     }
     // per-query scalars: rows past Nq get lse = +inf -> P = 0
     const bool qvalid = q0 + r32 < Nq;
@@ -628,12 +633,12 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
       const bf16x8 pb = pack8(Pd, s2), sb = pack8(S, s2);
       const int qrow = 16 * s2 + 4 * (g >> 1) + tq;
       const int dcol = (g & 1) * 16 + 4 * tp;
-      const bf16x8 d0 = tr_pair(Dw + vswz(qrow, dcol), Dw + vswz(qrow + 8, dcol));
-      const bf16x8 d1 = tr_pair(Dw + vswz(qrow, 32 + dcol), Dw + vswz(qrow + 8, 32 + dcol));
+      const bf16x8 d0 = tr_pair(Dw + uswz(qrow, dcol), Dw + uswz(qrow + 8, dcol));
+      const bf16x8 d1 = tr_pair(Dw + uswz(qrow, 32 + dcol), Dw + uswz(qrow + 8, 32 + dcol));
       dV0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, pb, dV0, 0, 0, 0);
       dV1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, pb, dV1, 0, 0, 0);
-      const bf16x8 q0f = tr_pair(Qw + vswz(qrow, dcol), Qw + vswz(qrow + 8, dcol));
-      const bf16x8 q1f = tr_pair(Qw + vswz(qrow, 32 + dcol), Qw + vswz(qrow + 8, 32 + dcol));
+      const bf16x8 q0f = tr_pair(Qw + uswz(qrow, dcol), Qw + uswz(qrow + 8, dcol));
+      const bf16x8 q1f = tr_pair(Qw + uswz(qrow, 32 + dcol), Qw + uswz(qrow + 8, 32 + dcol));
       dK0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0f, sb, dK0, 0, 0, 0);
       dK1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1f, sb, dK1, 0, 0, 0);
     }
@@ -724,8 +729,13 @@ static inline int drop_mode(const AttnP& p) { return p.thr16 == 0 ? 0 : (p.drop_
     default: hipLaunchKernelGGL(kern<2>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;        \
   }
 
-// (the multiply-high divisions are exact below 65536: positions, and the (batch, head) index)
-bool attn2_ok(const AttnP& p) { return (p.N + 31) / 32 <= MAXT2 && (long)p.B * p.H < 65536 && p.m < 65536 && p.r < 65536 && p.mq < 65536; }
+// (the multiply-high divisions are exact below 65536: positions, and the (batch, head) index;
+// and the 24-bit row-address products need strides below 2^24 and N * stride below 2^32)
+bool attn2_ok(const AttnP& p) {
+  const long ldmax = std::max(std::max(p.ld, p.ldo), p.ldq);
+  return (p.N + 31) / 32 <= MAXT2 && (long)p.B * p.H < 65536 && p.m < 65536 && p.r < 65536 && p.mq < 65536 &&
+         ldmax < (1l << 24) && (long)std::max(p.N, p.Nq) * ldmax < (1l << 32);
+}
 
 int attn2_fwd(const AttnP& p, hipStream_t st) {
   Attn2P pp;

@@ -65,6 +65,19 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((ch
 // LDS image of a [rows][64] bf16 tile read through tr reads (8-B pieces): flip the 64-B half on
 // rows 2,3 (mod 4) so the four rows of a tr block sit on distinct banks
 __device__ __forceinline__ int vswz(int row, int col) { return row * 64 + (col ^ (((row >> 1) & 1) << 5)); }
+// row * ld as a 24 x 24-bit product (attn2_ok: rows and strides below 2^24, products below 2^32): one full-rate multiply
+// and a 64-bit add per row address instead of the five-instruction 64-bit multiply the `long` arithmetic compiles to -
+// the loops form five such addresses per sub-tile
+__device__ __forceinline__ const bf16* row_at(const bf16* base, int row, uint32_t ld) { return base + __umul24((uint32_t)row, ld); }
+// The same tile when it is WRITTEN from MFMA operand registers (lane = row, one 16-B chunk per instruction: 16 rows of one
+// chunk column per LDS pass) and read through tr reads.  vswz serves the tr reads but puts those 16 rows on 4 bank groups
+// (PMC: 40-47 % of the LDS cycles of the two backward kernels were bank conflicts).  XOR the chunk with a value that is a
+// bijection of (row >> 1) & 7 - conflict-free row writes - whose bit 2 separates rows 2,3 (mod 4) from rows 0,1 - the
+// four rows of a tr block stay on distinct banks.
+__device__ __forceinline__ int uswz(int row, int col) {
+  const int s = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+  return row * 64 + ((((col >> 3) ^ s) << 3) | (col & 7));
+}
 
 __device__ __forceinline__ s16x4 ds_tr16(const bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
