@@ -27,13 +27,16 @@ def t_us(fn, iters=30):
 
 R = 6544
 g = torch.Generator(device="cuda").manual_seed(0)
-for name, N, K in (("fc1 fwd", 3072, 768), ("qkv fwd", 2304, 768), ("fc2 fwd", 768, 3072)):
+SHAPES = (("fc1 fwd", 3072, 768), ("qkv fwd", 2304, 768), ("fc2 fwd", 768, 3072), ("out fwd", 768, 768))
+if len(sys.argv) > 1:
+    SHAPES = tuple(s for s in SHAPES if s[0].split()[0] in sys.argv[1:])
+for name, N, K in SHAPES:
     x = torch.randn(R, K, device="cuda", generator=g).to(BF)
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(BF)
     b = torch.randn(N, device="cuda", generator=g).to(BF)
     aux = torch.randn(R, N, device="cuda", generator=g).to(BF)
     ref = (x.float() @ w.float().t() + b.float())
-    for cfg_name, tune in (("default", (-1, 0)), ("128^2 dma", (2, 0)), ("lc 256x128", (3, 256)), ("lc 160x128", (3, 160)), ("lc 160x256", (3, 1160)), ("persist 256x128", (5, 256)), ("persist 160x128", (5, 160)),
+    for cfg_name, tune in (("default", (-1, 0)), ("128^2 dma", (2, 0)), ("lc 256x128", (3, 256)), ("lc 160x128", (3, 160)), ("lc 160x256", (3, 1160)), ("persist 256x128", (5, 256)), ("persist 192x128", (5, 192)), ("lc 192x128", (3, 192)), ("128^2 regs", (0, 0)), ("128^2 mode1", (1, 0)), ("persist 160x128", (5, 160)),
                            ("persist 160x256", (5, 1160))):
         if tune[1] == 1160 and N % 256:
             continue

@@ -361,6 +361,23 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
     qf[s] = *(const bf16x8*)(Q + (long)qc * p.ldq + 16 * s + 8 * hh);
     dof[s] = *(const bf16x8*)(dO + (long)qc * p.ldo + 16 * s + 8 * hh);
   }
+  // the first sub-tile's K / V loads go out before anything waits: the delta below needs a round trip of its own (O rows)
+  SubList tl;
+  tl.nT = (int)(rec >> 10) & 1023; tl.nM = (int)(rec >> 20) & 1023; tl.rc0 = (int)(rec >> 30) & 1023;
+  auto tile_of = [&](int pos) { return pos < tl.nM ? pos : tl.rc0 + (pos - tl.nM); };
+  bf16x8 kr[4], vr[4];
+  auto load_k = [&](int t) {
+    const bf16* krow = row_at(K, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(krow + 16 * s);
+  };
+  auto load_v = [&](int t) {
+    const bf16* vrow_p = row_at(V, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vr[s] = *(const bf16x8*)(vrow_p + 16 * s);
+  };
+  int pos = wid;
+  if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
   const long sidx = ((long)(b * p.H + h)) * p.Ns + qc;
   const float lse2 = p.lse[sidx] * LOG2E;
   float delta = 0.f;
@@ -376,8 +393,6 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   delta += other_half(delta);
   if (wid == 0 && q < Nq && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
   const QLimits L = q_limits_mg(qc, p);
-  SubList tl;
-  tl.nT = (int)(rec >> 10) & 1023; tl.nM = (int)(rec >> 20) & 1023; tl.rc0 = (int)(rec >> 30) & 1023;
   const int wfull = kp ? 0 : ((int)(rec >> 40) & 1023) * 32;     // keys [0, wfull) are visible to all 32 queries
   const float c = p.scale * LOG2E;
   const uint32_t thr = DM ? p.thr16 : 0u;
@@ -390,20 +405,6 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   for (int i = 0; i < 16; ++i) { D0[i] = 0.f; D1[i] = 0.f; }
   bf16* Kw = (bf16*)red_mem + wid * (32 * HD);
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-  auto tile_of = [&](int pos) { return pos < tl.nM ? pos : tl.rc0 + (pos - tl.nM); };
-  bf16x8 kr[4], vr[4];
-  auto load_k = [&](int t) {
-    const bf16* krow = row_at(K, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(krow + 16 * s);
-  };
-  auto load_v = [&](int t) {
-    const bf16* vrow_p = row_at(V, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) vr[s] = *(const bf16x8*)(vrow_p + 16 * s);
-  };
-  int pos = wid;
-  if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
   while (pos < tl.nT) {
     const int k0 = tile_of(pos) * 32;
     const int nxt = pos + NW2;

@@ -1,6 +1,7 @@
 // Device helpers shared by the attention kernels (attention.hip: v1, one workgroup = 128 queries walking the keys in
 // lockstep; attention2.hip: v2, one workgroup = 32 queries / 32 keys with the reduction dimension split over its waves).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "w2vs_internal.h"
 
@@ -50,15 +51,23 @@ __device__ __forceinline__ int fdiv(int x, uint32_t mg) { return mg ? (int)__umu
 // workgroup, measured with s_memtime).  The "+s" makes each value opaque: a plain kernarg load is rematerialisable and the
 // register allocator happily re-issues it (with its wait) further down instead of keeping the register.
 #define W2VS_PIN_S(x) asm volatile("" : "+s"(x))
+// pointers: the asm hides that they came from the kernel arguments (= global memory) and every access would turn into a
+// flat_load - which also counts on lgkmcnt, so each LDS wait would drain the K / V prefetch.  Say it again.
+#define W2VS_PIN_P(x)                                                                                                   \
+  do {                                                                                                                  \
+    __attribute__((address_space(1))) std::remove_pointer_t<decltype(x)>* g_;                                           \
+    asm volatile("" : "=s"(g_) : "0"(x));     /* the opaque value is born a global pointer */                           \
+    x = (decltype(x))g_;                                                                                                \
+  } while (0)
 #define W2VS_PIN_ATTNP(p)                                                                                              \
-  W2VS_PIN_S((p).q); W2VS_PIN_S((p).k); W2VS_PIN_S((p).v); W2VS_PIN_S((p).o); W2VS_PIN_S((p).lse); W2VS_PIN_S((p).kpad); \
+  W2VS_PIN_P((p).q); W2VS_PIN_P((p).k); W2VS_PIN_P((p).v); W2VS_PIN_P((p).o); W2VS_PIN_P((p).lse); W2VS_PIN_P((p).kpad); \
   W2VS_PIN_S((p).ld); W2VS_PIN_S((p).ldo); W2VS_PIN_S((p).sb); W2VS_PIN_S((p).sbo); W2VS_PIN_S((p).H); W2VS_PIN_S((p).N); \
   W2VS_PIN_S((p).Tp); W2VS_PIN_S((p).m); W2VS_PIN_S((p).r); W2VS_PIN_S((p).Nq); W2VS_PIN_S((p).scale);                  \
   W2VS_PIN_S((p).seed); W2VS_PIN_S((p).mq); W2VS_PIN_S((p).ldq); W2VS_PIN_S((p).sbq); W2VS_PIN_S((p).Ns);               \
   W2VS_PIN_S((p).mg_m); W2VS_PIN_S((p).mg_r); W2VS_PIN_S((p).mg_mq); W2VS_PIN_S((p).mg_H); W2VS_PIN_S((p).thr16);       \
-  W2VS_PIN_S((p).drop_bits); W2VS_PIN_S((p).nQT); W2VS_PIN_S((p).nKT)
+  W2VS_PIN_P((p).drop_bits); W2VS_PIN_S((p).nQT); W2VS_PIN_S((p).nKT)
 #define W2VS_PIN_ATTNP_BWD(p)                                                                                          \
-  W2VS_PIN_S((p).dout); W2VS_PIN_S((p).delta); W2VS_PIN_S((p).dq); W2VS_PIN_S((p).dk); W2VS_PIN_S((p).dv)
+  W2VS_PIN_P((p).dout); W2VS_PIN_P((p).delta); W2VS_PIN_P((p).dq); W2VS_PIN_P((p).dk); W2VS_PIN_P((p).dv)
 
 // LDS image of a [rows][64] bf16 tile read by rows (16-B chunks): XOR swizzle as in gemm.hip
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
