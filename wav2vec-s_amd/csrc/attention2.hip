@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   // loop: wave-private V tiles (tr-read images, 4 KB each); afterwards the same memory carries (O0, O1, m, l) of waves 1..3.
   // 26 KB per workgroup and <= 128 registers: four workgroups per CU, so one workgroup's prologue / merge (dependent
   // global loads, a barrier) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
-  __shared__ __attribute__((aligned(16))) float smem[(NW2 - 1) * 34 * 64];
+  __shared__ __attribute__((aligned(16))) float smem[NW2 * 2 * 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 25.5)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
@@ -193,24 +193,24 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { O0[i] = 0.f; O1[i] = 0.f; }
   float mrun = -INFINITY, lrun = 0.f;       // mrun: scaled (log2) units, shared by both lane halves of a query
-  bf16* Vw = (bf16*)smem + wid * (32 * HD);
+  bf16* Vw = (bf16*)smem + wid * (2 * 32 * HD);
+  bf16* Kw = Vw + 32 * HD;
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   const int vrow = lane >> 3, vch = lane & 7;
 
   auto tile_of = [&](int pos) { return pos < tl.nM ? pos : tl.rc0 + (pos - tl.nM); };
-  bf16x8 kr[4];
-  u32x4 vr[4];
-  auto load_k = [&](int t) {
-    const bf16* krow = row_at(K, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
+  // K and V rows alike: row-contiguous global loads (8 lanes x 16 B per row) -> the wave's LDS tiles -> MFMA operands
+  u32x4 kr[4], vr[4];
+  auto load_kv = [&](int t) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(krow + 16 * s);
-  };
-  auto load_v = [&](int t) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) vr[j] = *(const u32x4*)(row_at(V, min(t * 32 + vrow + 8 * j, N - 1), ld24) + vch * 8);
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t off = __umul24((uint32_t)min(t * 32 + vrow + 8 * j, N - 1), ld24) + vch * 8;
+      kr[j] = *(const u32x4*)(K + off);
+      vr[j] = *(const u32x4*)(V + off);
+    }
   };
   int pos = wid;
-  if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
+  if (pos < tl.nT) load_kv(tile_of(pos));
   while (pos < tl.nT) {
     const int k0 = tile_of(pos) * 32;
     const int nxt = pos + NW2;
@@ -218,14 +218,19 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
     // sub-tile's loads go out right there and have the softmax and the P.V product to land
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(u32x4*)(Vw + vswz(vrow + 8 * j, vch * 8)) = vr[j];
-    if (nxt < tl.nT) load_v(tile_of(nxt));
+    for (int j = 0; j < 4; ++j) {
+      *(u32x4*)(Kw + uswz(vrow + 8 * j, vch * 8)) = kr[j];
+      *(u32x4*)(Vw + vswz(vrow + 8 * j, vch * 8)) = vr[j];
+    }
+    if (nxt < tl.nT) load_kv(tile_of(nxt));
     f32x16 S;
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[s], qf[s], S, 0, 0, 0);
-    if (nxt < tl.nT) load_k(tile_of(nxt));
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 kfr = *(const bf16x8*)(Kw + uswz(r32, (2 * s + hh) * 8));
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[s], S, 0, 0, 0);
+    }
     if (!(k0 + 32 <= wfull)) {          // wave-uniform: boundary / right-context / padded tiles only
       const uint32_t pb = (kp || k0 + 32 > N) ? pad_bits(kp, k0, N, r32) : 0u;
       mask_keys(S, hh, L.lim - k0, L.clo - k0, L.chi - k0, pb);
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   W2VS_PIN_ATTNP(p);
   W2VS_PIN_ATTNP_BWD(p);
   // loop: wave-private K tiles (tr-read images); afterwards the partial dQ of waves 1..3 (24 KB)
-  __shared__ __attribute__((aligned(16))) float red_mem[(NW2 - 1) * 32 * 64];
+  __shared__ __attribute__((aligned(16))) float red_mem[NW2 * 2 * 32 * HD / 2];   // 32 KB: K and V tile per wave; the merge needs 24
   float (*red)[32][64] = (float (*)[32][64])red_mem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -365,19 +370,20 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   SubList tl;
   tl.nT = (int)(rec >> 10) & 1023; tl.nM = (int)(rec >> 20) & 1023; tl.rc0 = (int)(rec >> 30) & 1023;
   auto tile_of = [&](int pos) { return pos < tl.nM ? pos : tl.rc0 + (pos - tl.nM); };
-  bf16x8 kr[4], vr[4];
-  auto load_k = [&](int t) {
-    const bf16* krow = row_at(K, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
+  // K / V rows: row-contiguous global loads (8 lanes x 16 B per row) -> the wave's two LDS tiles -> MFMA operands (as in the
+  // dK/dV pass: loads in the operand layout, one row per lane, cost 13 % of the backward)
+  u32x4 kr[4], vr[4];
+  const int crow = lane >> 3, cch = lane & 7;
+  auto load_kv = [&](int t) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kr[s] = *(const bf16x8*)(krow + 16 * s);
-  };
-  auto load_v = [&](int t) {
-    const bf16* vrow_p = row_at(V, min(t * 32 + r32, N - 1), ld24) + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) vr[s] = *(const bf16x8*)(vrow_p + 16 * s);
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t off = __umul24((uint32_t)min(t * 32 + crow + 8 * j, N - 1), ld24) + cch * 8;
+      kr[j] = *(const u32x4*)(K + off);
+      vr[j] = *(const u32x4*)(V + off);
+    }
   };
   int pos = wid;
-  if (pos < tl.nT) { load_k(tile_of(pos)); load_v(tile_of(pos)); }
+  if (pos < tl.nT) load_kv(tile_of(pos));
   const long sidx = ((long)(b * p.H + h)) * p.Ns + qc;
   const float lse2 = p.lse[sidx] * LOG2E;
   float delta = 0.f;
@@ -403,24 +409,29 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   f32x16 D0, D1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { D0[i] = 0.f; D1[i] = 0.f; }
-  bf16* Kw = (bf16*)red_mem + wid * (32 * HD);
+  bf16* Kw = (bf16*)red_mem + wid * (2 * 32 * HD);
+  bf16* Vw = Kw + 32 * HD;
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   while (pos < tl.nT) {
     const int k0 = tile_of(pos) * 32;
     const int nxt = pos + NW2;
     asm volatile("" ::: "memory");
-    // the K fragments this lane holds are chunks (2s + hh) of row r32: write them as the row-major tile the tr reads want
 #pragma unroll
-    for (int s = 0; s < 4; ++s) *(bf16x8*)(Kw + uswz(r32, (2 * s + hh) * 8)) = kr[s];
+    for (int j = 0; j < 4; ++j) {
+      *(u32x4*)(Kw + uswz(crow + 8 * j, cch * 8)) = kr[j];
+      *(u32x4*)(Vw + uswz(crow + 8 * j, cch * 8)) = vr[j];
+    }
+    if (nxt < tl.nT) load_kv(tile_of(nxt));     // one register set: free once the tiles sit in LDS
     f32x16 S, dP;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[s], qf[s], S, 0, 0, 0);
-      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[s], dof[s], dP, 0, 0, 0);
+      const bf16x8 kfr = *(const bf16x8*)(Kw + uswz(r32, (2 * s + hh) * 8));
+      const bf16x8 vfr = *(const bf16x8*)(Vw + uswz(r32, (2 * s + hh) * 8));
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[s], S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[s], dP, 0, 0, 0);
     }
-    if (nxt < tl.nT) { load_k(tile_of(nxt)); load_v(tile_of(nxt)); }     // one register set: free once S / dP are issued
     if (!(k0 + 32 <= wfull)) {
       const uint32_t pb = (kp || k0 + 32 > N) ? pad_bits(kp, k0, N, r32) : 0u;
       mask_keys(S, hh, L.lim - k0, L.clo - k0, L.chi - k0, pb);
