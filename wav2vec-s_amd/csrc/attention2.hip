@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   // loop: wave-private V tiles (tr-read images, 4 KB each); afterwards the same memory carries (O0, O1, m, l) of waves 1..3.
   // 26 KB per workgroup and <= 128 registers: four workgroups per CU, so one workgroup's prologue / merge (dependent
   // global loads, a barrier) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
-  __shared__ __attribute__((aligned(16))) float smem[NW2 * 2 * 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 25.5)
+  __shared__ __attribute__((aligned(16))) float smem[NW2 * 2 * 32 * HD / 2 + 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 25.5) + 4 KB: the Q tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
@@ -175,9 +175,14 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
   const uint32_t ld24 = (uint32_t)p.ld;
 
-  bf16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Q + (long)qc * p.ldq + 16 * s + 8 * hh);
+  // the workgroup's Q tile: fetched once, row-contiguous (wave w brings rows 8w .. 8w+7), parked in LDS behind the waves'
+  // K / V tiles; every wave takes its B fragments from there after the barrier below
+  bf16* Qs = (bf16*)(smem + NW2 * 2 * 32 * HD / 2);
+  {
+    const int trow = 8 * wid + (lane >> 3), tch = (lane & 7) * 8;
+    const u32x4 qv = *(const u32x4*)(Q + __umul24((uint32_t)min(q0 + trow, Nq - 1), (uint32_t)p.ldq) + tch);
+    *(u32x4*)(Qs + uswz(trow, tch)) = qv;
+  }
   const QLimits L = q_limits_mg(qc, p);
   SubList tl;
   tl.nT = (int)(rec >> 10) & 1023; tl.nM = (int)(rec >> 20) & 1023; tl.rc0 = (int)(rec >> 30) & 1023;
@@ -211,6 +216,10 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   };
   int pos = wid;
   if (pos < tl.nT) load_kv(tile_of(pos));
+  __syncthreads();
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qs + uswz(r32, (2 * s + hh) * 8));
   while (pos < tl.nT) {
     const int k0 = tile_of(pos) * 32;
     const int nxt = pos + NW2;
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   W2VS_PIN_ATTNP(p);
   W2VS_PIN_ATTNP_BWD(p);
   // loop: wave-private K tiles (tr-read images); afterwards the partial dQ of waves 1..3 (24 KB)
-  __shared__ __attribute__((aligned(16))) float red_mem[NW2 * 2 * 32 * HD / 2];   // 32 KB: K and V tile per wave; the merge needs 24
+  __shared__ __attribute__((aligned(16))) float red_mem[NW2 * 2 * 32 * HD / 2 + 3 * 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 24) + 12 KB: the Q, dO, O tiles
   float (*red)[32][64] = (float (*)[32][64])red_mem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -360,11 +369,19 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   const bf16* dO = p.dout + (long)b * p.sbo + h * HD;
   const uint8_t* kp = p.kpad ? p.kpad + (long)b * N : nullptr;
   const uint32_t ld24 = (uint32_t)p.ld;
-  bf16x8 qf[4], dof[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    qf[s] = *(const bf16x8*)(Q + (long)qc * p.ldq + 16 * s + 8 * hh);
-    dof[s] = *(const bf16x8*)(dO + (long)qc * p.ldo + 16 * s + 8 * hh);
+  // the workgroup's Q, dO and O tiles: fetched once, row-contiguous (wave w brings rows 8w .. 8w+7 of each), parked in LDS
+  // behind the waves' K / V tiles; every wave takes its fragments from there (before: four waves x twelve loads in the
+  // one-row-per-lane operand layout - twice the address-unit time of the loop's loads)
+  bf16* QDO = (bf16*)(red_mem + NW2 * 2 * 32 * HD / 2);
+  {
+    const int trow = 8 * wid + (lane >> 3), tch = (lane & 7) * 8;
+    const uint32_t row = (uint32_t)min(q0 + trow, Nq - 1);
+    const u32x4 qv = *(const u32x4*)(Q + __umul24(row, (uint32_t)p.ldq) + tch);
+    const u32x4 dv = *(const u32x4*)(dO + __umul24(row, (uint32_t)p.ldo) + tch);
+    const u32x4 ov = *(const u32x4*)(p.o + (long)b * p.sbo + h * HD + __umul24(row, (uint32_t)p.ldo) + tch);
+    *(u32x4*)(QDO + uswz(trow, tch)) = qv;
+    *(u32x4*)(QDO + 32 * HD + uswz(trow, tch)) = dv;
+    *(u32x4*)(QDO + 2 * 32 * HD + uswz(trow, tch)) = ov;
   }
   // the first sub-tile's K / V loads go out before anything waits: the delta below needs a round trip of its own (O rows)
   SubList tl;
@@ -386,15 +403,16 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   if (pos < tl.nT) load_kv(tile_of(pos));
   const long sidx = ((long)(b * p.H + h)) * p.Ns + qc;
   const float lse2 = p.lse[sidx] * LOG2E;
+  __syncthreads();
+  bf16x8 qf[4], dof[4];
   float delta = 0.f;
-  {
-    const bf16* Orow = p.o + (long)b * p.sbo + (long)qc * p.ldo + h * HD;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 ov = *(const bf16x8*)(Orow + 16 * s + 8 * hh);
+  for (int s = 0; s < 4; ++s) {
+    qf[s] = *(const bf16x8*)(QDO + uswz(r32, (2 * s + hh) * 8));
+    dof[s] = *(const bf16x8*)(QDO + 32 * HD + uswz(r32, (2 * s + hh) * 8));
+    const bf16x8 ov = *(const bf16x8*)(QDO + 2 * 32 * HD + uswz(r32, (2 * s + hh) * 8));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) delta = fmaf(bf2f(ov[e]), bf2f(dof[s][e]), delta);
-    }
+    for (int e = 0; e < 8; ++e) delta = fmaf(bf2f(ov[e]), bf2f(dof[s][e]), delta);
   }
   delta += other_half(delta);
   if (wid == 0 && q < Nq && hh == 0) const_cast<float*>(p.delta)[sidx] = delta;
@@ -525,11 +543,16 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   const float* lse_bh = p.lse + (long)bh * p.Ns;
   const float* delta_bh = p.delta + (long)bh * p.Ns;
   const bool key_ok = key < N && !(p.kpad && p.kpad[(long)b * N + key]);
-  bf16x8 kf[4], vf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    kf[s] = *(const bf16x8*)(K + (long)keyc * p.ld + 16 * s + 8 * hh);
-    vf[s] = *(const bf16x8*)(V + (long)keyc * p.ld + 16 * s + 8 * hh);
+  // the workgroup's K / V tile: fetched ONCE, row-contiguous (wave w brings rows 8w .. 8w+7), parked in LDS, and every wave
+  // takes its MFMA fragments from there (before: four waves x eight loads in the one-row-per-lane operand layout - as much
+  // address-unit time as the whole loop's loads)
+  bf16* KVs = (bf16*)(smem + 9216);       // behind the waves' tiles and query vectors: K tile, then V tile (4 KB each)
+  {
+    const int trow = 8 * wid + (lane >> 3), tch = (lane & 7) * 8;
+    const uint32_t off = __umul24((uint32_t)min(kb0 + trow, N - 1), (uint32_t)p.ld) + tch;
+    const u32x4 kv = *(const u32x4*)(K + off), vv = *(const u32x4*)(V + off);
+    *(u32x4*)(KVs + uswz(trow, tch)) = kv;
+    *(u32x4*)(KVs + 32 * HD + uswz(trow, tch)) = vv;
   }
   const float c = p.scale * LOG2E;
   const uint32_t thr = DM ? p.thr16 : 0u;
@@ -568,6 +591,13 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   };
   int pos = wid;
   if (pos < ql.nT) gload(tile_of(pos));
+  __syncthreads();
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf[s] = *(const bf16x8*)(KVs + uswz(r32, (2 * s + hh) * 8));
+    vf[s] = *(const bf16x8*)(KVs + 32 * HD + uswz(r32, (2 * s + hh) * 8));
+  }
   while (pos < ql.nT) {
     const int q0 = tile_of(pos) * 32;
     const int nxt = pos + NW2;
