@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   const uint32_t dbase = (uint32_t)(b * p.H + h) * (uint32_t)p.Ns;
   const uint32_t khalf = (uint32_t)keyc >> 1, kodd = (uint32_t)keyc & 1u;
   const uint32_t stepK = Nh * HASH_K;
+  const uint32_t lane_rows = (uint32_t)(lane & 1) * 2u;
   const bool keys_clean = __all(key_ok);
   SubList ql;
   ql.nT = (int)(rec >> 10) & 1023; ql.nM = (int)(rec >> 20) & 1023; ql.rc0 = (int)(rec >> 30) & 1023;
@@ -639,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
     const uint32_t wbits = bits_now >> (4 * hh);      // bit (i&3) + 8(i>>2) = query row of accumulator element i
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     const uint32_t wsub = ((dbase + (uint32_t)(q0 + 4 * hh)) * Nh + khalf) * HASH_K;
+    const uint32_t wsub_l = wsub + lane_rows * stepK;      // this lane's share of the hashing starts at row 0 or 2 of each group
     f32x16 Pd;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -659,6 +661,18 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
           pe[e] = ok ? v : 0.f;
         }
       }
+      // The two lanes of a key pair (keys 2j, 2j+1: lanes l, l^1) need the SAME words - a word covers the pair - and only
+      // test different halves.  Each hashes half of them (even lane: rows e = 0, 1 of the group of four; odd lane: e = 2, 3)
+      // and reads the other half from its neighbour through DPP: 8 hashes per sub-tile instead of 16.
+      uint32_t hw4[4] = {0u, 0u, 0u, 0u};
+      if (DM == 1) {
+        const uint32_t h0 = pair_hash_pm(s0, s1, wsub_l + (uint32_t)(8 * g4) * stepK);
+        const uint32_t h1 = pair_hash_pm(s0, s1, wsub_l + (uint32_t)(8 * g4 + 1) * stepK);
+        hw4[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0xA0, 0xF, 0xF, false);   // quad_perm [0,0,2,2]: the even lane's
+        hw4[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0xA0, 0xF, 0xF, false);
+        hw4[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0xF5, 0xF, 0xF, false);   // quad_perm [1,1,3,3]: the odd lane's
+        hw4[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0xF5, 0xF, 0xF, false);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g4 + e;
@@ -666,8 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
         if (DM) {
           if (DM == 2) km = (int)(wbits & (1u << ((i & 3) + 8 * (i >> 2))));
           else {           // word ((dbase + query) * Nh + key / 2): consecutive rows are stepK apart
-            const uint32_t hw = pair_hash_pm(s0, s1, wsub + (uint32_t)(8 * g4 + e) * stepK);
-            km = ((kodd ? (hw >> 16) : (hw & 0xFFFFu)) >= thr) ? -1 : 0;
+            km = ((kodd ? (hw4[e] >> 16) : (hw4[e] & 0xFFFFu)) >= thr) ? -1 : 0;
           }
         }
         // 1/(1-p) multiplies dV once at the end; inside dS it rides in the fma
