@@ -298,7 +298,7 @@ def _dense_attention(qkv, H, Tp, m, r, kpad):
 
 
 @pytest.mark.parametrize("Tp,m,r,H", [(48, 16, 8, 2), (50, 8, 4, 3), (130, 32, 16, 2), (546, 16, 8, 2), (40, 8, 0, 1),
-                                      (10, 16, 8, 1), (300, 24, 6, 2)])
+                                      (10, 16, 8, 1), (300, 24, 6, 2), (97, 7, 3, 1), (200, 13, 5, 2), (64, 1, 1, 1)])
 def test_block_attention(ops, Tp, m, r, H):
     B = 2
     N = Tp + (Tp // m) * r
