@@ -441,9 +441,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
   load_row(p.g, C, lane, g);
   load_row(p.b, C, lane, b);
   float sq = 0.f;
+  // two or three rows per wave (ln_fwd caps the grid): the raw bf16 bits of the NEXT row (and of its residual) are in flight
+  // while this one is reduced, and gamma / beta are fetched once per wave instead of once per row
+  RawRow nx, nres;
+  if (wave_id < p.rows) {
+    load_raw(p.x + (long)wave_id * C, C, lane, nx);
+    if (p.res) load_raw(p.res + (long)wave_id * C, C, lane, nres);
+  }
   for (long row = wave_id; row < p.rows; row += nwaves) {
-    Row x;
-    load_row(p.x + row * C, C, lane, x);
+    Row x, rr;
+    unpack_row(nx, x);
+    if (p.res) unpack_row(nres, rr);
+    if (row + nwaves < p.rows) {
+      load_raw(p.x + (row + nwaves) * C, C, lane, nx);
+      if (p.res) load_raw(p.res + (row + nwaves) * C, C, lane, nres);
+    }
     if (p.sumsq) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -454,12 +466,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
       drop_row(D, row, C, lane, x);
     }
     if (p.res) {
-      Row r;
-      load_row(p.res + row * C, C, lane, r);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x.v[h][e] += r.v[h][e];
+        for (int e = 0; e < 8; ++e) x.v[h][e] += rr.v[h][e];
     }
     if (p.sum_out) {
       store_row(p.sum_out + row * C, C, lane, x);
@@ -664,7 +674,8 @@ int ln_fwd(const LnFwdDesc& d, hipStream_t st) {
   if (!p.x || !p.g || !p.b) return set_error("ln_fwd: null pointer");
   if (p.y && !p.mean) return set_error("ln_fwd: mean/rstd buffers required");
   if (int e = ln_check(p, "ln_fwd")) return e;
-  int grid = (int)std::min<long>((p.rows + 3) / 4, 256 * 8);
+  static const int cap = getenv("W2VS_LN_FWD_GRID") ? atoi(getenv("W2VS_LN_FWD_GRID")) : 256 * 4;   // ~1.6 rows per wave at the encoder size: measured best of 512 / 768 / 1024 / 2048
+  int grid = (int)std::min<long>((p.rows + 3) / 4, cap);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "ln_fwd");
 }
