@@ -1294,6 +1294,9 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   const bool wide = (lc_h == 1160) || (wide_auto && lc_h == 160 && lc_env <= 0 && g_force_lc_h <= 0 && mode_env < 0 && g_force_nt_mode < 0);
   if (wide) { lc_h = 160; if (mode != 3 && mode != 5 && mode != 6) return set_error("gemm_nt: the 160 x 256 tile exists for the loader/consumer kernels only"); }
   if (lc_h != 256 && lc_h != 192 && lc_h != 160) return set_error("gemm_nt: tile height must be 256, 192 or 160");
+  static const bool nt_log = getenv("W2VS_GEMM_LOG") != nullptr;      // shapes and the form chosen for them, one line per launch
+  if (nt_log) fprintf(stderr, "gemm_nt M %d N %d K %d batch %d epi %d lda %ld -> mode %d tile %dx%d\n", d.M, d.N, d.K, (int)d.batch, d.epi,
+                      (long)d.lda, mode, mode >= 3 ? lc_h : 128, wide ? 256 : 128);
   const dim3 grid8((d.N + (wide ? 255 : 127)) / (wide ? 256 : 128), (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
