@@ -254,8 +254,10 @@ def test_streamed_adam_equals_single_launch(update_freq):
         res.append((step.flat.p32.clone(), step.flat.m.clone(), step.flat.v.clone(), step.flat.p16.clone(), losses))
         ops.ARENA.deactivate()
     (p1, m1, v1, q1, l1), (p2, m2, v2, q2, l2) = res
-    # the first update is bitwise identical; the second differs only through fp32-atomic ordering in the weight gradients
-    assert l1[:update_freq] == l2[:update_freq]
+    # before the first update the two runs compute the same thing; the scalar loss is summed with float atomics across blocks
+    # (ce_kernel), so it may differ in the last bit from run to run (seen: 316.89401 vs 316.89404) - compare to 1e-6, not bitwise
+    for a, b in zip(l1[:update_freq], l2[:update_freq]):
+        assert abs(a - b) <= 1e-6 * abs(a), (a, b)
     assert float((p1.double() - p2.double()).abs().max()) < 2e-5
     assert float((m1.double() - m2.double()).norm() / m1.double().norm()) < 2e-4
     assert abs(l1[-1] - l2[-1]) / abs(l1[-1]) < 1e-4
