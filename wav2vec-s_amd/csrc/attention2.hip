@@ -11,11 +11,19 @@
 //                       round-robin, each with its own online-softmax state, and merge (m, l, O) / sum dQ through LDS;
 //   dK/dV pass        : workgroup = 32 keys; its 4 waves take the visible 32-query sub-tiles round-robin, dK / dV summed
 //                       through LDS.
-// Workgroups are launched longest-first (host-made order table), so the tail of the launch is made of the short ones.
-// A wave never waits for another inside its loop: K / V (or Q / dO) fragments come straight from global memory into
-// MFMA operand registers, the one operand that must be transposed goes through a wave-private LDS tile
-// (ds_read_b64_tr_b16) - no barrier until the final merge.  The next sub-tile's loads are issued before the current
-// one is computed (two register sets).
+// Workgroups are launched longest-first (host-made record table, which also carries each tile's sub-tile list), so the tail
+// of the launch is made of the short ones.  A wave never waits for another inside its loop - one barrier after the
+// workgroup's shared operand tile is parked, one before the final merge.
+//
+// Data path (the second thing this file is about): EVERY operand row travels global -> registers -> an LDS tile -> MFMA
+// operand, and every global load is row-contiguous (8 lanes x 16 B per row, 8 rows per instruction).  The first version
+// loaded K / V (Q / dO) fragments straight into the MFMA operand layout - one row per lane, 32 rows x 32 B per instruction -
+// which costs the vector-memory address path four lines per quad of lanes instead of one; that, not VALU work, occupancy or
+// prologue length, was what those kernels waited on (a timing-only build with row-contiguous addresses ran the
+// backward 13 % faster, the reworked kernels 127 -> 100 us).  Per-workgroup tiles (Q; Q, dO, O; K, V) are fetched ONCE by the
+// four waves together; per-sub-tile operands go through wave-private 4 KB tiles whose swizzle (uswz) is conflict-free for
+// the row writes, the ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads.  One register set: the next
+// sub-tile's loads are issued as soon as the current tiles sit in LDS.
 #include <algorithm>
 #include <vector>
 #include "attn_common.h"
@@ -157,7 +165,7 @@ template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mas
 __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   AttnP p = pp.a;
   W2VS_PIN_ATTNP(p);
-  // loop: wave-private V tiles (tr-read images, 4 KB each); afterwards the same memory carries (O0, O1, m, l) of waves 1..3.
+  // loop: a V and a K tile per wave (4 KB each) + the workgroup's Q tile; afterwards the first 25.5 KB carry (O0, O1, m, l) of waves 1..3.
   // 26 KB per workgroup and <= 128 registers: four workgroups per CU, so one workgroup's prologue / merge (dependent
   // global loads, a barrier) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
   __shared__ __attribute__((aligned(16))) float smem[NW2 * 2 * 32 * HD / 2 + 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 25.5) + 4 KB: the Q tile
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   AttnP p = pp.a;
   W2VS_PIN_ATTNP(p);
   W2VS_PIN_ATTNP_BWD(p);
-  // loop: wave-private K tiles (tr-read images); afterwards the partial dQ of waves 1..3 (24 KB)
+  // loop: a K and a V tile per wave + the workgroup's Q / dO / O tiles; afterwards the partial dQ of waves 1..3 (24 KB)
   __shared__ __attribute__((aligned(16))) float red_mem[NW2 * 2 * 32 * HD / 2 + 3 * 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 24) + 12 KB: the Q, dO, O tiles
   float (*red)[32][64] = (float (*)[32][64])red_mem;
   const int tid = threadIdx.x, lane = tid & 63;
