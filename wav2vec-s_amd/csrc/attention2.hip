@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   AttnP p = pp.a;
   W2VS_PIN_ATTNP(p);
   // loop: a V and a K tile per wave (4 KB each) + the workgroup's Q tile; afterwards the first 25.5 KB carry (O0, O1, m, l) of waves 1..3.
-  // 26 KB per workgroup and <= 128 registers: four workgroups per CU, so one workgroup's prologue / merge (dependent
-  // global loads, a barrier) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
+  // 36 KB per workgroup and ~150 registers: three workgroups per CU, so one workgroup's prologue / merge (dependent global
+  // loads, two barriers) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
   __shared__ __attribute__((aligned(16))) float smem[NW2 * 2 * 32 * HD / 2 + 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 25.5) + 4 KB: the Q tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
