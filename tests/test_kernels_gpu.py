@@ -323,6 +323,22 @@ def test_block_attention(ops, Tp, m, r, H):
         assert e < 1.5e-2, (name, e)
 
 
+def test_block_attention_beyond_8192_positions_takes_the_first_kernels(ops):
+    """attention2.hip's record table holds 256 tiles (N <= 8192); longer sequences run attention.hip's kernels behind the same
+    entry.  Forward only against the dense reference (the 8244^2 score matrix is built once, on the GPU in fp32)."""
+    Tp, m, r, H, B = 5500, 16, 8, 1, 1
+    N = Tp + (Tp // m) * r
+    assert N > 8192
+    qkv = rnd(B, N, 3 * H * 64, seed=11)
+    o, lse = ops.attn_fwd(dev(qkv), H, Tp, m, r)
+    _, _, masked = O.block_structure(Tp, m, r)
+    q, k, v = dev(qkv).float().split(64 * H, dim=-1)
+    s = (q[0] * 0.125) @ k[0].t() + torch.zeros(N, N, device="cuda").masked_fill(masked.cuda(), -1e4)
+    ref = torch.softmax(s, dim=-1) @ v[0]
+    assert rel(o[0], ref) < 8e-3
+    assert torch.isfinite(lse).all()
+
+
 @pytest.mark.parametrize("Tp,m,r,H,nq", [(130, 32, 16, 2, 0), (546, 16, 8, 3, 0), (300, 24, 6, 2, 300)])
 def test_attention_stored_keep_masks_equal_rehash(ops, Tp, m, r, H, nq):
     """w2vs_attn_desc.drop_bits: the forward parks its dropout decisions as bits, the backward reads them instead of
