@@ -1253,9 +1253,12 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
                     ((uintptr_t)d.C2 % 16) == 0 && ((uintptr_t)d.aux % 16) == 0 && (d.sC % 8) == 0;
   static const int conv_p_env = [] { const char* e = getenv("W2VS_CONV_PERSIST"); return e ? atoi(e) : 1; }();
   bool wide_auto = false;
-  if (mode == 1 && p_ok && conv_p_env) {
+  static const int conv_model_env = [] { const char* e = getenv("W2VS_CONV_TILE_MODEL"); return e ? atoi(e) : 1; }();   // 0: 256 x 128 on the conv grids (A/B)
+  if (mode == 1 && p_ok && conv_p_env && (d.N < 256 || !conv_model_env)) {
     mode = 5;
-  } else if (mode == 2 && p_ok && conv_p_env && ntiles >= 256 && d.N >= 256) {
+  } else if ((mode == 1 || mode == 2) && p_ok && conv_p_env && ntiles >= 256 && d.N >= 256) {
+    // (the huge conv grids too: 160 x 256 tiles run conv1 forward 267 -> 205 us, with GELU + saved gelu' 319 -> 255, conv2
+    // forward 158 -> 135, conv1 dgrad 372 -> 345 against the 256 x 128 tiles they used to get unconditionally)
     // Round 2: at least a chip's worth of output -> the PERSISTENT loader/consumer kernel (register-direct epilogue, the DMA ring
     // keeps running across tile boundaries) with the tile shape that minimises rounds x (rows + columns) - the staged bytes per
     // K step set the step time (~36 GB/s per CU with every CU streaming), the rounds of 256 workgroups the number of K loops.
