@@ -28,7 +28,8 @@ def t_us(fn, iters=30):
 R = 6544
 g = torch.Generator(device="cuda").manual_seed(0)
 SHAPES = (("fc1 fwd", 3072, 768), ("qkv fwd", 2304, 768), ("fc2 fwd", 768, 3072), ("out fwd", 768, 768),
-          ("conv1 fwd", 512, 1536, 140000), ("conv1 dgrad", 1024, 1024, 140000), ("conv2 fwd", 512, 1536, 70000))
+          ("conv1 fwd", 512, 1536, 140000), ("conv1 dgrad", 1024, 1024, 140000), ("conv2 fwd", 512, 1536, 70000),
+          ("last fc2", 768, 3072, 2080), ("last fc1", 3072, 768, 2080), ("last out", 768, 768, 2080), ("conv4 fwd", 512, 1536, 17500), ("conv5 fwd", 512, 1024, 8744))
 if len(sys.argv) > 1:
     SHAPES = tuple(s for s in SHAPES if s[0].split()[0] in sys.argv[1:])
 for name, N, K, *rest in SHAPES:

@@ -1278,12 +1278,17 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   } else if (mode == 2) {
     const double nkt = (d.K + BK - 1) / BK;
     const long nbz = d.batch > 0 ? d.batch : 1;
-    double best = 0.95 * (double)((ntiles + 255) / 256) * (nkt * 0.47 + 2.8);
+    // Below one workgroup per CU the 128^2 kernel has no co-resident partner to overlap its loads with (0.8 us per K tile
+    // measured on 102 tiles x 48 K tiles, against 0.47 with two per CU), while the loader/consumer kernels speed up with
+    // fewer CUs streaming (0.40 us per K tile for 78 workgroups of 160 rows): the last layer's pruned fc2 forward /
+    // fc1 dgrad (2080 x 768 x 3072) ran 39 us on the former and 26.5 us on the latter.
+    double best = 0.95 * (double)((ntiles + 255) / 256) * (nkt * (ntiles <= 256 ? 0.8 : 0.47) + 2.8);
     const int hs[3] = {256, 192, 160};
     const double tk[3] = {0.74, 0.71, 0.62};
     for (int c = 0; c < 3; ++c) {
       const long t8 = (long)((d.N + 127) / 128) * ((d.M + hs[c] - 1) / hs[c]) * nbz;
-      const double t = (double)((t8 + 255) / 256) * (nkt * tk[c] + 7.5 + (epi_is_save(d.epi) ? 4.0 : 0.0));
+      const double fill = t8 >= 256 ? 1.0 : std::max(0.6, (double)t8 / 256.0);
+      const double t = (double)((t8 + 255) / 256) * (nkt * tk[c] * fill + 7.5 + (epi_is_save(d.epi) ? 4.0 : 0.0));
       if (t < best) { best = t; mode = 3; lc_h = hs[c]; }
     }
   }
