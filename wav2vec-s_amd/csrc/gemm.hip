@@ -1366,6 +1366,8 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
     bool use_lc = tiles8 >= 16 && tiles8 <= ncu && d.sC == 0;
     if (tn_lc_env >= 0) use_lc = tn_lc_env != 0;
     if (g_force_tn_lc >= 0) use_lc = g_force_tn_lc != 0 && d.sC == 0;
+    static const bool tn_log = getenv("W2VS_GEMM_LOG") != nullptr;
+    if (tn_log) fprintf(stderr, "gemm_tn M %d N %d K %d batch %d -> %s (%d tiles of 256x128)\n", d.M, d.N, d.K, nb, use_lc ? "loader/consumer" : "128^2 atomics", tiles8);
     if (use_lc) {
       int splits = std::max(1, ncu / tiles8);
       const int max_splits = (d.K + TK - 1) / TK;
