@@ -161,14 +161,14 @@ __device__ __forceinline__ uint32_t* bits_block(const AttnP& p, int bh, int qt, 
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
-__global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
+template <int DM, int NW>   // DM dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits); NW waves
+__global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
   AttnP p = pp.a;
   W2VS_PIN_ATTNP(p);
   // loop: a V and a K tile per wave (4 KB each) + the workgroup's Q tile; afterwards the first 25.5 KB carry (O0, O1, m, l) of waves 1..3.
   // 36 KB per workgroup and ~150 registers: three workgroups per CU, so one workgroup's prologue / merge (dependent global
   // loads, two barriers) is covered by the loops of the others - with ~3 sub-tiles per wave those ends are not small.
-  __shared__ __attribute__((aligned(16))) float smem[NW2 * 2 * 32 * HD / 2 + 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 25.5) + 4 KB: the Q tile
+  __shared__ __attribute__((aligned(16))) float smem[NW * 2 * 32 * HD / 2 + 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 25.5) + 4 KB: the Q tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
@@ -185,11 +185,15 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
 
   // the workgroup's Q tile: fetched once, row-contiguous (wave w brings rows 8w .. 8w+7), parked in LDS behind the waves'
   // K / V tiles; every wave takes its B fragments from there after the barrier below
-  bf16* Qs = (bf16*)(smem + NW2 * 2 * 32 * HD / 2);
+  bf16* Qs = (bf16*)(smem + NW * 2 * 32 * HD / 2);
   {
-    const int trow = 8 * wid + (lane >> 3), tch = (lane & 7) * 8;
-    const u32x4 qv = *(const u32x4*)(Q + __umul24((uint32_t)min(q0 + trow, Nq - 1), (uint32_t)p.ldq) + tch);
-    *(u32x4*)(Qs + uswz(trow, tch)) = qv;
+    const int tch = (lane & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 4 / NW; ++j) {
+      const int trow = (32 / NW) * wid + 8 * j + (lane >> 3);
+      const u32x4 qv = *(const u32x4*)(Q + __umul24((uint32_t)min(q0 + trow, Nq - 1), (uint32_t)p.ldq) + tch);
+      *(u32x4*)(Qs + uswz(trow, tch)) = qv;
+    }
   }
   const QLimits L = q_limits_mg(qc, p);
   SubList tl;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qs + uswz(r32, (2 * s + hh) * 8));
   while (pos < tl.nT) {
     const int k0 = tile_of(pos) * 32;
-    const int nxt = pos + NW2;
+    const int nxt = pos + NW;
     // one register set: the V registers are free again once they sit in LDS, the K registers once S is issued - the next
     // sub-tile's loads go out right there and have the softmax and the P.V product to land
     asm volatile("" ::: "memory");
@@ -318,16 +322,16 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
   }
   __syncthreads();
   if (wid != 0) return;
-  float mw[NW2 - 1], mall = mrun;
+  float mw[NW - 1], mall = mrun;
 #pragma unroll
-  for (int w = 0; w < NW2 - 1; ++w) { mw[w] = smem[(w * 34 + 32) * 64 + lane]; mall = fmaxf(mall, mw[w]); }
+  for (int w = 0; w < NW - 1; ++w) { mw[w] = smem[(w * 34 + 32) * 64 + lane]; mall = fmaxf(mall, mw[w]); }
   const float mref = (mall == -INFINITY) ? 0.f : mall;
   const float a0s = fast_exp2(mrun - mref);
   ltot *= a0s;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { O0[i] *= a0s; O1[i] *= a0s; }
 #pragma unroll
-  for (int w = 0; w < NW2 - 1; ++w) {
+  for (int w = 0; w < NW - 1; ++w) {
     const float* rw = smem + w * 34 * 64;
     const float aw = fast_exp2(mw[w] - mref);
     ltot = fmaf(rw[33 * 64 + lane], aw, ltot);
@@ -355,13 +359,13 @@ __global__ __launch_bounds__(256, 3) void attn2_fwd_kernel(Attn2P pp) {
 //   S^T = K Q^T ; P^T = exp(S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T o drop - delta)
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]           (scale applied once at the end)
 // =================================================================================================
-template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
-__global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
+template <int DM, int NW>
+__global__ __launch_bounds__(NW * 64, 3) void attn2_dq_kernel(Attn2P pp) {
   AttnP p = pp.a;
   W2VS_PIN_ATTNP(p);
   W2VS_PIN_ATTNP_BWD(p);
   // loop: a K and a V tile per wave + the workgroup's Q / dO / O tiles; afterwards the partial dQ of waves 1..3 (24 KB)
-  __shared__ __attribute__((aligned(16))) float red_mem[NW2 * 2 * 32 * HD / 2 + 3 * 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 24) + 12 KB: the Q, dO, O tiles
+  __shared__ __attribute__((aligned(16))) float red_mem[NW * 2 * 32 * HD / 2 + 3 * 32 * HD / 2];   // 32 KB: a K and a V tile per wave (the merge needs 24) + 12 KB: the Q, dO, O tiles
   float (*red)[32][64] = (float (*)[32][64])red_mem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -380,16 +384,20 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   // the workgroup's Q, dO and O tiles: fetched once, row-contiguous (wave w brings rows 8w .. 8w+7 of each), parked in LDS
   // behind the waves' K / V tiles; every wave takes its fragments from there (before: four waves x twelve loads in the
   // one-row-per-lane operand layout - twice the address-unit time of the loop's loads)
-  bf16* QDO = (bf16*)(red_mem + NW2 * 2 * 32 * HD / 2);
+  bf16* QDO = (bf16*)(red_mem + NW * 2 * 32 * HD / 2);
   {
-    const int trow = 8 * wid + (lane >> 3), tch = (lane & 7) * 8;
-    const uint32_t row = (uint32_t)min(q0 + trow, Nq - 1);
-    const u32x4 qv = *(const u32x4*)(Q + __umul24(row, (uint32_t)p.ldq) + tch);
-    const u32x4 dv = *(const u32x4*)(dO + __umul24(row, (uint32_t)p.ldo) + tch);
-    const u32x4 ov = *(const u32x4*)(p.o + (long)b * p.sbo + h * HD + __umul24(row, (uint32_t)p.ldo) + tch);
-    *(u32x4*)(QDO + uswz(trow, tch)) = qv;
-    *(u32x4*)(QDO + 32 * HD + uswz(trow, tch)) = dv;
-    *(u32x4*)(QDO + 2 * 32 * HD + uswz(trow, tch)) = ov;
+    const int tch = (lane & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 4 / NW; ++j) {
+      const int trow = (32 / NW) * wid + 8 * j + (lane >> 3);
+      const uint32_t row = (uint32_t)min(q0 + trow, Nq - 1);
+      const u32x4 qv = *(const u32x4*)(Q + __umul24(row, (uint32_t)p.ldq) + tch);
+      const u32x4 dv = *(const u32x4*)(dO + __umul24(row, (uint32_t)p.ldo) + tch);
+      const u32x4 ov = *(const u32x4*)(p.o + (long)b * p.sbo + h * HD + __umul24(row, (uint32_t)p.ldo) + tch);
+      *(u32x4*)(QDO + uswz(trow, tch)) = qv;
+      *(u32x4*)(QDO + 32 * HD + uswz(trow, tch)) = dv;
+      *(u32x4*)(QDO + 2 * 32 * HD + uswz(trow, tch)) = ov;
+    }
   }
   // the first sub-tile's K / V loads go out before anything waits: the delta below needs a round trip of its own (O rows)
   SubList tl;
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
   while (pos < tl.nT) {
     const int k0 = tile_of(pos) * 32;
-    const int nxt = pos + NW2;
+    const int nxt = pos + NW;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(256, 3) void attn2_dq_kernel(Attn2P pp) {
   __syncthreads();
   if (wid != 0) return;
 #pragma unroll
-  for (int w = 0; w < NW2 - 1; ++w)
+  for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { D0[i] += red[w][i][lane]; D1[i] += red[w][16 + i][lane]; }
   if (q < Nq) {
@@ -797,6 +805,27 @@ static inline int drop_mode(const AttnP& p) { return p.thr16 == 0 ? 0 : (p.drop_
     case 1: hipLaunchKernelGGL(kern<1>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;         \
     default: hipLaunchKernelGGL(kern<2>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;        \
   }
+// forward / dQ pass: waves per workgroup.  Both kernels are bound by instruction issue, and a workgroup's prologue + merge are
+// about a third of its instructions: two waves instead of four halve that share - as long as the longest tile's sub-tile
+// list, now split two ways only, does not become the tail of the launch.  Measured (p = 0.1): N = 818 (longest list 26)
+// forward 33.4 -> 31.0 us, dQ pass -2 us; N = 1496 (longest 47) forward 35.3 -> 38.2 us.  W2VS_ATTN_NW=2|4 forces one.
+static const int g_attn_nw_env = [] { const char* e = getenv("W2VS_ATTN_NW"); return e ? atoi(e) : 0; }();
+#define W2VS_LAUNCH_DM_NW(kern, tiles)                                                                              \
+  const int longest_ = (int)(pp.rec[0] >> 10) & 1023;     /* the table is sorted longest first */                   \
+  const int nw_ = g_attn_nw_env == 2 || g_attn_nw_env == 4 ? g_attn_nw_env : (longest_ <= 32 ? 2 : 4);               \
+  if (nw_ == 2) {                                                                                              \
+    switch (drop_mode(p)) {                                                                                          \
+      case 0: hipLaunchKernelGGL((kern<0, 2>), dim3(p.B * p.H, tiles), dim3(128), 0, st, pp); break;                 \
+      case 1: hipLaunchKernelGGL((kern<1, 2>), dim3(p.B * p.H, tiles), dim3(128), 0, st, pp); break;                 \
+      default: hipLaunchKernelGGL((kern<2, 2>), dim3(p.B * p.H, tiles), dim3(128), 0, st, pp); break;                \
+    }                                                                                                                \
+  } else {                                                                                                           \
+    switch (drop_mode(p)) {                                                                                          \
+      case 0: hipLaunchKernelGGL((kern<0, 4>), dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;                 \
+      case 1: hipLaunchKernelGGL((kern<1, 4>), dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;                 \
+      default: hipLaunchKernelGGL((kern<2, 4>), dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;                \
+    }                                                                                                                \
+  }
 
 // (the multiply-high divisions are exact below 65536: positions, and the (batch, head) index;
 // and the 24-bit row-address products need strides below 2^24 and N * stride below 2^32)
@@ -812,7 +841,7 @@ int attn2_fwd(const AttnP& p, hipStream_t st) {
   pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32;
   query_tile_table(pp, p, nqt);
-  W2VS_LAUNCH_DM(attn2_fwd_kernel, nqt)
+  W2VS_LAUNCH_DM_NW(attn2_fwd_kernel, nqt)
   return hip_check(hipGetLastError(), "attn_fwd");
 }
 
@@ -822,7 +851,7 @@ int attn2_bwd(const AttnP& p, hipStream_t st) {
   pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32, nkt = (p.N + 31) / 32;
   query_tile_table(pp, p, nqt);
-  W2VS_LAUNCH_DM(attn2_dq_kernel, nqt)     // dq rows >= Nq are not written
+  W2VS_LAUNCH_DM_NW(attn2_dq_kernel, nqt)     // dq rows >= Nq are not written
   key_tile_table(pp, p, nkt);
   W2VS_LAUNCH_DM(attn2_dkv_kernel, nkt)
   return hip_check(hipGetLastError(), "attn_bwd");
