@@ -533,14 +533,16 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_dq_kernel(Attn2P pp) {
 //   S = Q K^T ; P = exp(S - lse[q]) ; dP = dO V^T ; dS = P o (dP o drop - delta[q])        (scale at the end, dK only)
 //   dV^T[d][key] += dO^T[d][q] (P o drop)[q][key]      dK^T[d][key] += Q^T[d][q] dS[q][key]
 // =================================================================================================
-template <int DM>   // dropout mode: 0 none, 1 hashed keep decisions, 2 keep-mask records (AttnP::drop_bits)
-__global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
+template <int DM, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn2_dkv_kernel(Attn2P pp) {
   AttnP p = pp.a;
   W2VS_PIN_ATTNP(p);
   W2VS_PIN_ATTNP_BWD(p);
   // during the loop: per wave a Q tile and a dO tile (tr-read images, 4 KB each) and five 32-entry query vectors;
   // afterwards the same memory carries the partial dK / dV of waves 1..3
-  __shared__ __attribute__((aligned(16))) float smem[(NW2 - 1) * 64 * 64];
+  constexpr int TILES_F = NW * 2 * 32 * HD / 2, KVS_F = TILES_F + ((NW * 160 + 255) / 256) * 256, LOOP_F = KVS_F + 2 * 32 * HD / 2;
+  constexpr int MERGE_F = (NW - 1) * 64 * 64;
+  __shared__ __attribute__((aligned(16))) float smem[LOOP_F > MERGE_F ? LOOP_F : MERGE_F];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   const int kb0 = kt * 32, key = kb0 + r32, keyc = min(key, N - 1);
   bf16* Qw = (bf16*)smem + wid * (2 * 32 * HD);
   bf16* Dw = Qw + 32 * HD;
-  float* qs = smem + (NW2 * 2 * 32 * HD) / 2 + wid * 160;       // lse, delta, lim, clo, chi of the sub-tile's 32 queries
+  float* qs = smem + (NW * 2 * 32 * HD) / 2 + wid * 160;       // lse, delta, lim, clo, chi of the sub-tile's 32 queries
   const bf16* Q = p.q + (long)b * p.sbq + h * HD;
   const bf16* K = p.k + (long)b * p.sb + h * HD;
   const bf16* V = p.v + (long)b * p.sb + h * HD;
@@ -562,13 +564,17 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   // the workgroup's K / V tile: fetched ONCE, row-contiguous (wave w brings rows 8w .. 8w+7), parked in LDS, and every wave
   // takes its MFMA fragments from there (before: four waves x eight loads in the one-row-per-lane operand layout - as much
   // address-unit time as the whole loop's loads)
-  bf16* KVs = (bf16*)(smem + 9216);       // behind the waves' tiles and query vectors: K tile, then V tile (4 KB each)
+  bf16* KVs = (bf16*)(smem + KVS_F);      // behind the waves' tiles and query vectors: K tile, then V tile (4 KB each)
   {
-    const int trow = 8 * wid + (lane >> 3), tch = (lane & 7) * 8;
-    const uint32_t off = __umul24((uint32_t)min(kb0 + trow, N - 1), (uint32_t)p.ld) + tch;
-    const u32x4 kv = *(const u32x4*)(K + off), vv = *(const u32x4*)(V + off);
-    *(u32x4*)(KVs + uswz(trow, tch)) = kv;
-    *(u32x4*)(KVs + 32 * HD + uswz(trow, tch)) = vv;
+    const int tch = (lane & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 4 / NW; ++j) {
+      const int trow = (32 / NW) * wid + 8 * j + (lane >> 3);
+      const uint32_t off = __umul24((uint32_t)min(kb0 + trow, N - 1), (uint32_t)p.ld) + tch;
+      const u32x4 kv = *(const u32x4*)(K + off), vv = *(const u32x4*)(V + off);
+      *(u32x4*)(KVs + uswz(trow, tch)) = kv;
+      *(u32x4*)(KVs + 32 * HD + uswz(trow, tch)) = vv;
+    }
   }
   const float c = p.scale * LOG2E;
   const uint32_t thr = DM ? p.thr16 : 0u;
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   }
   while (pos < ql.nT) {
     const int q0 = tile_of(pos) * 32;
-    const int nxt = pos + NW2;
+    const int nxt = pos + NW;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv_kernel(Attn2P pp) {
   __syncthreads();
   if (wid != 0) return;
 #pragma unroll
-  for (int w = 0; w < NW2 - 1; ++w) {
+  for (int w = 0; w < NW - 1; ++w) {
     const float* rw = smem + w * 64 * 64;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -853,7 +859,26 @@ int attn2_bwd(const AttnP& p, hipStream_t st) {
   query_tile_table(pp, p, nqt);
   W2VS_LAUNCH_DM_NW(attn2_dq_kernel, nqt)     // dq rows >= Nq are not written
   key_tile_table(pp, p, nkt);
-  W2VS_LAUNCH_DM(attn2_dkv_kernel, nkt)
+  {
+    static const int dkv_nw_env = [] { const char* e = getenv("W2VS_ATTN_DKV_NW"); return e ? atoi(e) : 0; }();
+    const int longest_k = (int)(pp.rec[0] >> 10) & 1023;
+    // two waves per workgroup: half the K / V staging, hand-over and merge instructions per key tile (measured: dQ + dK/dV
+    // 96.6 -> 89.8 us at N = 818, 99.6 -> 92.2 us at N = 1496); four once a key tile's query list gets long enough to be the tail
+    const int nwk = dkv_nw_env == 2 || dkv_nw_env == 4 ? dkv_nw_env : (longest_k <= 128 ? 2 : 4);
+    if (nwk == 2) {
+      switch (drop_mode(p)) {
+        case 0: hipLaunchKernelGGL((attn2_dkv_kernel<0, 2>), dim3(p.B * p.H, nkt), dim3(128), 0, st, pp); break;
+        case 1: hipLaunchKernelGGL((attn2_dkv_kernel<1, 2>), dim3(p.B * p.H, nkt), dim3(128), 0, st, pp); break;
+        default: hipLaunchKernelGGL((attn2_dkv_kernel<2, 2>), dim3(p.B * p.H, nkt), dim3(128), 0, st, pp); break;
+      }
+    } else {
+      switch (drop_mode(p)) {
+        case 0: hipLaunchKernelGGL((attn2_dkv_kernel<0, 4>), dim3(p.B * p.H, nkt), dim3(256), 0, st, pp); break;
+        case 1: hipLaunchKernelGGL((attn2_dkv_kernel<1, 4>), dim3(p.B * p.H, nkt), dim3(256), 0, st, pp); break;
+        default: hipLaunchKernelGGL((attn2_dkv_kernel<2, 4>), dim3(p.B * p.H, nkt), dim3(256), 0, st, pp); break;
+      }
+    }
+  }
   return hip_check(hipGetLastError(), "attn_bwd");
 }
 
