@@ -323,6 +323,29 @@ def test_block_attention(ops, Tp, m, r, H):
         assert e < 1.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("Tp,m,r", [(999, 16, 8), (3000, 16, 8)])
+def test_block_attention_long_lists_use_four_waves(ops, Tp, m, r):
+    """attention2.hip runs forward / dQ with 4 waves per workgroup once the longest sub-tile list exceeds 32 (N = 1495:
+    47) and the dK/dV pass with 4 once a key tile has more than 128 query sub-tiles (N = 4496: 141); the small shapes above
+    all take the 2-wave instantiations.  Forward and backward against dense fp32 autograd on the GPU."""
+    H, B = 1, 1
+    N = Tp + (Tp // m) * r
+    qkv = dev(rnd(B, N, 3 * 64, seed=Tp))
+    o, lse = ops.attn_fwd(qkv, H, Tp, m, r)
+    _, _, masked = O.block_structure(Tp, m, r)
+    add = torch.zeros(N, N, device="cuda").masked_fill(masked.cuda(), -1e4)
+    x = qkv[0].float().requires_grad_(True)
+    q, k, v = x.split(64, dim=-1)
+    ref = torch.softmax((q * 0.125) @ k.t() + add, dim=-1) @ v
+    assert rel(o[0], ref) < 8e-3
+    dout = dev(rnd(B, N, 64, seed=3))
+    ref.backward(dout[0].float())
+    dqkv = ops.attn_bwd(dout, qkv, o, lse, H, Tp, m, r)
+    for name, sl in [("dq", slice(0, 64)), ("dk", slice(64, 128)), ("dv", slice(128, 192))]:
+        e = rel(dqkv[0][..., sl], x.grad[..., sl])
+        assert e < 1.5e-2, (name, e)
+
+
 def test_block_attention_beyond_8192_positions_takes_the_first_kernels(ops):
     """attention2.hip's record table holds 256 tiles (N <= 8192); longer sequences run attention.hip's kernels behind the same
     entry.  Forward only against the dense reference (the 8244^2 score matrix is built once, on the GPU in fp32)."""
