@@ -31,7 +31,6 @@
 namespace w2vs {
 namespace {
 
-constexpr int NW2 = 4;       // waves per workgroup
 constexpr int MAXT2 = 256;   // 32-row tiles per sequence (N <= 8192; longer sequences take attention.hip)
 
 // One record per workgroup row of the launch, longest first, made on the host (make_table): the tile and its list of
@@ -805,12 +804,6 @@ static void key_tile_table(Attn2P& pp, const AttnP& p, int nkt) {
 // dropout mode of a launch: the kernels are compiled once per mode, so the no-dropout loop carries neither the hash nor
 // the branches around it
 static inline int drop_mode(const AttnP& p) { return p.thr16 == 0 ? 0 : (p.drop_bits ? 2 : 1); }
-#define W2VS_LAUNCH_DM(kern, tiles)                                                                   \
-  switch (drop_mode(p)) {                                                                              \
-    case 0: hipLaunchKernelGGL(kern<0>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;         \
-    case 1: hipLaunchKernelGGL(kern<1>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;         \
-    default: hipLaunchKernelGGL(kern<2>, dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;        \
-  }
 // forward / dQ pass: waves per workgroup.  Both kernels are bound by instruction issue, and a workgroup's prologue + merge are
 // about a third of its instructions: two waves instead of four halve that share - as long as the longest tile's sub-tile
 // list, now split two ways only, does not become the tail of the launch.  Measured (p = 0.1): N = 818 (longest list 26)
