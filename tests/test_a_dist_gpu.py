@@ -203,7 +203,9 @@ def test_load_state_dict_resyncs_master_and_optimizer_state_round_trips():
     for k, v in model_a.state_dict().items():
         if "pos_conv" in k:
             continue
-        assert float((v.float() - model_b.state_dict()[k].float()).abs().max()) <= 2e-2 * float(v.float().abs().max()) + 1e-6, k
+        # (what is checked is that the LOADED weights survived, i.e. agreement at the scale of the weights; a single update
+        # may differ by up to ~2 lr on a near-zero-gradient element, see _same_update)
+        assert float((v.float() - model_b.state_dict()[k].float()).abs().max()) <= 2e-2 * float(v.float().abs().max()) + 2.1e-3, k
     # optimizer state round trip: a third trainer resumes from (a) and takes the same second step
     osd = step_a.flat.state_dict()
     w, cfg, model_c, crit_c = _build(SMALL, seed=9)
