@@ -574,7 +574,8 @@ def test_transpose_multi(ops):
 
 # ------------------------------------------------------------------------------------------ GEMM kernel variants
 NT_VARIANTS = [(0, 0), (1, 0), (2, 0), (3, 256), (3, 192), (3, 160), (5, 256), (5, 192), (5, 160),
-               (3, 1160), (5, 1160), (-1, 0)]     # 1160 = the 160 x 256 tile (round 2); (-1, 0) = automatic choice
+               (3, 1160), (5, 1160), (8, 256), (8, 320), (-1, 0)]     # 1160 = the 160 x 256 tile (round 2); 8 = the 8-phase
+                                                                        # kernel (round 3; K % 64 == 0); (-1, 0) = automatic choice
 
 
 @pytest.mark.parametrize("mode,height", NT_VARIANTS)
@@ -584,7 +585,10 @@ def test_gemm_nt_every_variant(ops, mode, height):
     rows, batch, the 'row -1' dgrad operand)."""
     try:
         ops.gemm_tune(nt_mode=mode, lc_height=height)
-        for (M, N, K) in [(1000, 392, 200), (257, 128, 64), (6544, 768, 768), (130, 2304, 776), (1700, 3072, 136)]:
+        shapes = [(1000, 392, 200), (257, 128, 64), (6544, 768, 768), (130, 2304, 776), (1700, 3072, 136)]
+        if mode == 8:     # whole K tiles only: 1, 2, 3, 5 (odd: padded to a pair), 12 of them; ragged M / N; several tiles per workgroup
+            shapes = [(1000, 384, 192), (257, 128, 64), (6544, 768, 768), (130, 2304, 128), (1700, 3072, 320), (70000, 512, 64)]
+        for (M, N, K) in shapes:
             x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
             y = ops.linear_fwd(dev(x), dev(w), dev(b))
             ref = x.float() @ w.float().t() + b.float()

@@ -29,6 +29,7 @@ R = 6544
 g = torch.Generator(device="cuda").manual_seed(0)
 SHAPES = (("fc1 fwd", 3072, 768), ("qkv fwd", 2304, 768), ("fc2 fwd", 768, 3072), ("out fwd", 768, 768),
           ("conv1 fwd", 512, 1536, 140000), ("conv1 dgrad", 1024, 1024, 140000), ("conv2 fwd", 512, 1536, 70000),
+          ("sq4k fwd", 4096, 4096, 4096), ("sq8k fwd", 8192, 8192, 8192),
           ("last fc2", 768, 3072, 2080), ("last fc1", 3072, 768, 2080), ("last out", 768, 768, 2080), ("conv4 fwd", 512, 1536, 17500), ("conv5 fwd", 512, 1024, 8744))
 if len(sys.argv) > 1:
     SHAPES = tuple(s for s in SHAPES if s[0].split()[0] in sys.argv[1:])
@@ -39,7 +40,7 @@ for name, N, K, *rest in SHAPES:
     b = torch.randn(N, device="cuda", generator=g).to(BF)
     aux = torch.randn(R, N, device="cuda", generator=g).to(BF)
     ref = (x.float() @ w.float().t() + b.float())
-    for cfg_name, tune in (("default", (-1, 0)), ("128^2 dma", (2, 0)), ("lc 256x128", (3, 256)), ("lc 160x128", (3, 160)), ("lc 160x256", (3, 1160)), ("persist 256x128", (5, 256)), ("persist 192x128", (5, 192)), ("lc 192x128", (3, 192)), ("128^2 regs", (0, 0)), ("128^2 mode1", (1, 0)), ("persist 160x128", (5, 160)),
+    for cfg_name, tune in (("default", (-1, 0)), ("8ph 256x256", (8, 256)), ("8ph 320x256", (8, 320)), ("128^2 dma", (2, 0)), ("lc 256x128", (3, 256)), ("lc 160x128", (3, 160)), ("lc 160x256", (3, 1160)), ("persist 256x128", (5, 256)), ("persist 192x128", (5, 192)), ("lc 192x128", (3, 192)), ("128^2 regs", (0, 0)), ("128^2 mode1", (1, 0)), ("persist 160x128", (5, 160)),
                            ("persist 160x256", (5, 1160))):
         if tune[1] == 1160 and N % 256:
             continue

@@ -611,6 +611,21 @@ struct TileIter {   // tiles of one workgroup, in XCD-aware order: round r cover
   }
 };
 
+struct TileIter32 {   // the same order in 32-bit arithmetic (total tiles < 2^31): the 8-phase kernel calls it from its staging cursor
+  int G, slot, total, ntm, ntn;
+  __device__ __forceinline__ bool get(int r, int& bz, int& tm, int& tn) const {
+    const unsigned id = (unsigned)r * (unsigned)G + (unsigned)slot;
+    if (id >= (unsigned)total) return false;
+    const unsigned plane = (unsigned)(ntm * ntn), b = id / plane, t = id - b * plane, GM = 4;
+    const unsigned per_group = GM * (unsigned)ntn, group = t / per_group, first_m = group * GM;
+    const unsigned gsz = min((unsigned)ntm - first_m, GM), in_group = t - group * per_group, q = in_group / gsz;
+    bz = __builtin_amdgcn_readfirstlane((int)b);
+    tm = __builtin_amdgcn_readfirstlane((int)(first_m + in_group - q * gsz));
+    tn = __builtin_amdgcn_readfirstlane((int)q);
+    return true;
+  }
+};
+
 template <int EPI, int WM, int MI, int WN = 2>     // WN = 4: (WM * MI * 16) x 256 tiles (round 2, the N = 3072 / 2304 encoder outputs)
 __global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, int ntm, int ntn, int total_tiles) {
   constexpr int NLOAD = 4, NC = WN * WM;
@@ -781,6 +796,288 @@ __global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, 
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT, EIGHT-PHASE (round 3): (64 MH) x 256 x 64 tiles (256 rows at MH = 4, 320 at MH = 5, 192 at MH = 3), 8 waves =
+// 2 (M) x 4 (N), one persistent workgroup per CU.  Every wave both stages (LDS-DMA) and computes; a wave owns
+// (32 MH) x 64 outputs = 2 x 2 quadrants of (16 MH) x 32, one quadrant per PHASE, four phases per K tile:
+//     { fragment reads of the quadrant | LDS-DMA of ONE half-tile two K tiles ahead | s_barrier | 4 MH MFMAs | s_barrier }
+// The two wave groups (wr = 0 / 1, SIMD partners) run staggered by one barrier, so on every SIMD one wave is in its MFMA
+// section while its partner reads / stages.  A K tile lives in four half-tile images:  A_h = the m-half h rows of both wave
+// groups, B_h = the n-half h columns (32) of all four wave columns - a half-tile is dead as soon as ITS quadrants are done,
+// which is what lets three half-tiles stay in flight behind a counted vmcnt with only two LDS buffers:
+//     phase 1: read B_h0 (first) + A_h0, stage A_h1 of K tile s+1 -> other buffer | lgkmcnt retires the B reads | q(0,0)
+//     phase 2: read B_h1,                stage B_h0 of K tile s+2 -> this buffer  | q(0,1)
+//     phase 3: read A_h1,                stage A_h0 of s+2                        | q(1,1)
+//     phase 4:                           stage B_h1 of s+2, s_waitcnt vmcnt(the 3 youngest half-tiles) | q(1,0)
+// Hazards (guide, "8-phase template"): RAW - the wait of phase 4 (step s+1) retires every piece of K tile s+2, whose first
+// read is phase 1 of step s+2, one phase and (for both groups) at least one barrier later.  WAR - a half-tile is restaged two
+// phases after its last read, or one phase after when those reads were retired before the reading phase's first barrier
+// (B_h0).  The staging cursor runs over the workgroup's whole (tile, K tile) stream, so the first K tiles of the next output
+// tile are already in flight during an epilogue.  The epilogue is register-direct (operands swapped + permuted B rows, as
+// in the persistent kernel above).  Needs K % 64 == 0 (no k tail: garbage beyond M / N only reaches masked outputs).
+// ---------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm8() {
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, int MH>
+__global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn, int total_tiles) {
+  constexpr int HROWS = 16 * MH, WROWS = 2 * HROWS, TBM = 2 * WROWS;
+  constexpr int HA_ROWS = 2 * HROWS;                    // an A half-tile: m-half h of both wave groups
+  constexpr int HA_EL = HA_ROWS * 64, HB_EL = 128 * 64;
+  constexpr int BUF_EL = 2 * HA_EL + 2 * HB_EL;
+  constexpr int APC = HA_ROWS / 8;                       // 1-KiB pieces (8 rows x 128 B) of an A half-tile
+  constexpr int NPA = (APC + 7) / 8;                     // LDS-DMA instructions per wave and A half-tile
+  constexpr bool PADA = (APC % 8) != 0;                  // some waves issue one dummy piece (zeros into a scratch KiB)
+  constexpr int VMW = NPA + 4;                           // DMAs of the three youngest half-tiles: B_h0, A_h0, B_h1
+  static_assert(VMW == 6 || VMW == 7, "add the immediate to wait_vm8");
+  static_assert((2 * BUF_EL + (PADA ? 8 * 512 : 0)) * 2 <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) bf16 lds[2 * BUF_EL + (PADA ? 8 * 512 : 0)];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3, fr = lane & 15, fq = lane >> 4, l3 = lane >> 3, l7 = lane & 7;
+  const int nk = p.K / BK, nk2 = (nk + 1) & ~1;          // K tiles per output tile, padded to a pair (pad = zeros)
+  TileIter32 it;
+  it.G = gridDim.x; it.total = total_tiles; it.ntm = ntm; it.ntn = ntn;
+  {
+    const int g = blockIdx.x, G = gridDim.x, qd = G >> 3, rm = G & 7, xcd = g & 7;
+    it.slot = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (g >> 3);
+  }
+  // ---- staging geometry.  Piece pc = j * 8 + wid of a half-tile = LDS rows pc*8 .. pc*8+7 (lane>>3 = row, lane&7 = physical
+  // chunk); the XOR swizzle of the fragment reads, chunk ^ ((row >> 1) & 7), goes on the SOURCE chunk.
+  const int csrc = l7 ^ (((wid & 1) * 4 + (l3 >> 1)) & 7);
+  const uint32_t a_thr = (uint32_t)(((long)l3 * p.lda + csrc * 8) * 2);
+  const uint32_t b_thr = (uint32_t)(((long)((l3 >> 2) * 8 + (l3 & 3)) * p.ldb + csrc * 8) * 2);
+  uint32_t arow[NPA][2], brow[2][2];
+  bool a_dummy[NPA];
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int pc = j * 8 + wid;
+    a_dummy[j] = PADA && pc >= APC;
+    const int g = pc / (2 * MH), rr0 = (pc % (2 * MH)) * 8;     // 2 MH pieces per wave group
+#pragma unroll
+    for (int h = 0; h < 2; ++h) arow[j][h] = (uint32_t)((long)(g * WROWS + h * HROWS + rr0) * p.lda * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    // LDS row (wc*32 + j1*16 + f) of B_h  <-  B row wc*64 + h*32 + (f>>2)*8 + j1*4 + (f&3): with the MFMA operands swapped a
+    // lane then holds 8 consecutive output columns in the accumulators of the j-tiles (2h, 2h+1)
+    const int pc = j * 8 + wid;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      brow[j][h] = (uint32_t)((long)((pc >> 2) * 64 + h * 32 + (pc & 1) * 16 + ((pc >> 1) & 1) * 4) * p.ldb * 2);
+  }
+  // ---- fragment read offsets (elements): row = 16-aligned base + fr, so (row >> 1) & 7 = fr >> 1
+  const int a_rd0 = (wr * HROWS + fr) * 64 + ((fq ^ (fr >> 1)) << 3), a_rd1 = (wr * HROWS + fr) * 64 + (((4 + fq) ^ (fr >> 1)) << 3);
+  const int b_rd0 = (wc * 32 + fr) * 64 + ((fq ^ (fr >> 1)) << 3), b_rd1 = (wc * 32 + fr) * 64 + (((4 + fq) ^ (fr >> 1)) << 3);
+
+  // ---- staging cursor over the (tile, K tile) stream of this workgroup
+  int r_s = 0, kt_s = 0;
+  bool live_s = false, ok_cur = false, ok_prev = false;
+  uint32_t a_cur = 0, b_cur = 0, a_prev = 0;
+  __amdgpu_buffer_rsrc_t ra_cur = make_rsrc(p.A, p.a_bytes), rb_cur = make_rsrc(p.B, p.b_bytes), ra_prev = ra_cur;
+  auto set_tile = [&](int r) {
+    int bz, tm, tn;
+    live_s = it.get(r, bz, tm, tn);
+    ok_cur = live_s;
+    if (live_s) {
+      a_cur = a_thr + (uint32_t)((p.a_off + (long)tm * TBM * p.lda) * 2);
+      b_cur = b_thr + (uint32_t)((long)tn * 256 * p.ldb * 2);
+      ra_cur = make_rsrc(p.A + (long)bz * p.sA, p.a_bytes);
+      rb_cur = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
+    }
+  };
+  auto advance = [&]() {
+    a_prev = a_cur; ok_prev = ok_cur; ra_prev = ra_cur;
+    ++kt_s;
+    if (kt_s < nk2) { a_cur += 2 * BK; b_cur += 2 * BK; ok_cur = live_s && kt_s < nk; }
+    else { kt_s = 0; ++r_s; set_tile(r_s); }
+  };
+  auto stage_A = [&](int buf, int h, __amdgpu_buffer_rsrc_t rs, uint32_t base, bool ok) {
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+      const uint32_t o = (ok && !a_dummy[j]) ? base + arow[j][h] : 0xFFFFFFF0u;
+      bf16* dst = a_dummy[j] ? lds + 2 * BUF_EL + wid * 512 : lds + buf * BUF_EL + h * HA_EL + (j * 8 + wid) * 512;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+    }
+  };
+  auto stage_B = [&](int buf, int h, __amdgpu_buffer_rsrc_t rs, uint32_t base, bool ok) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t o = ok ? base + brow[j][h] : 0xFFFFFFF0u;
+      bf16* dst = lds + buf * BUF_EL + 2 * HA_EL + h * HB_EL + (j * 8 + wid) * 512;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+    }
+  };
+  set_tile(0);
+  if (!live_s) return;                                   // workgroup-uniform: more workgroups than tiles
+  // ---- prologue: K tile 0 whole, K tile 1 without its A_h1 (phase 1 of step 0 brings it)
+  stage_B(0, 0, rb_cur, b_cur, ok_cur); stage_A(0, 0, ra_cur, a_cur, ok_cur);
+  stage_B(0, 1, rb_cur, b_cur, ok_cur); stage_A(0, 1, ra_cur, a_cur, ok_cur);
+  advance();
+  stage_B(1, 0, rb_cur, b_cur, ok_cur); stage_A(1, 0, ra_cur, a_cur, ok_cur); stage_B(1, 1, rb_cur, b_cur, ok_cur);
+  advance();
+  wait_vm8<VMW>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();             // the stagger: group 1 runs one barrier behind group 0
+
+  f32x4 acc[2][MH][4];
+  bf16x8 af[MH][2], b0[2][2], b1[2][2];
+  auto mfma_q = [&](int mh, int nh, bf16x8 (&bb)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int j1 = 0; j1 < 2; ++j1)   // operands swapped: the accumulator holds C^T, 4 consecutive columns per lane
+          acc[mh][i][nh * 2 + j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[j1][ks], af[i][ks], acc[mh][i][nh * 2 + j1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto ktile = [&](auto ebuf) {
+    constexpr int EB = decltype(ebuf)::value;
+    const bf16* sA0 = lds + EB * BUF_EL;
+    const bf16* sA1 = sA0 + HA_EL;
+    const bf16* sB0 = sA0 + 2 * HA_EL;
+    const bf16* sB1 = sB0 + HB_EL;
+    // ---- phase 1
+#pragma unroll
+    for (int j1 = 0; j1 < 2; ++j1) {
+      b0[j1][0] = *(const bf16x8*)(sB0 + b_rd0 + j1 * 1024);
+      b0[j1][1] = *(const bf16x8*)(sB0 + b_rd1 + j1 * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MH; ++i) {
+      af[i][0] = *(const bf16x8*)(sA0 + a_rd0 + i * 1024);
+      af[i][1] = *(const bf16x8*)(sA0 + a_rd1 + i * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_A(EB ^ 1, 1, ra_prev, a_prev, ok_prev);
+    wait_lgkm<2 * MH>();                                 // the four B_h0 reads (issued first) are done: phase 2 may restage it
+    __builtin_amdgcn_s_barrier();
+    mfma_q(0, 0, b0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2
+#pragma unroll
+    for (int j1 = 0; j1 < 2; ++j1) {
+      b1[j1][0] = *(const bf16x8*)(sB1 + b_rd0 + j1 * 1024);
+      b1[j1][1] = *(const bf16x8*)(sB1 + b_rd1 + j1 * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_B(EB, 0, rb_cur, b_cur, ok_cur);
+    __builtin_amdgcn_s_barrier();
+    mfma_q(0, 1, b1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3
+#pragma unroll
+    for (int i = 0; i < MH; ++i) {
+      af[i][0] = *(const bf16x8*)(sA1 + a_rd0 + i * 1024);
+      af[i][1] = *(const bf16x8*)(sA1 + a_rd1 + i * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_A(EB, 0, ra_cur, a_cur, ok_cur);
+    __builtin_amdgcn_s_barrier();
+    mfma_q(1, 1, b1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4
+    stage_B(EB, 1, rb_cur, b_cur, ok_cur);
+    wait_vm8<VMW>();                                     // everything but the three youngest half-tiles has landed
+    __builtin_amdgcn_s_barrier();
+    mfma_q(1, 0, b0);
+    __builtin_amdgcn_s_barrier();
+    advance();
+  };
+
+  for (int r = 0;; ++r) {
+    int bz, tm, tn;
+    if (!it.get(r, bz, tm, tn)) break;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int i = 0; i < MH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mh][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kp = 0; kp < nk2; kp += 2) {
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
+    }
+    // ---- epilogue straight from the registers: lane (fr, fq) holds row .. + i*16 + fr and, from the j-tiles 2u / 2u+1,
+    // the EIGHT consecutive columns wc*64 + u*32 + fq*8 .. +7.  The stagger is suspended around it (group 0 waits one barrier
+    // for group 1's last MFMA phase, group 1 re-opens the gap afterwards): staggered, the two groups' epilogues run one after
+    // the other, each with one wave per SIMD - half the VALU / store issue rate of the CU.
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    const int m0 = tm * TBM, n0 = tn * 256;
+    const long cbase = (long)bz * p.sC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = n0 + wc * 64 + u * 32 + fq * 8;
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (epi_has_bias(EPI)) {
+        if (p.bias != nullptr && col < p.N) {
+          const bf16x8 b8 = *(const bf16x8*)(p.bias + col);      // N % 8 == 0, bias 16-byte aligned (host check)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[e] = bf2f(b8[e]);
+        }
+      }
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+          const int row = m0 + wr * WROWS + mh * HROWS + i * 16 + fr;
+          const long o = (long)row * p.ldc + col;
+          if (row >= p.M || col >= p.N) continue;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = acc[mh][i][2 * u][e]; v[4 + e] = acc[mh][i][2 * u + 1][e]; }
+          if (EPI == EPI_F32) {
+            *(f32x4*)(p.Cf + cbase + o) = f32x4{v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha};
+            *(f32x4*)(p.Cf + cbase + o + 4) = f32x4{v[4] * p.alpha, v[5] * p.alpha, v[6] * p.alpha, v[7] * p.alpha};
+            continue;
+          }
+          if (o + 8 > p.c_elems) continue;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[e];
+          bf16x8 o8;
+          if (epi_is_gelu(EPI)) {
+            bf16x8 pre;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              pre[e] = f2bf(v[e]);
+              float gv, dv;
+              gelu_pair(epi_is_save(EPI) ? bf2f(pre[e]) : v[e], gv, dv);   // the activation of the value that is saved
+              o8[e] = f2bf(gv);
+              if (EPI == EPI_BIAS_GELU_SAVEG) pre[e] = f2bf(dv);
+            }
+            if (epi_is_save(EPI)) *(bf16x8*)(p.C2 + cbase + o) = pre;
+          } else if (epi_is_dact(EPI)) {
+            const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
+          } else if (EPI == EPI_ADD) {
+            const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) + bf2f(a[e]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = f2bf(v[e]);
+          }
+          *(bf16x8*)(p.C + cbase + o) = o8;
+        }
+    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 falls one barrier behind again
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's extra barrier in front of the tile loop
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (out-of-range) prefetches still target the LDS
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1275,6 +1572,20 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
       if (best < 0 || cost < best) { best = cost; lc_h = hs[c]; wide_auto = ws[c] == 256; }
     }
     mode = 5;
+    // Round 3: the 8-phase kernel (256 x 256 / 320 x 256 tiles, every wave stages and computes).  Per staged byte it does 1.3x
+    // the work of a 160 x 256 tile, but its three half-tiles in flight fill the LDS at ~45 GB/s per CU against ~52 for the
+    // dedicated loader waves, and its tile epilogue is longer: measured time ~ 1.35 x the rounds x (rows + columns) proxy
+    // relative to the kernels above (tools/gemm_probe.py on QKV / fc1 / conv1 dgrad / conv2 / 4096^3: predicted 0.90 - 0.93,
+    // measured 0.92 - 0.95; conv1 forward predicted 1.07, measured 1.04).
+    static const int nt8_env = [] { const char* e = getenv("W2VS_NT8"); return e ? atoi(e) : 1; }();
+    if (nt8_env && (d.K % 64) == 0 && ((uintptr_t)d.bias % 16) == 0) {
+      const int h8[2] = {256, 320};
+      for (int c = 0; c < 2; ++c) {
+        const long t8 = (long)((d.N + 255) / 256) * ((d.M + h8[c] - 1) / h8[c]) * nbz;
+        const long cost = (((t8 + 255) / 256) * (h8[c] + 256) * 135 + 99) / 100;
+        if (cost < best) { best = cost; lc_h = h8[c]; mode = 8; wide_auto = false; }
+      }
+    }
   } else if (mode == 2) {
     const double nkt = (d.K + BK - 1) / BK;
     const long nbz = d.batch > 0 ? d.batch : 1;
@@ -1301,14 +1612,25 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   // lc_h = 1160 selects the 160 x 256 loader/consumer tile (WN = 4)
   const bool wide = (lc_h == 1160) || (wide_auto && lc_h == 160 && lc_env <= 0 && g_force_lc_h <= 0 && mode_env < 0 && g_force_nt_mode < 0);
   if (wide) { lc_h = 160; if (mode != 3 && mode != 5 && mode != 6) return set_error("gemm_nt: the 160 x 256 tile exists for the loader/consumer kernels only"); }
-  if (lc_h != 256 && lc_h != 192 && lc_h != 160) return set_error("gemm_nt: tile height must be 256, 192 or 160");
+  if (mode != 8 && lc_h == 320) lc_h = 256;                  // a forced mode after the model picked the 8-phase tile
+  if (mode == 8 && lc_h != 320) lc_h = 256;
+  if (mode == 8) {
+    if (!p_ok || (d.K % 64) || ((uintptr_t)d.bias % 16)) return set_error("gemm_nt: the 8-phase kernel needs K % 64 == 0, N % 8 == 0, ldc % 8 == 0, 16-byte aligned outputs / bias");
+    if (lc_h != 256 && lc_h != 320) return set_error("gemm_nt: 8-phase tile height must be 256 or 320");
+  } else if (lc_h != 256 && lc_h != 192 && lc_h != 160) return set_error("gemm_nt: tile height must be 256, 192 or 160");
   static const bool nt_log = getenv("W2VS_GEMM_LOG") != nullptr;      // shapes and the form chosen for them, one line per launch
   if (nt_log) fprintf(stderr, "gemm_nt M %d N %d K %d batch %d epi %d lda %ld -> mode %d tile %dx%d\n", d.M, d.N, d.K, (int)d.batch, d.epi,
-                      (long)d.lda, mode, mode >= 3 ? lc_h : 128, wide ? 256 : 128);
+                      (long)d.lda, mode, mode >= 3 ? lc_h : 128, (wide || mode == 8) ? 256 : 128);
   const dim3 grid8((d.N + (wide ? 255 : 127)) / (wide ? 256 : 128), (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
-    if (mode == 5 || mode == 6) {   /* 6: the same kernel with one workgroup per tile */       \
+    if (mode == 8) {                /* 8-phase, persistent: (lc_h) x 256 tiles */              \
+      const int ntm_ = (d.M + lc_h - 1) / lc_h, ntn_ = (d.N + 255) / 256;                     \
+      const int tot_ = ntm_ * ntn_ * (d.batch > 0 ? d.batch : 1);                              \
+      const dim3 gp(std::min(tot_, 256));                                                     \
+      if (lc_h == 320) hipLaunchKernelGGL((gemm_nt8_kernel<E, 5>), gp, dim3(512), 0, s, p, ntm_, ntn_, tot_); \
+      else hipLaunchKernelGGL((gemm_nt8_kernel<E, 4>), gp, dim3(512), 0, s, p, ntm_, ntn_, tot_);             \
+    } else if (mode == 5 || mode == 6) {   /* 6: the same kernel with one workgroup per tile */ \
       const int ntm_ = grid8.y, ntn_ = grid8.x, tot_ = ntm_ * ntn_ * (int)grid8.z;            \
       const dim3 gp(mode == 6 ? tot_ : std::min(tot_, 256));                                  \
       if (wide) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_);          \
@@ -1338,7 +1660,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
 #undef NT_LAUNCH
   // profiling id = one kernel symbol family: 16 * form + epilogue (form 0: gemm_nt_kernel, 1: gemm_nt_lc_kernel, 2: gemm_nt_p_kernel);
   // the weight-gradient kernels use 10..12 (form 0 epilogues stop at 8)
-  const int form = (mode == 5 || mode == 6) ? 2 : (mode == 3 ? 1 : 0);
+  const int form = mode == 8 ? 3 : (mode == 5 || mode == 6) ? 2 : (mode == 3 ? 1 : 0);
   prof_end(pe, 16 * form + d.epi, 2.0 * d.M * d.N * d.K * (d.batch > 0 ? d.batch : 1), s);
   return hip_check(hipGetLastError(), "gemm_nt launch");
 }
