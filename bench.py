@@ -189,7 +189,7 @@ def main():
                                 use_optimizer=not args.no_optimizer, update_freq=args.update_freq,
                                 lr=sched.current, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
                                 clip_norm=25.0 if large else 0.0, arena_gib=40.0 if large else 12.0,
-                                overlap_adam=os.environ.get("W2VS_OVERLAP_ADAM", "0") == "1")
+                                check_finite=os.environ.get("W2VS_CHECK_FINITE", "1") == "1")
     B, L = args.batch, args.samples
     g = torch.Generator().manual_seed(1234 + rank)
     source = torch.randn(B, L, generator=g)

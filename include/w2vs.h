@@ -290,7 +290,10 @@ int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, v
 int w2vs_relu_gate(const void* x, const void* gate, void* out, int64_t n, void* stream);
 /* Fused Adam on flat arrays: fairseq Adam (fs/optim/adam.py:205-229: decoupled weight decay,
  * bias-corrected step) + fp32 master / bf16 working copy (fs/optim/fp16_optimizer.py:205-218).
- * g = fp32 gradient arena; effective gradient = g * scale_host * (scale_dev ? *scale_dev : 1).  */
+ * g = fp32 gradient arena; effective gradient = g * scale_host * (scale_dev ? *scale_dev : 1).
+ * An effective scale of exactly 0 (what w2vs_clip_scale emits for a non-finite gradient norm) SKIPS the update:
+ * master, moments and bf16 image are left untouched, no weight decay (fs/trainer.py:791-793 raises before
+ * optimizer.step in that case).  */
 int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int32_t step, const float* scale_dev, float scale_host,
                    void* stream);

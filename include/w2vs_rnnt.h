@@ -66,8 +66,10 @@ rnntStatus_t compute_rnnt_loss(const float* const activations, float* gradients,
 
 /* rnnt.h:115-124 (called for double tensors by pytorch_binding/src/binding.cpp:69, :141).  Same contract as
  * compute_rnnt_loss with fp64 activations / gradients (device) and fp64 costs (host).  A CONVERTING WRAPPER: the
- * lattice runs in fp32 (activations narrowed into a temporary device buffer, results widened), so results carry fp32
- * accuracy - the reference instantiates GpuRNNT<double> here, which exists for its gradient checks. */
+ * lattice runs in fp32, so results carry fp32 ACCURACY - the reference instantiates GpuRNNT<double> here, which exists
+ * for its gradient checks: a finite-difference check through this entry needs fp32-sized steps and tolerances.  With a
+ * gradient buffer nothing is allocated (that buffer doubles as the fp32 staging area and is widened in place); a
+ * costs-only call (gradients == NULL) allocates the narrowed activations for the duration of the call. */
 rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gradients, const int* const flat_labels,
                                     const int* const label_lengths, const int* const input_lengths, int alphabet_size,
                                     int minibatch, double* costs, void* workspace, struct rnntOptions options);

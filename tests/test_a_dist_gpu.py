@@ -60,14 +60,25 @@ def _draws(cfg, B, L, keep=None, seed=7):
     return lambda: engine.Draws(mask_indices=mask, neg_idx=neg, context=(8, 4), layer_keep=list(keep), gumbel_noise=noise)
 
 
-def _same_update(p1, p2, lr):
-    """Two runs of the same update agree to 2e-5 - except on the few elements whose gradient is analytically zero (k_proj.bias:
-    the softmax does not see a per-query constant), where the computed gradient is summation noise, the order of the float atomics
-    that sum it has a few possible outcomes, and Adam's lr * g / (|g| + eps) turns them into moves of up to ~lr (observed, twice
-    the same: 6.7e-4 on 1.3e-4 of the elements).  The attention kernels themselves are bitwise reproducible (checked run to run)."""
+def _same_update(p1, p2, lr, arena):
+    """Two runs of the same update agree to 2e-5 in EVERY parameter element - except inside the ``k_proj.bias`` ranges, which are
+    named here: their gradient is analytically zero (the softmax does not see a per-query constant), what is computed is
+    summation noise whose float-atomic order has a few possible outcomes, and Adam's lr * g / (|g| + eps) turns those into moves
+    of up to ~lr (observed twice: 6.7e-4 on 1.3e-4 of all elements, every one of them a k_proj.bias element).  Any other
+    tensor that moves is a finding, not tolerance.  The attention kernels themselves are bitwise reproducible."""
     diff = (p1.double() - p2.double()).abs()
-    mx, frac = float(diff.max()), float((diff > 2e-5).double().mean())
-    assert mx <= 2.1 * lr and frac < 1e-3, "max |dp| %.3g (lr %.3g), share of elements off by > 2e-5: %.3g" % (mx, lr, frac)
+    free = torch.zeros(diff.numel(), dtype=torch.bool, device=diff.device)
+    for n, (off, numel, _) in arena.offsets.items():
+        if n.endswith("k_proj.bias"):
+            free[off:off + numel] = True
+    assert int(free.sum()) > 0
+    worst_named = float(diff[free].max())
+    rest = diff[~free]
+    assert worst_named <= 2.1 * lr, "k_proj.bias moved by %.3g (lr %.3g)" % (worst_named, lr)
+    if float(rest.max()) > 2e-5:
+        idx = int(torch.nonzero(diff * (~free) > 2e-5)[0])
+        owner = [n for n, (off, numel, _) in arena.offsets.items() if off <= idx < off + numel]
+        raise AssertionError("max |dp| outside k_proj.bias %.3g at element %d of %s" % (float(rest.max()), idx, owner))
     return True
 
 
@@ -108,7 +119,7 @@ def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
     den = float(g1.double().norm())
     assert float((g1.double() - g2.double()).norm()) / den < 2e-4          # fp32-atomic ordering only
     assert float((m1.double() - m2.double()).norm()) / float(m1.double().norm()) < 2e-4
-    assert _same_update(p1, p2, 1e-3)
+    assert _same_update(p1, p2, 1e-3, step.flat.arena)
     assert float((q1.float() != q2.float()).float().mean()) < 1e-3        # bf16 images: a last-bit flip at most
     if clip > 0:
         assert abs(n1 - n2) / n1 < 1e-4
@@ -198,14 +209,15 @@ def test_load_state_dict_resyncs_master_and_optimizer_state_round_trips():
         model.inject_draws(mk())
         step({"net_input": {"source": src}})
     torch.cuda.synchronize()
-    # same weights, same draws: the two updates agree (seen once: 6.7e-4 on one near-zero-gradient element of 400 k)
-    assert _same_update(step_a.flat.p32, step_b.flat.p32, 1e-3)
+    # same weights, same draws: the two updates agree everywhere but in the named zero-gradient tensors (_same_update)
+    assert _same_update(step_a.flat.p32, step_b.flat.p32, 1e-3, step_a.flat.arena)
     for k, v in model_a.state_dict().items():
         if "pos_conv" in k:
             continue
-        # (what is checked is that the LOADED weights survived, i.e. agreement at the scale of the weights; a single update
-        # may differ by up to ~2 lr on a near-zero-gradient element, see _same_update)
-        assert float((v.float() - model_b.state_dict()[k].float()).abs().max()) <= 2e-2 * float(v.float().abs().max()) + 2.1e-3, k
+        # the LOADED weights survived the update: per tensor, agreement at the scale of the weights; only k_proj.bias may
+        # carry the ~2 lr of its noise-gradient update on top
+        slack = 2.1e-3 if k.endswith("k_proj.bias") else 1e-6
+        assert float((v.float() - model_b.state_dict()[k].float()).abs().max()) <= 2e-2 * float(v.float().abs().max()) + slack, k
     # optimizer state round trip: a third trainer resumes from (a) and takes the same second step
     osd = step_a.flat.state_dict()
     w, cfg, model_c, crit_c = _build(SMALL, seed=9)
@@ -216,7 +228,7 @@ def test_load_state_dict_resyncs_master_and_optimizer_state_round_trips():
         model.inject_draws(mk())
         step({"net_input": {"source": src}})
     torch.cuda.synchronize()
-    assert _same_update(step_a.flat.p32, step_c.flat.p32, 1e-3)
+    assert _same_update(step_a.flat.p32, step_c.flat.p32, 1e-3, step_a.flat.arena)
     with pytest.raises(ValueError):
         bad = dict(osd, layout={})
         step_c.flat.load_state_dict(bad)
@@ -246,32 +258,39 @@ def test_step_arena_is_scoped_to_the_step():
     ops.ARENA.deactivate()
 
 
-@pytest.mark.parametrize("update_freq", [1, 2])
-def test_streamed_adam_equals_single_launch(update_freq):
-    """TrainStep(overlap_adam=True) enqueues the Adam update of every gradient range on a side stream as soon as the
-    backward reports it final; the result must equal the one-launch update bit for bit (same kernel, same operands), and the
-    next step must see the updated weights."""
+@pytest.mark.parametrize("clip", [0.0, 0.05])
+def test_nonfinite_gradient_skips_the_update_and_raises(clip):
+    """fs/trainer.py:781-793: the gradient norm is computed on every update and a non-finite one raises FloatingPointError
+    BEFORE optimizer.step.  Here: an Inf planted in the gradient arena right before the norm / Adam launches must leave the
+    fp32 master, both moments and the bf16 image bit-identical (NaN * 0 would have poisoned them), ``grad_norm()`` raises,
+    and so does a later step once the flag has reached the host - with and without clipping."""
     from wav2vec_s_amd import trainer, ops
     B, L = 2, 16000
     src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
-    res = []
-    for overlap in (False, True):
-        w, cfg, model, crit = _build(SMALL)
-        step = trainer.TrainStep(model, crit, lr=1e-3, update_freq=update_freq, arena_gib=1.0, overlap_adam=overlap)
-        mk = _draws(cfg, B, L, [True, True, False, True])
-        losses = []
-        for _ in range(2 * update_freq):              # two updates: the second forward runs on the updated weights
+    w, cfg, model, crit = _build(SMALL)
+    step = trainer.TrainStep(model, crit, lr=1e-3, clip_norm=clip, arena_gib=1.0)
+    mk = _draws(cfg, B, L)
+    model.inject_draws(mk())
+    step({"net_input": {"source": src}})                 # a normal first update: moments become non-zero
+    torch.cuda.synchronize()
+    assert np.isfinite(step.grad_norm()) and step.grad_norm() > 0
+    before = [t.clone() for t in (step.flat.p32, step.flat.m, step.flat.v, step.flat.p16)]
+    assert float(before[1].abs().max()) > 0
+
+    def plant(ts):
+        ts.flat.arena.flat[12345] = float("inf")
+    step._before_optimizer = plant
+    model.inject_draws(mk())
+    step({"net_input": {"source": src}})
+    step._before_optimizer = None
+    torch.cuda.synchronize()
+    for a, b in zip(before, (step.flat.p32, step.flat.m, step.flat.v, step.flat.p16)):
+        assert torch.equal(a, b)
+    with pytest.raises(FloatingPointError):
+        step.grad_norm()
+    with pytest.raises(FloatingPointError):
+        for _ in range(3):                               # the flag copy was enqueued behind the poisoned update
             model.inject_draws(mk())
-            losses.append(float(step({"net_input": {"source": src}})))
-        torch.cuda.synchronize()
-        assert step.flat.step == 2
-        res.append((step.flat.p32.clone(), step.flat.m.clone(), step.flat.v.clone(), step.flat.p16.clone(), losses))
-        ops.ARENA.deactivate()
-    (p1, m1, v1, q1, l1), (p2, m2, v2, q2, l2) = res
-    # before the first update the two runs compute the same thing; the scalar loss is summed with float atomics across blocks
-    # (ce_kernel), so it may differ in the last bit from run to run (seen: 316.89401 vs 316.89404) - compare to 1e-6, not bitwise
-    for a, b in zip(l1[:update_freq], l2[:update_freq]):
-        assert abs(a - b) <= 1e-6 * abs(a), (a, b)
-    assert _same_update(p1, p2, 1e-3)
-    assert float((m1.double() - m2.double()).norm() / m1.double().norm()) < 2e-4
-    assert abs(l1[-1] - l2[-1]) / abs(l1[-1]) < 1e-4
+            step({"net_input": {"source": src}})
+            torch.cuda.synchronize()
+    ops.ARENA.deactivate()

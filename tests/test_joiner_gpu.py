@@ -8,7 +8,22 @@ import pytest
 import torch
 
 import rnnt_oracle as R
-from conftest import GOLDEN
+from conftest import GOLDEN, by_family, dump_parity
+
+# worst relative parameter-gradient error per family (conftest.grad_family), measured on MI355X in round 3
+# (gpurun_out/parity_joiner_*.json); bars = ~2 x measured
+# measured (ln / bias / weight): fixtures pre .054 .051 .053, post .010 .032 .036, offline .039 .042 .042; caat width .065 .066 .062
+# - the worst are always the LAST layers' fc1 / final_layer_norm: their gradient passes the ReLU gate, whose near-zero
+# decisions differ between bf16 and fp32 pre-activations
+JOINER_BARS = {"fixture": {"ln": 0.08, "bias": 0.075, "weight": 0.08}, "caat": {"ln": 0.10, "bias": 0.10, "weight": 0.095}}
+
+
+def _check_families(errs, which, tag):
+    fam = by_family(errs)
+    dump_parity("joiner_" + tag, {"by_family": fam, "median": float(np.median(list(errs.values()))),
+                                  "worst": sorted(errs.items(), key=lambda kv: -kv[1])[:5]})
+    over = {f: e for f, e in fam.items() if not e <= JOINER_BARS[which][f]}
+    assert not over, (over, sorted(errs.items(), key=lambda kv: -kv[1])[:5])
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -46,7 +61,7 @@ def test_joiner_matches_reference_fixture(tag):
     for n, p in net.named_parameters():
         if "k_proj.bias" in n:
             assert float(p.grad.float().norm()) < 2e-2 * float(dict(net.named_parameters())[n.replace("k_proj", "q_proj")].grad.float().norm())
-    assert max(errs.values()) < 6e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _check_families(errs, "fixture", tag)
     assert float(np.median(list(errs.values()))) < 2e-2
 
 
@@ -81,7 +96,7 @@ def test_joiner_caat_width_matches_oracle_and_feeds_the_head():
     (x.float() * w.cuda()).sum().backward()
     assert rel(e_g.grad, e_r.grad) < 4e-2 and rel(d_g.grad, d_r.grad) < 4e-2
     errs = {n: rel(p.grad, P[n].grad) for n, p in net.named_parameters() if "k_proj.bias" not in n}
-    assert max(errs.values()) < 8e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _check_families(errs, "caat", "caat_width")
     # dropout on: same expectation, different draw per call, deterministic per seed
     net_t = joiner.MHAJointNet(_args(D, H, 16, 2, True, 1024, p=0.1)).to(BF).cuda().train()
     torch.manual_seed(5); torch.cuda.manual_seed(5)

@@ -711,3 +711,32 @@ def test_gemm_tn_group_equals_single_launches():
     w3, b3 = targets()
     ops.gemm_tn_group([dict(a=dys[2], b=xs[2], out_f32=w3[2], M=E, N=E, K=R, lda=E, ldb=E, ldc=E, alpha=0.5, colsum_out=b3[2])])
     assert torch.equal(w3[2], w1[2]) and rel(b3[2], b1[2]) < 1e-5     # the column sums arrive through atomics: order varies
+
+
+def test_group_attention_beyond_one_record_table(ops):
+    """Cross (joiner) mode with more query tiles than one launch's record table holds (G*U = 8 712 rows = 273 tiles > 256:
+    the launch is chunked) against plain torch, forward and backward; and the limit itself (512 tiles) is an error, not an
+    overrun (rain/layers/attention_transducer.py:591-716 is what this mode replaces)."""
+    torch.manual_seed(11)
+    B, H, G, U, m, C = 1, 2, 33, 264, 4, 128
+    S, Nq = G * m, G * U
+    q = (torch.randn(B, Nq, C) * 0.5).to(BF)
+    kv = (torch.randn(B, S, 2 * C) * 0.5).to(BF)
+    do = torch.randn(B, Nq, C).to(BF)
+    o, lse = ops.group_attn_fwd(dev(q), dev(kv), H, m, U)
+    dq, dkv = ops.group_attn_bwd(dev(do), dev(q), dev(kv), o, lse, H, m, U)
+    qr, kvr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    qh = qr.view(B, Nq, H, C // H).transpose(1, 2)
+    kh = kvr[..., :C].reshape(B, S, H, C // H).transpose(1, 2)
+    vh = kvr[..., C:].reshape(B, S, H, C // H).transpose(1, 2)
+    sc = qh @ kh.transpose(-1, -2) * (C // H) ** -0.5
+    vis = torch.arange(S).view(1, S) < ((torch.arange(Nq) // U + 1) * m).clamp(max=S).view(Nq, 1)
+    sc = sc.masked_fill(~vis, float("-inf"))
+    ref = (sc.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+    ref.backward(do.double())
+    assert rel(o, ref.detach()) < 1e-2
+    assert rel(dq, qr.grad) < 2e-2 and rel(dkv, kvr.grad) < 2e-2
+    from wav2vec_s_amd._lib import W2vsError
+    big = torch.zeros(1, 16416, C, dtype=BF, device="cuda")          # 513 tiles
+    with pytest.raises(W2vsError):
+        ops.group_attn_fwd(big, dev(kv), H, m, 16416 // 4)

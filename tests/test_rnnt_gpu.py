@@ -325,3 +325,34 @@ def test_nonzero_blank_label():
         gc, gg = _c_api(acts, lab, xl, yl, blank=blank, delay=dv, delay_scale=0.6)
         np.testing.assert_allclose(gc.reshape(3, B), oc, rtol=2e-4, atol=2e-4)
         np.testing.assert_allclose(gg, og, atol=2e-4)
+
+
+def test_fp64_entry_equals_the_fp32_entry():
+    """compute_rnnt_loss_fp64 (rnnt.h:115-124) is a converting wrapper: same costs and gradients as compute_rnnt_loss on the
+    narrowed activations, to fp32 rounding - with gradients (the fp64 gradient buffer doubles as staging and is widened
+    in place: an odd element count exercises every halving pass) and costs-only."""
+    from wav2vec_s_amd import transducer as tr
+    lib = tr._rnnt_lib()
+    lib.compute_rnnt_loss_fp64.restype = C.c_int
+    rng = np.random.default_rng(5)
+    B, T, U, V = 3, 7, 5, 11                                             # 1155 elements: odd
+    acts = rng.standard_normal((B, T, U, V)).astype(np.float32)
+    lab = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
+    xl, yl = np.array([7, 5, 6], dtype=np.int32), np.array([4, 2, 3], dtype=np.int32)
+    c32, g32 = _c_api(acts, lab, xl, yl)
+    a64 = _dev(acts.astype(np.float64), torch.float64)
+    g64 = torch.full_like(a64, float("nan"))
+    labd, x, y = _dev(lab, torch.int32), _dev(xl, torch.int32), _dev(yl, torch.int32)
+    size = C.c_size_t(0)
+    assert lib.get_workspace_size(T, U, B, True, C.byref(size), 8) == 0
+    ws = torch.empty(size.value, dtype=torch.uint8, device="cuda")
+    opt = tr.RnntOptions(1, 1, torch.cuda.current_stream().cuda_stream, 0, T, U, False)
+    for want_grad in (True, False):
+        costs = np.zeros(B, dtype=np.float64)
+        rc = lib.compute_rnnt_loss_fp64(C.c_void_p(a64.data_ptr()), C.c_void_p(g64.data_ptr()) if want_grad else None,
+                                        C.c_void_p(labd.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), V, B,
+                                        costs.ctypes.data_as(C.c_void_p), C.c_void_p(ws.data_ptr()), opt)
+        assert rc == 0
+        np.testing.assert_allclose(costs, c32, rtol=1e-6, atol=1e-6)
+        if want_grad:
+            np.testing.assert_allclose(g64.cpu().numpy(), g32, rtol=0, atol=1e-7)

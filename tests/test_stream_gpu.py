@@ -13,8 +13,24 @@ import pytest
 import torch
 
 import w2vs_oracle as O
+from conftest import by_family, dump_parity
 
 pytestmark = pytest.mark.gpu
+
+# Worst relative gradient error per parameter family (conftest.grad_family), bf16 HIP vs the reference's recorded fp32
+# values / the fp32 oracle, measured on MI355X in round 3 (gpurun_out/parity_stream_*.json); bars = ~2 x measured.
+TWIN_BARS = {   # measured: golden .019 .021 .025 .012 .021 | online .024 .023 .019 .015 .026 | full width .028 .018 .017 .016 .031
+    "golden": {"bias": 0.04, "extractor_conv": 0.045, "extractor_norm": 0.05, "ln": 0.025, "weight": 0.045},
+    "online": {"bias": 0.05, "extractor_conv": 0.05, "extractor_norm": 0.04, "ln": 0.03, "weight": 0.055},
+    "full": {"bias": 0.06, "extractor_conv": 0.04, "extractor_norm": 0.035, "ln": 0.035, "weight": 0.065}}
+
+
+def _check_families(errs, which, tag):
+    fam = by_family(errs)
+    dump_parity("stream_" + tag, {"by_family": fam, "median": float(np.median(list(errs.values()))),
+                                  "worst": sorted(errs.items(), key=lambda kv: -kv[1])[:5]})
+    over = {f: e for f, e in fam.items() if not e <= TWIN_BARS[which][f]}
+    assert not over, (over, sorted(errs.items(), key=lambda kv: -kv[1])[:5])
 BF = torch.bfloat16
 
 
@@ -66,7 +82,7 @@ def test_twin_matches_reference_golden(golden_dir):
     errs = _grad_report(model.named_parameters(), lambda n: z["grad." + n], lambda n: bool(z["hasgrad." + n][0]))
     assert len(errs) > 50
     assert float(np.median(list(errs.values()))) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert max(errs.values()) < 0.15, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _check_families(errs, "golden", "twin_golden")
     # streaming calls: unfinished (right context withheld), finished, un-padded prefix with odd T
     model.eval()
     with torch.no_grad():
@@ -123,7 +139,7 @@ def test_online_encoder_from_checkpoint_freeze_and_proj(golden_dir, tmp_path):
         else:
             assert len(errs) > 40
         assert float(np.median(list(errs.values()))) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-        assert max(errs.values()) < 0.15, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+        _check_families(errs, "online", "online_" + tag)
     enc.eval()
     with torch.no_grad():
         r = enc(src, lens, None, False, True)
@@ -170,7 +186,7 @@ def test_twin_full_width_padded_batch_matches_oracle():
     (x * w.cuda().to(BF) * validr.cuda().to(BF)).sum().backward()
     errs = _grad_report(model.named_parameters(), lambda n: P[n].grad, lambda n: P[n].grad is not None)
     assert float(np.median(list(errs.values()))) < 4e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert max(errs.values()) < 0.2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _check_families(errs, "full", "twin_full_width")
     # a growing prefix, as the SimulEval agent feeds it: frames emitted for a prefix never change afterwards
     # (their whole receptive field - own block, all earlier blocks, own right context - is inside the prefix)
     model.eval()

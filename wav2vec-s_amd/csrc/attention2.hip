@@ -768,13 +768,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_dkv_kernel(Attn2P pp) {
 // the launch's record table (host): one record per 32-row tile with its visible sub-tile list, longest list first - the
 // tail of the launch is then made of the short workgroups
 template <class F>
-void make_table(Attn2P& pp, int ntiles, F list) {      // list(t, aux) -> SubList of tile t (nM without packed extras)
-  struct E { int nT, t, nM, rc0, aux; };
+void make_table(Attn2P& pp, int first, int ntiles, F list) {   // list(t, aux) -> SubList of tile t (nM without packed extras)
+  struct E { int nT, t, nM, rc0, aux; };                        // tiles [first, first + ntiles): one launch holds <= MAXT2 records
+  if (ntiles > MAXT2) ntiles = MAXT2;                           // (callers chunk; never write past the kernel argument)
   std::vector<E> v(ntiles);
-  for (int t = 0; t < ntiles; ++t) {
+  for (int i = 0; i < ntiles; ++i) {
     int aux = 0;
-    const SubList l = list(t, aux);
-    v[t] = {l.nT, t, l.nM, l.rc0, aux};
+    const SubList l = list(first + i, aux);
+    v[i] = {l.nT, first + i, l.nM, l.rc0, aux};
   }
   std::stable_sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.nT > b.nT; });
   pp.ntiles = ntiles;
@@ -782,8 +783,8 @@ void make_table(Attn2P& pp, int ntiles, F list) {      // list(t, aux) -> SubLis
     pp.rec[i] = (uint64_t)v[i].t | ((uint64_t)v[i].nT << 10) | ((uint64_t)v[i].nM << 20) | ((uint64_t)v[i].rc0 << 30) |
                 ((uint64_t)v[i].aux << 40);
 }
-static void query_tile_table(Attn2P& pp, const AttnP& p, int nqt) {
-  make_table(pp, nqt, [&](int t, int& aux) {
+static void query_tile_table(Attn2P& pp, const AttnP& p, int first, int nqt) {
+  make_table(pp, first, nqt, [&](int t, int& aux) {
     int full;
     const SubList l = key_list(t * 32, std::min(t * 32 + 32, p.Nq) - 1, p.Tp, p.m, p.r, p.N, p.mq, full);
     aux = full >> 5;
@@ -791,7 +792,7 @@ static void query_tile_table(Attn2P& pp, const AttnP& p, int nqt) {
   });
 }
 static void key_tile_table(Attn2P& pp, const AttnP& p, int nkt) {
-  make_table(pp, nkt, [&](int t, int& aux) {
+  make_table(pp, 0, nkt, [&](int t, int& aux) {
     SubList l = query_list(t * 32, std::min(t * 32 + 32, p.N) - 1, p.Tp, p.m, p.r, p.N, p.Nq, p.mq);
     aux = l.nM >> 16;
     l.nM &= 0xFFFF;
@@ -810,7 +811,7 @@ static inline int drop_mode(const AttnP& p) { return p.thr16 == 0 ? 0 : (p.drop_
 // forward 33.4 -> 31.0 us, dQ pass -2 us; N = 1496 (longest 47) forward 35.3 -> 38.2 us.  W2VS_ATTN_NW=2|4 forces one.
 static const int g_attn_nw_env = [] { const char* e = getenv("W2VS_ATTN_NW"); return e ? atoi(e) : 0; }();
 #define W2VS_LAUNCH_DM_NW(kern, tiles)                                                                              \
-  const int longest_ = (int)(pp.rec[0] >> 10) & 1023;     /* the table is sorted longest first */                   \
+ {const int longest_ = (int)(pp.rec[0] >> 10) & 1023;     /* the table is sorted longest first */                   \
   const int nw_ = g_attn_nw_env == 2 || g_attn_nw_env == 4 ? g_attn_nw_env : (longest_ <= 32 ? 2 : 4);               \
   if (nw_ == 2) {                                                                                              \
     switch (drop_mode(p)) {                                                                                          \
@@ -824,7 +825,7 @@ static const int g_attn_nw_env = [] { const char* e = getenv("W2VS_ATTN_NW"); re
       case 1: hipLaunchKernelGGL((kern<1, 4>), dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;                 \
       default: hipLaunchKernelGGL((kern<2, 4>), dim3(p.B * p.H, tiles), dim3(256), 0, st, pp); break;                \
     }                                                                                                                \
-  }
+  }}
 
 // (the multiply-high divisions are exact below 65536: positions, and the (batch, head) index;
 // and the 24-bit row-address products need strides below 2^24 and N * stride below 2^32)
@@ -839,8 +840,13 @@ int attn2_fwd(const AttnP& p, hipStream_t st) {
   pp.a = p;
   pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32;
-  query_tile_table(pp, p, nqt);
-  W2VS_LAUNCH_DM_NW(attn2_fwd_kernel, nqt)
+  // a launch carries at most MAXT2 tile records in its kernel argument: the cross mode (queries = G x U joiner rows, up to
+  // 512 tiles) goes out in chunks of query tiles; records hold absolute tile numbers, so the kernels need no offset
+  for (int t0 = 0; t0 < nqt; t0 += MAXT2) {
+    const int cnt = std::min(MAXT2, nqt - t0);
+    query_tile_table(pp, p, t0, cnt);
+    W2VS_LAUNCH_DM_NW(attn2_fwd_kernel, cnt)
+  }
   return hip_check(hipGetLastError(), "attn_fwd");
 }
 
@@ -849,8 +855,11 @@ int attn2_bwd(const AttnP& p, hipStream_t st) {
   pp.a = p;
   pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32, nkt = (p.N + 31) / 32;
-  query_tile_table(pp, p, nqt);
-  W2VS_LAUNCH_DM_NW(attn2_dq_kernel, nqt)     // dq rows >= Nq are not written
+  for (int t0 = 0; t0 < nqt; t0 += MAXT2) {
+    const int cnt = std::min(MAXT2, nqt - t0);
+    query_tile_table(pp, p, t0, cnt);
+    W2VS_LAUNCH_DM_NW(attn2_dq_kernel, cnt)     // dq rows >= Nq are not written
+  }
   key_tile_table(pp, p, nkt);
   {
     static const int dkv_nw_env = [] { const char* e = getenv("W2VS_ATTN_DKV_NW"); return e ? atoi(e) : 0; }();

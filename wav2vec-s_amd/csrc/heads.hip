@@ -820,6 +820,10 @@ __global__ void adam_kernel(float* p32, bf16* p16, float* m, float* v, const flo
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   const float gs = scale_dev ? scale_host * scale_dev[0] : scale_host;
+  // a gradient scale of exactly 0 is w2vs_clip_scale's mark for a non-finite gradient norm: the update is SKIPPED - master,
+  // moments and the bf16 image keep their values, no weight decay (NaN * 0 would poison all four).  The reference raises
+  // FloatingPointError before optimizer.step in that case (fs/trainer.py:791-793); the host raises it from the flag later.
+  if (gs == 0.f) return;
   f32x4 pv = *(f32x4*)(p32 + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i), gv = *(const f32x4*)(g + i);
   bf16x4 o;
 #pragma unroll

@@ -562,9 +562,9 @@ __global__ void f64_to_f32_kernel(const double* in, float* out, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (float)in[i];
 }
-__global__ void f32_to_f64_kernel(const float* in, double* out, long n) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = (double)in[i];
+__global__ void f32_to_f64_kernel(const float* in, double* out, long lo, long hi) {   // elements [lo, hi)
+  const long i = lo + (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < hi) out[i] = (double)in[i];
 }
 
 }  // namespace
@@ -602,8 +602,12 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
 
 // rnnt.h:115-124, called by pytorch_binding/src/binding.cpp:69 / :141 for double tensors.  A CONVERTING WRAPPER: the
 // lattice runs in fp32 exactly as compute_rnnt_loss (MI355X has no use for an fp64 transducer: the reference's fp64
-// instantiation exists for its gradient checks); activations are narrowed into a temporary device buffer, gradients
-// and costs widened on the way out.  Synchronous, like the reference's entry (costs land on the host).
+// instantiation exists for its gradient checks - results here carry fp32 accuracy, so a finite-difference check through
+// this entry needs fp32-sized steps and tolerances).  No allocation on the gradient path: the caller's fp64 gradient
+// buffer (8 n bytes) doubles as the staging area - fp32 gradients in its first half, the narrowed activations in its
+// second - and the gradients are widened in place, top half first (pass [ceil(hi/2), hi) writes bytes >= 4 hi, which
+// only holds values already widened or the dead activations).  Costs-only calls (gradients == NULL) have no such buffer
+// and allocate the activation staging.  Synchronous, like the reference's entry (costs land on the host).
 rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gradients, const int* const flat_labels,
                                     const int* const label_lengths, const int* const input_lengths, int alphabet_size,
                                     int minibatch, double* costs, void* workspace, rnntOptions options) {
@@ -614,21 +618,24 @@ rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gra
   const long n = (long)minibatch * options.maxT * options.maxU * alphabet_size;
   float* a32 = nullptr;
   float* g32 = nullptr;
-  if (hipMalloc((void**)&a32, sizeof(float) * n) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
-  if (gradients && hipMalloc((void**)&g32, sizeof(float) * n) != hipSuccess) { (void)hipFree(a32); return RNNT_STATUS_MEMOPS_FAILED; }
+  if (gradients) { g32 = (float*)gradients; a32 = g32 + n; }
+  else if (hipMalloc((void**)&a32, sizeof(float) * n) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks), dim3(256), 0, st, activations, a32, n);
   std::vector<float> c32((size_t)minibatch);
   rnntStatus_t rc = run(a32, g32, flat_labels, label_lengths, input_lengths, nullptr, alphabet_size, minibatch, c32.data(),
                         workspace, 0.f, 1.f, options, false);
   if (rc == RNNT_STATUS_SUCCESS && gradients) {
-    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(blocks), dim3(256), 0, st, g32, gradients, n);
+    for (long hi = n; hi > 0;) {
+      const long lo = hi == 1 ? 0 : (hi + 1) / 2;
+      hipLaunchKernelGGL(f32_to_f64_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, g32, gradients, lo, hi);
+      hi = lo;
+    }
     if (hipStreamSynchronize(st) != hipSuccess) rc = RNNT_STATUS_EXECUTION_FAILED;
   }
   if (rc == RNNT_STATUS_SUCCESS)
     for (int b = 0; b < minibatch; ++b) costs[b] = (double)c32[b];
-  (void)hipFree(a32);
-  if (g32) (void)hipFree(g32);
+  if (!gradients) (void)hipFree(a32);
   return rc;
 }
 

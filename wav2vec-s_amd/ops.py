@@ -124,7 +124,7 @@ class _GemmTimer:
         torch.cuda.synchronize()
         # one id per kernel symbol family: NT = 16 * form + epilogue, the weight-gradient (TN) kernels 10..12
         epis = ["none", "bias", "bias_gelu", "bias_gelu_save", "dgelu", "f32", "add", "bias_gelu_savegrad", "mul"]
-        names = {16 * f + e: "%s<%s>" % (fn, en) for f, fn in enumerate(("gemm_nt_kernel", "gemm_nt_lc_kernel", "gemm_nt_p_kernel"))
+        names = {16 * f + e: "%s<%s>" % (fn, en) for f, fn in enumerate(("gemm_nt_kernel", "gemm_nt_lc_kernel", "gemm_nt_p_kernel", "gemm_nt8_kernel"))
                  for e, en in enumerate(epis)}
         names.update({10: "gemm_tn_kernel", 11: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)", 12: "gemm_tn_group_kernel"})
         groups = {}

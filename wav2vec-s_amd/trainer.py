@@ -177,7 +177,7 @@ class TrainStep:
 
     def __init__(self, model, criterion, world_size=1, use_optimizer=True, lr=5e-4, betas=(0.9, 0.98), eps=1e-6,
                  weight_decay=0.01, clip_norm=0.0, arena_gib=12.0, update_freq=1, lr_scheduler=None, group=None,
-                 overlap_adam=False):
+                 check_finite=True):
         self.model, self.criterion, self.world = model, criterion, world_size
         self.flat = FlatParams(model)
         self.use_optimizer = use_optimizer
@@ -198,16 +198,19 @@ class TrainStep:
             self.exchange = GradExchange(self.flat.arena.flat, dist, group=group,
                                          flush_at=tail if tail < self.flat.arena.numel else -1)
         dev = self.flat.p16.device
-        # Streamed optimizer (opt-in): Adam is HBM-bound (30 B per parameter), the backward MFMA-bound.  As soon as a suffix
-        # of the gradient arena is final (and, with N > 1, all-reduced) its Adam update is enqueued on a side stream, under
-        # the rest of the backward.  Not with clip_norm (the norm needs every gradient first) and not for partial updates.
-        # Measured on MI355X, base model, same box, interleaved runs: 10.58 / 10.57 ms per step with it, 10.35 / 10.39 without -
-        # the 2.7 GB of optimizer traffic slows the concurrent GEMMs by more than the 0.5 ms it hides.  Hence off by default.
-        self.overlap_adam = bool(overlap_adam) and dev.type == "cuda"
-        self.opt_stream = torch.cuda.Stream(device=dev) if self.overlap_adam else None
-        self._adam = None
+        # The reference computes the gradient norm on EVERY update (clip_grad_norm_ with max_norm 0 still returns the norm,
+        # fs/trainer.py:781) and raises FloatingPointError before optimizer.step when it is not finite (:791-793).  Here the
+        # norm, the test and the consequence stay on the device: a non-finite norm makes the gradient scale 0, which the fused
+        # Adam treats as "skip this update" (nothing is written - master, moments and the bf16 image keep their values), and
+        # the flag travels to the host through a pinned buffer that is looked at - without waiting - at the start of later
+        # steps, where the error is raised.  check_finite=False (and clip_norm == 0) skips the norm pass (361 MB read).
+        self.check_finite = bool(check_finite)
         self.norm_buf = torch.zeros(1, device=dev, dtype=torch.float32)
         self.clip_out = torch.zeros(3, device=dev, dtype=torch.float32)   # [grad scale, gnorm, non-finite flag]
+        self._bad_acc = torch.zeros(1, device=dev, dtype=torch.float32)   # sticky: number of skipped (non-finite) updates
+        self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
+        self._flag_event = None
+        self._before_optimizer = None     # test hook: called right before the norm / Adam launches of an update
         # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB.  It hands out
         # memory only while a step runs: anything else in the process (validation forward, streaming twin) gets torch's.
         self.arena_bytes = int(arena_gib * (1 << 30))
@@ -216,13 +219,22 @@ class TrainStep:
 
     def grad_norm(self):
         """Gradient norm of the last update after the 1/sample_size scaling (what fairseq logs as ``gnorm``); available
-        when clip_norm > 0.  Reads the device (a sync) - call it when logging, not every step."""
+        when clip_norm > 0 or check_finite.  Reads the device (a sync) - call it when logging, not every step."""
         gn, bad = float(self.clip_out[1]), float(self.clip_out[2])
         if bad:
             raise FloatingPointError("gradients are Nan/Inf")        # fs/trainer.py:791-793
         return gn
 
+    def _raise_if_nonfinite(self):
+        """Raise for an EARLIER update whose gradient norm was not finite, once its flag has reached the host (no wait)."""
+        ev = self._flag_event
+        if ev is not None and ev.query():
+            self._flag_event = None
+            if float(self._flag_host[0]) != 0.0:
+                raise FloatingPointError("gradients are Nan/Inf")    # fs/trainer.py:791-793; that update was skipped on the device
+
     def __call__(self, sample):
+        self._raise_if_nonfinite()
         ops.ARENA.activate(self.arena_bytes, self.flat.p16.device)
         try:
             return self._step(sample)
@@ -239,25 +251,11 @@ class TrainStep:
                 self.exchange.begin_step()
         # only the closing micro-batch reports gradient milestones: earlier ones would all-reduce partial sums
         self.model._on_grad_ready = self.exchange.on_ready if (self.exchange is not None and last) else None
-        streamed = last and self.use_optimizer and self.overlap_adam and not self.clip > 0
-        if streamed:
-            self.model._on_grad_ready = self._ready_streamed
-        self.model._after_forward = (lambda ss: self._begin_streamed_adam(self.ss_acc + ss)) if streamed else None
         loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
-        if streamed and self._adam is None:       # a model without the hook: start here (sample_size is a host int)
-            self._begin_streamed_adam(self.ss_acc + sample_size)
-        loss.backward()                           # milestones inside launch the bucketed all-reduces (and Adam ranges)
+        loss.backward()                           # milestones inside launch the bucketed all-reduces
         self.ss_acc += sample_size
         self.micro = 0 if last else self.micro + 1
         if not last:
-            return loss.detach()
-        if streamed:
-            if self.exchange is not None:
-                self.exchange.finish()            # launches what is left; every launch chains its Adam range
-            self._ready_streamed(0)
-            torch.cuda.current_stream().wait_stream(self.opt_stream)    # the next forward reads the updated bf16 image
-            self.last_lr = self._adam["lr"]
-            self._adam = None
             return loss.detach()
         total = self.ss_acc
         if self.exchange is not None:
@@ -270,6 +268,8 @@ class TrainStep:
             self.ss_dev = ss
             total = None
         if self.use_optimizer:
+            if self._before_optimizer is not None:
+                self._before_optimizer(self)
             lr = self.lr_scheduler.step_update(f.step) if self.lr_scheduler is not None else self.lr
             f.step += 1
             scale_dev = None
@@ -277,56 +277,20 @@ class TrainStep:
                 scale, scale_dev = 1.0, self.ss_dev.reciprocal_()     # 1 / sum of sample_size over ranks, on device
             else:
                 scale = 1.0 / float(total)
-            if self.clip > 0:
+            if self.clip > 0 or self.check_finite:
                 # clip_grad_norm_ (fs/utils.py:341-386) on the gradient AFTER its division by sample_size
                 # (fs/trainer.py:769-774): norm, comparison and factor stay on the device; Adam reads the product
+                # (0 = non-finite norm = skip the update)
                 self.norm_buf.zero_()
                 ops.sumsq(f.arena.flat, self.norm_buf)
                 ops.clip_scale(self.norm_buf, self.clip_out, scale_host=scale, scale_dev=scale_dev, clip=self.clip)
                 scale, scale_dev = 1.0, self.clip_out[0:1]
+                self._bad_acc += self.clip_out[2:3]          # sticky on the device: a copy that is skipped below loses nothing
+                if self._flag_host is not None and self._flag_event is None:
+                    self._flag_host.copy_(self._bad_acc, non_blocking=True)
+                    self._flag_event = torch.cuda.Event()
+                    self._flag_event.record()
             ops.adam_step(f.p32, f.p16, f.m, f.v, f.arena.flat, lr=lr, beta1=self.betas[0], beta2=self.betas[1],
                           eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale, scale_dev=scale_dev)
             self.last_lr = lr
         return loss.detach()
-
-    # ---- streamed optimizer -------------------------------------------------------------------------------------
-    def _begin_streamed_adam(self, total_ss):
-        """Called right after the forward of the closing micro-batch: the update's sample_size is known (on the host),
-        so the 1 / sample_size factor - summed over ranks by ONE scalar all-reduce issued before any gradient bucket - and
-        the learning rate are fixed before the first gradient range becomes final."""
-        if self._adam is not None:
-            return
-        f = self.flat
-        lr = self.lr_scheduler.step_update(f.step) if self.lr_scheduler is not None else self.lr
-        f.step += 1
-        st = dict(lr=lr, hi=f.arena.numel, scale=1.0 / float(total_ss), scale_dev=None)
-        if self.exchange is not None:
-            ss = torch.full((1,), float(total_ss), device=f.p16.device, dtype=torch.float32)
-            self.dist.all_reduce(ss, group=self.group)
-            st["scale"], st["scale_dev"] = 1.0, ss.reciprocal_()
-            self.exchange.on_launch = lambda lo, hi, work: self._adam_range(lo, hi, work)
-        self._adam = st
-
-    def _ready_streamed(self, offset):
-        """Backward milestone: arena elements >= offset are final."""
-        if self.exchange is not None:
-            self.exchange.on_ready(offset)        # buckets; each launched bucket calls _adam_range through on_launch
-            return
-        st = self._adam
-        offset = max(0, min(int(offset), st["hi"]))
-        if st["hi"] - offset >= (4 << 20) or offset == 0:      # >= 4 M parameters per launch (a layer is 7 M)
-            self._adam_range(offset, st["hi"], None)
-            st["hi"] = offset
-
-    def _adam_range(self, lo, hi, work):
-        if hi <= lo:
-            return
-        f, st = self.flat, self._adam
-        main = torch.cuda.current_stream()
-        self.opt_stream.wait_stream(main)         # everything that wrote this range was issued on the main stream before now
-        with torch.cuda.stream(self.opt_stream):
-            if work is not None:
-                work.wait()                       # the range's all-reduce (runs on RCCL's stream); blocks opt_stream only
-            ops.adam_step(f.p32[lo:hi], f.p16[lo:hi], f.m[lo:hi], f.v[lo:hi], f.arena.flat[lo:hi], lr=st["lr"],
-                          beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=f.step,
-                          scale_host=st["scale"], scale_dev=st["scale_dev"])
