@@ -258,7 +258,8 @@ def main():
         pmc = json.load(open(cands[-1]))
         src_hash = hashlib.sha256(open(os.path.join(ROOT, "wav2vec-s_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
         key = {"gemm_tn_lc_kernel": "w2vs::gemm_tn_lc_kernel<true>", "gemm_tn_kernel": "w2vs::gemm_tn_kernel",
-               "gemm_tn_group_kernel": "w2vs::gemm_tn_group_kernel"}.get(roof["kernel"].split(" ")[0], roof["kernel"].split("<")[0])
+               "gemm_tn_group_kernel": "w2vs::gemm_tn_group_kernel",
+               "gemm_tn8_group_kernel": "w2vs::gemm_tn8_group_kernel"}.get(roof["kernel"].split(" ")[0], roof["kernel"].split("<")[0])
         if pmc.get("_gemm_hip_sha256") != src_hash:
             roof["traffic_note"] = "%s was collected from another build of gemm.hip: not quoted" % os.path.basename(cands[-1])
         elif key in pmc:

@@ -1434,6 +1434,286 @@ __global__ __launch_bounds__(768) void gemm_tn_group_kernel(TnGroupP g) {
   tn_lc_body<2>(p, first_m + in_group % gsz, in_group / gsz, 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// TN, EIGHT-PHASE (round 3): the weight gradients of an encoder layer on 256 x 256 output tiles - 1.5 x the MFMA work per
+// staged byte of the 256 x 128 loader/consumer tiles above, whose operand stream (not their MFMAs) set the pace - with the
+// phase structure of gemm_nt8_kernel: 8 waves = 2 (m) x 4 (n), every wave stages and computes, three half-tiles in flight
+// behind a counted vmcnt, wave groups staggered by one barrier.  A K tile is 64 token rows; its four half-tile images are
+// [64 k][128] bf16 (A_h: the m-half h columns of both wave groups, B_h: the n-half h columns of all four wave columns) in
+// the k-major orientation of global memory; fragments come out through ds_read_b64_tr_b16 (tswz swizzle on the DMA source).
+// 256 x 256 tiles of a base layer number 108, so the token dimension is split S = 2 ways over workgroup PAIRS (adjacent
+// ids: same XCD) that exchange half a partial tile each at the end (see the tail of the kernel): every output element
+// still has a single writer per launch - no atomics (but the bias column sums), no summing launch.
+// Measured while building it (timing-only ablations, cfgB layer, 216 workgroups x 52 K tiles): the loop runs 1.45 us per
+// K tile with or without its memory traffic (MFMA floor 1.05-1.15 us; fragment reads + barriers alone 1.06 us), i.e. it is
+// issue-bound, not operand-bound like the 256 x 128 kernel; a one-sided hand-off (256 KB slab, plain stores + release
+// fence, last arriver combines) cost ~30 us per launch and erased the gain, hence the symmetric write-through form.
+// ---------------------------------------------------------------------------------------------
+struct Tn8GroupP { GemmP p[4]; int first[5]; int S; float* slab; long slab_bytes; unsigned* cnt; int dbg; };   // dbg: timing-only ablations
+// the tr read as inline asm: behind the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the first read of every loop
+// iteration (an LDS read without a memory operand "may alias" every LDS-DMA in flight), which drains the staging pipeline.
+// The wave waits for these reads itself: s_waitcnt lgkmcnt(0) + sched_barrier behind the phase's first barrier.
+template <int OFF> __device__ __forceinline__ s16x4 ds_tr_asm(uint32_t lds_byte_addr) {   // OFF: immediate byte offset (< 64 KiB)
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int OFF> __device__ __forceinline__ bf16x8 tr_frag(uint32_t lds_byte_addr) {      // k rows q and q + 4 of a 32-deep step
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = ds_tr_asm<OFF>(lds_byte_addr);
+  u.h[1] = ds_tr_asm<OFF + 4 * TP * 2>(lds_byte_addr);
+  return u.v;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
+  constexpr int IMG = TK * TP;                    // [64 k][128] bf16 = 16 KiB
+  constexpr int BUF_EL = 4 * IMG;                 // A_h0 A_h1 B_h0 B_h1
+  __shared__ __attribute__((aligned(16))) bf16 lds[2 * BUF_EL];     // 128 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  int tile, sp;
+  {
+    const int nwg = gridDim.x, lin = blockIdx.x;
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = lin & 7;
+    const int id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (lin >> 3);   // contiguous run per XCD
+    tile = id / g.S; sp = id - tile * g.S;
+  }
+  int pi = 0;
+  if (tile >= g.first[1]) pi = 1;
+  if (tile >= g.first[2]) pi = 2;
+  if (tile >= g.first[3]) pi = 3;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  const GemmP& p = g.p[pi];
+  const int t = tile - g.first[pi];
+  const int ntn = (p.N + 255) / 256;
+  const int tm = t / ntn, tn = t - tm * ntn;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int units = (p.K + TK - 1) / TK;
+  const int u0 = (int)((long)sp * units / g.S), u1 = (int)((long)(sp + 1) * units / g.S);
+  const int nk = u1 - u0, nk2 = (nk + 1) & ~1;
+  __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes), rb = make_rsrc(p.B, p.b_bytes);
+  // ---- staging: piece pc = j * 8 + wid of an image = k rows pc*4 .. pc*4+3 (lane >> 4 = row, lane & 15 = physical chunk)
+  const int l4 = lane >> 4;
+  const int wsw = l4 | (((wid >> 1) & 1) << 2);                 // tswz window of row (j*32 + wid*4 + l4): independent of j
+  const int lc = (lane & 15) ^ (wsw << 1);                      // logical 16-byte chunk (8 columns) this lane fetches
+  const uint32_t a_thr = (uint32_t)((p.a_off + (long)(u0 * TK + wid * 4 + l4) * p.lda + m0 + (lc >> 3) * 128 + (lc & 7) * 8) * 2);
+  const uint32_t b_thr = (uint32_t)(((long)(u0 * TK + wid * 4 + l4) * p.ldb + n0 + (lc >> 2) * 64 + (lc & 3) * 8) * 2);
+  const uint32_t a_j = (uint32_t)(32 * p.lda * 2), b_j = (uint32_t)(32 * p.ldb * 2);      // piece j = 1: 32 rows further
+  const uint32_t a_kt = (uint32_t)(TK * p.lda * 2), b_kt = (uint32_t)(TK * p.ldb * 2);    // next K tile
+  int kt_s = 0;
+  const bool live = !(g.dbg & 1);                 // dbg bit 0: every DMA out of range (zero fill, no memory traffic)
+  bool ok_cur = nk > 0 && live, ok_prev = false;
+  uint32_t a_cur = a_thr, b_cur = b_thr, a_prev = 0;
+  auto advance = [&]() {
+    a_prev = a_cur; ok_prev = ok_cur;
+    ++kt_s;
+    a_cur += a_kt; b_cur += b_kt;
+    ok_cur = kt_s < nk && live;
+  };
+  auto stage_A = [&](int buf, int h, uint32_t base, bool ok) {    // h: + 64 columns
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t o = ok ? base + (j ? a_j : 0u) + (uint32_t)(h * 128) : 0xFFFFFFF0u;
+      bf16* dst = lds + buf * BUF_EL + h * IMG + (j * 8 + wid) * 512;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+    }
+  };
+  auto stage_B = [&](int buf, int h, uint32_t base, bool ok) {    // h: + 32 columns
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t o = ok ? base + (j ? b_j : 0u) + (uint32_t)(h * 64) : 0xFFFFFFF0u;
+      bf16* dst = lds + buf * BUF_EL + (2 + h) * IMG + (j * 8 + wid) * 512;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
+    }
+  };
+  // ---- fragment addresses (elements): 16-lane group gq owns k rows 8 gq .. 8 gq + 7 of a 32-deep step; inside it lane
+  // 4 q + pp supplies row q (and q + 4), columns 4 pp .. 4 pp + 3, and receives column (lane & 15)
+  const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int rsw = (q | ((gq & 1) << 2)) << 4;                   // tswz of rows (ks*32 + gq*8 + q) and (.. + 4): the same window
+  // (byte addresses inside the LDS, one set per K-tile buffer: buffer 1 lies 64 KiB up, beyond an immediate offset)
+  uint32_t a_tr[2][4], b_tr[2][2];
+  {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)lds;
+    // fragment slot i of wave column wc holds i-tile (i + wc) & 3 of the m-half: the wave's share of the bias column sums
+    // (one i-tile per wave column) is then always slot 0 - a wave-dependent CHOICE among the slots would make them a
+    // runtime-indexed array, which hipcc keeps in scratch memory
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a_tr[eb][i] = lds0 + (uint32_t)(eb * BUF_EL + (gq * 8 + q) * TP + ((wr * 64 + ((i + wc) & 3) * 16 + pp * 4) ^ rsw)) * 2;
+#pragma unroll
+      for (int j1 = 0; j1 < 2; ++j1)
+        b_tr[eb][j1] = lds0 + (uint32_t)(eb * BUF_EL + 2 * IMG + (gq * 8 + q) * TP + ((wc * 32 + j1 * 16 + pp * 4) ^ rsw)) * 2;
+    }
+  }
+  constexpr int KS1 = 32 * TP * 2, IMGB = IMG * 2;      // byte offsets: second 32-deep k step; next half-tile image
+  // bias gradient (column sums of A) on the matrix cores, spread over the four wave columns of the tn == 0 tiles: wave
+  // column wc takes the i-tile wc of each m-half against an all-ones fragment
+  const bool do_cs = p.colsum != nullptr && tn == 0;
+  union { bf16x8 v; uint32_t u[4]; } ones;
+  ones.u[0] = ones.u[1] = ones.u[2] = ones.u[3] = 0x3F803F80u;
+
+  // ---- prologue
+  stage_B(0, 0, b_cur, ok_cur); stage_A(0, 0, a_cur, ok_cur); stage_B(0, 1, b_cur, ok_cur); stage_A(0, 1, a_cur, ok_cur);
+  advance();
+  stage_B(1, 0, b_cur, ok_cur); stage_A(1, 0, a_cur, ok_cur); stage_B(1, 1, b_cur, ok_cur);
+  advance();
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  f32x4 acc[2][4][4], cs[2];
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh) {
+    cs[mh] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[mh][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 af[4][2], b0[2][2], b1[2][2];
+  auto mfma_q = [&](int mh, int nh, bf16x8 (&bb)[2][2], bool with_cs) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this phase's (inline-asm) fragment reads
+    __builtin_amdgcn_sched_barrier(0);                     // ... and no MFMA may move above the wait
+    if (g.dbg & 2) return;                                 // dbg bit 1: no MFMAs
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j1 = 0; j1 < 2; ++j1)   // operands swapped: lane (fr, fq) holds output row i*16 + fr, columns j*16 + 4 fq .. + 3
+          acc[mh][i][nh * 2 + j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[j1][ks], af[i][ks], acc[mh][i][nh * 2 + j1], 0, 0, 0);
+    if (with_cs) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) cs[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, af[0][ks], cs[mh], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto ktile = [&](auto ebuf) {
+    constexpr int EB = decltype(ebuf)::value;
+    // ---- phase 1: B_h0 first; lgkmcnt counts to 15 only, so the wait that retires those 4 fragments (8 reads) sits
+    // after 7 of the 16 A reads
+#pragma unroll
+    for (int j1 = 0; j1 < 2; ++j1) { b0[j1][0] = tr_frag<0>(b_tr[EB][j1]); b0[j1][1] = tr_frag<KS1>(b_tr[EB][j1]); }
+    af[0][0] = tr_frag<0>(a_tr[EB][0]); af[0][1] = tr_frag<KS1>(a_tr[EB][0]); af[1][0] = tr_frag<0>(a_tr[EB][1]);
+    {
+      union { bf16x8 v; s16x4 h[2]; } u;
+      u.h[0] = ds_tr_asm<KS1>(a_tr[EB][1]);
+      asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+      u.h[1] = ds_tr_asm<KS1 + 4 * TP * 2>(a_tr[EB][1]);
+      af[1][1] = u.v;
+    }
+    af[2][0] = tr_frag<0>(a_tr[EB][2]); af[2][1] = tr_frag<KS1>(a_tr[EB][2]);
+    af[3][0] = tr_frag<0>(a_tr[EB][3]); af[3][1] = tr_frag<KS1>(a_tr[EB][3]);
+    stage_A(EB ^ 1, 1, a_prev, ok_prev);
+    __builtin_amdgcn_s_barrier();
+    mfma_q(0, 0, b0, do_cs);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2
+#pragma unroll
+    for (int j1 = 0; j1 < 2; ++j1) { b1[j1][0] = tr_frag<IMGB>(b_tr[EB][j1]); b1[j1][1] = tr_frag<IMGB + KS1>(b_tr[EB][j1]); }
+    stage_B(EB, 0, b_cur, ok_cur);
+    __builtin_amdgcn_s_barrier();
+    mfma_q(0, 1, b1, false);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i][0] = tr_frag<IMGB>(a_tr[EB][i]); af[i][1] = tr_frag<IMGB + KS1>(a_tr[EB][i]); }
+    stage_A(EB, 0, a_cur, ok_cur);
+    __builtin_amdgcn_s_barrier();
+    mfma_q(1, 1, b1, do_cs);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4
+    stage_B(EB, 1, b_cur, ok_cur);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    mfma_q(1, 0, b0, false);
+    __builtin_amdgcn_s_barrier();
+    advance();
+  };
+  for (int kp = 0; kp < nk2; kp += 2) {
+    ktile(std::integral_constant<int, 0>{});
+    ktile(std::integral_constant<int, 1>{});
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's extra barrier: both groups in step again
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing (out-of-range) prefetches have landed: the LDS is free
+  __builtin_amdgcn_s_barrier();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // ---- split K over a PAIR of workgroups (S == 2), symmetric exchange: workgroup sp keeps the column half sp of the tile
+  // (wave columns 2 sp, 2 sp + 1) and gives the other half away.  The four giving waves park their accumulators in the slab
+  // with write-through (sc1) 16-byte stores, lane-linear (the partner's waves have the same lane -> element map), drain,
+  // and after the workgroup barrier one lane raises flag[tile][sp].  Then one lane polls the PARTNER's flag, lowers it
+  // again (the flags are zero between launches), and after another barrier the four keeping waves add the partner's half
+  // (sc1 loads: no acquire needed, guide Guideline 16 / MI355X_MICROARCH "Valid forms") and update Cf with plain 16-byte
+  // loads / stores.  Every output element has one writer per launch; both workgroups work during the exchange.
+  bool keep = true;
+  if (g.S == 2) {
+    keep = (wc >> 1) == sp;
+    const int ws = wr * 2 + (wc & 1);                       // wave slot inside a half: 0 .. 3
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(g.slab, (uint32_t)g.slab_bytes);
+    unsigned* flags = g.cnt + tile * 2;
+    if (!keep) {
+      const uint32_t o = (uint32_t)(((tile * 2 + sp) * 4 + ws) * 32) * 1024u + (uint32_t)lane * 16u;   // 32 x 1 KiB per wave
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            union { f32x4 f; u32x4 u; } cv; cv.f = acc[mh][i][j];
+            __builtin_amdgcn_raw_buffer_store_b128(cv.u, rs, o + (uint32_t)(((mh * 4 + i) * 4 + j) * 1024), 0, 16);   // aux 16 = sc1
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the flag
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(flags + sp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(flags + (sp ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
+      __hip_atomic_store(flags + (sp ^ 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    }
+    __syncthreads();
+    if (keep) {
+      const uint32_t o = (uint32_t)(((tile * 2 + (sp ^ 1)) * 4 + ws) * 32) * 1024u + (uint32_t)lane * 16u;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            union { f32x4 f; u32x4 u; } cv;
+            cv.u = __builtin_amdgcn_raw_buffer_load_b128(rs, o + (uint32_t)(((mh * 4 + i) * 4 + j) * 1024), 0, 16);
+            acc[mh][i][j][0] += cv.f[0]; acc[mh][i][j][1] += cv.f[1]; acc[mh][i][j][2] += cv.f[2]; acc[mh][i][j][3] += cv.f[3];
+          }
+    }
+  }
+  if (keep) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = m0 + wr * 128 + mh * 64 + ((i + wc) & 3) * 16 + fr, col = n0 + wc * 64 + j * 16 + fq * 4;
+          if (row >= p.M || col >= p.N) continue;      // N % 8 == 0: the four columns are in or out together
+          f32x4* dst = (f32x4*)(p.Cf + (long)row * p.ldc + col);
+          f32x4 o = *dst;
+          o[0] += acc[mh][i][j][0] * p.alpha; o[1] += acc[mh][i][j][1] * p.alpha;
+          o[2] += acc[mh][i][j][2] * p.alpha; o[3] += acc[mh][i][j][3] * p.alpha;
+          *dst = o;
+        }
+  }
+  if (do_cs && fq == 0) {   // every accumulator row of cs holds the same sums: lane fr owns output row (i-tile wc = slot 0) * 16 + fr
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      const int row = m0 + wr * 128 + mh * 64 + wc * 16 + fr;
+      if (row < p.M) atomicAdd(&p.colsum[row], cs[mh][0] * p.alpha);
+    }
+  }
+}
+
 // Cf[m][n] += sum over parts of slab[part][m][n]   (M x N fp32, N % 4 == 0; Cf rows are ldc apart)
 __global__ __launch_bounds__(256) void tn_slab_reduce_kernel(const float* slab, int parts, int M, int N, long ldc, float* Cf) {
   const long i4 = (long)blockIdx.x * 256 + threadIdx.x;      // one float4 per thread
@@ -1763,6 +2043,42 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
     ok = ok && (d.batch <= 1) && d.sC == 0 && (d.ldc % 4) == 0 && ((uintptr_t)d.Cf % 16) == 0 && d.K >= 8 * TK;
   }
   for (int i = n; i <= 4; ++i) g.first[i] = tiles;
+  // Round 3: 256 x 256 tiles + split K over workgroup pairs (gemm_tn8_group_kernel) when that fills the chip better
+  static const int tn8_env = [] { const char* e = getenv("W2VS_TN8"); return e ? atoi(e) : 1; }();
+  if (ok && tn8_env) {
+    Tn8GroupP g8{};
+    int t8 = 0;
+    for (int i = 0; i < n; ++i) { g8.p[i] = g.p[i]; g8.first[i] = t8; t8 += ((ds[i].N + 255) / 256) * ((ds[i].M + 255) / 256); }
+    for (int i = n; i <= 4; ++i) g8.first[i] = t8;
+    int minK = ds[0].K;
+    for (int i = 1; i < n; ++i) minK = std::min(minK, ds[i].K);
+    int S = std::max(1, std::min(2, ncu / std::max(1, t8)));
+    while (S > 1 && (minK < 8 * TK * S || !ds[0].ws || ds[0].ws_bytes < (int64_t)t8 * (S - 1) * 65536 * 4 || ((uintptr_t)ds[0].ws % 16))) --S;
+    // worth it when the 256^2 grid keeps at least as many CUs busy as the 256 x 128 grid would (a base layer: 108 tiles x 2)
+    if (t8 * S <= ncu && t8 * S * 8 >= ncu * 5 && t8 <= 1024) {
+      // 16 regions x 1024 tiles x 2 exchange flags, used round-robin (launches in flight on different streams do not share
+      // one); zero between launches: whoever polls a flag lowers it again
+      static unsigned* cnt_pool = nullptr;
+      static int cnt_next = 0;
+      if (!cnt_pool) {
+        if (hipMalloc((void**)&cnt_pool, 16 * 2048 * sizeof(unsigned)) != hipSuccess) return set_error("gemm_tn_group: flag allocation failed");
+        // on the launch stream: a memset on the null stream is not ordered with a kernel on a non-blocking stream
+        if (hipMemsetAsync(cnt_pool, 0, 16 * 2048 * sizeof(unsigned), s) != hipSuccess) return set_error("gemm_tn_group: flag memset failed");
+      }
+      static const int dbg_env = [] { const char* e = getenv("W2VS_TN8_DBG"); return e ? atoi(e) : 0; }();
+      static const int s_env = [] { const char* e = getenv("W2VS_TN8_S"); return e ? atoi(e) : 0; }();
+      if (s_env > 0) S = std::min(S, s_env);
+      g8.dbg = dbg_env;
+      g8.S = S; g8.slab = (float*)ds[0].ws; g8.slab_bytes = std::min<int64_t>(ds[0].ws_bytes, 0x7FFFFFF0L);
+      g8.cnt = cnt_pool + 2048 * (cnt_next++ & 15);
+      static const bool tn_log8 = getenv("W2VS_GEMM_LOG") != nullptr;
+      if (tn_log8) fprintf(stderr, "gemm_tn_group -> 8-phase, %d tiles of 256x256, split K %d\n", t8, S);
+      hipEvent_t pe = prof_begin(s, 5);
+      hipLaunchKernelGGL(gemm_tn8_group_kernel, dim3(t8 * S), dim3(512), 0, s, g8);
+      prof_end(pe, 13, flops, s);                  // id 13: the 8-phase grouped weight-gradient launch
+      return hip_check(hipGetLastError(), "gemm_tn8_group launch");
+    }
+  }
   static const int grp_env = [] { const char* e = getenv("W2VS_TN_GROUP"); return e ? atoi(e) : 1; }();
   // grouped only when it fills >= 3/4 of the chip AND leaves some slack: with exactly one workgroup per CU a single CU that is
   // not free at dispatch costs a whole extra round of full-length K loops (measured on the large model's 128 + 128 tiles)

@@ -126,7 +126,8 @@ class _GemmTimer:
         epis = ["none", "bias", "bias_gelu", "bias_gelu_save", "dgelu", "f32", "add", "bias_gelu_savegrad", "mul"]
         names = {16 * f + e: "%s<%s>" % (fn, en) for f, fn in enumerate(("gemm_nt_kernel", "gemm_nt_lc_kernel", "gemm_nt_p_kernel", "gemm_nt8_kernel"))
                  for e, en in enumerate(epis)}
-        names.update({10: "gemm_tn_kernel", 11: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)", 12: "gemm_tn_group_kernel"})
+        names.update({10: "gemm_tn_kernel", 11: "gemm_tn_lc_kernel (+ tn_slab_reduce_kernel)", 12: "gemm_tn_group_kernel",
+                      13: "gemm_tn8_group_kernel"})
         groups = {}
         for k in names:
             ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
@@ -144,10 +145,10 @@ class _GemmTimer:
                "frac": round(ach / peak_tflops, 4), "traffic": None, "launches_timed": n,
                "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": round(fl / n / 1e9, 3),
                "launches_in_timed_region": groups[k][3]}
-        nt = [g for kk, g in groups.items() if kk not in (10, 11, 12)]
+        nt = [g for kk, g in groups.items() if kk not in (10, 11, 12, 13)]
         if nt:
             out["all_gemm_nt_tflops"] = round(sum(g[1] for g in nt) / sum(g[0] for g in nt) / 1e12, 1)
-        tn = [g for kk, g in groups.items() if kk in (10, 11, 12)]
+        tn = [g for kk, g in groups.items() if kk in (10, 11, 12, 13)]
         if tn:
             out["all_gemm_tn_tflops"] = round(sum(g[1] for g in tn) / sum(g[0] for g in tn) / 1e12, 1)
         return out
