@@ -261,6 +261,71 @@ def load_joiner():
     return _JOINER
 
 
+_HEAD = None
+
+
+def load_transducer_out():
+    """The reference's CAAT loss head ``TransducerOut`` (``rain/layers/attention_transducer.py:289-456``), executable on the CPU
+    at ``delay_scale = 0``.
+
+    The class source is read from the reference file where it lies and executed unchanged (as ``load_joiner`` does for the
+    joint network), together with ``label_smoothed_nll_loss`` (``fs/criterions/label_smoothed_cross_entropy.py:33-50``, whose
+    module needs omegaconf - an ordinary ModuleNotFoundError).  Its one dependency that exists only for CUDA,
+    ``warprnnt_pytorch.DelayTLoss``, is bound to the reference's OWN CPU transducer compiled into
+    ``oracle/_ref/libwarprnnt_cpu.so`` (``make -C oracle ref``; wt/src/rnnt_entrypoint.cpp + cpu_rnnt.h): same constructor and
+    ``forward(acts, labels, act_lens, label_lens) -> (total, rnnt, delay)`` (delay_transducer.py:45-178), log-softmax applied
+    in front as warprnnt_pytorch/rnnt.py:67-68 does for the CPU path.  The CPU transducer has no delay terms, so the binding
+    accepts ``delay_scale == 0`` only and reports the delay cost as 0: everything but the delay term itself is the
+    reference's arithmetic."""
+    global _HEAD
+    if _HEAD is not None:
+        return _HEAD
+    load()
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch import autograd
+    import rnnt_oracle as R
+    assert R.RefCpuRnnt.available(), "build oracle/_ref first: make -C oracle ref"
+    cpu = R.RefCpuRnnt()
+
+    class _RefRnnt(autograd.Function):
+        @staticmethod
+        def forward(ctx, log_probs, labels, act_lens, label_lens, blank):
+            costs, g = cpu.loss_and_logprob_grads(log_probs.detach().numpy(), labels.numpy(), act_lens.numpy(),
+                                                  label_lens.numpy(), blank)
+            ctx.g = torch.from_numpy(np.ascontiguousarray(g))
+            return torch.from_numpy(costs.astype(np.float32)).sum()
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            return ctx.g * grad_out, None, None, None, None
+
+    class DelayTLoss(nn.Module):              # constructor of delay_transducer.py:149-166
+        def __init__(self, blank=0, delay_scale=1.0, temperature=1.0, reduction="sum", delay_func="zero"):
+            super().__init__()
+            assert delay_scale == 0 and temperature == 1.0 and reduction == "sum", "the CPU transducer has no delay terms"
+            self.blank = blank
+
+        def forward(self, acts, labels, act_lens, label_lens):
+            total = _RefRnnt.apply(F.log_softmax(acts.float(), dim=-1), labels, act_lens, label_lens, self.blank)
+            return total, total.detach(), torch.zeros(())
+
+    def _lines(path, first_prefix, stop_prefixes):
+        lines = open(path).read().split("\n")
+        start = next(i for i, l in enumerate(lines) if l.startswith(first_prefix))
+        stop = next(i for i in range(start + 1, len(lines)) if any(lines[i].startswith(sp) for sp in stop_prefixes))
+        return compile("\n" * start + "\n".join(lines[start:stop]), path, "exec")     # keeps the reference's line numbers
+
+    ns = dict(torch=torch, nn=nn, F=F, Tensor=torch.Tensor, autograd=autograd, DelayTLoss=DelayTLoss)
+    exec(_lines(os.path.join(REF_ROOT, "fairseq", "fairseq", "criterions", "label_smoothed_cross_entropy.py"),
+                "def label_smoothed_nll_loss", ("@register_criterion", "class ")), ns)
+    exec(_lines(os.path.join(REF_ROOT, "rain", "layers", "attention_transducer.py"), "class TransducerOut", ("class ", "def ")), ns)
+    _HEAD = types.SimpleNamespace(TransducerOut=ns["TransducerOut"], DelayTLoss=DelayTLoss)
+    return _HEAD
+
+
 def make_cfg(ref, **overrides):
     """Wav2VecSConfig with the base yaml's model overrides
     (fairseq/examples/wav2vec/config/pretraining/wav2vec-S_base_librispeech.yaml:50-77)."""

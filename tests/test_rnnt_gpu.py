@@ -356,3 +356,33 @@ def test_fp64_entry_equals_the_fp32_entry():
         np.testing.assert_allclose(costs, c32, rtol=1e-6, atol=1e-6)
         if want_grad:
             np.testing.assert_allclose(g64.cpu().numpy(), g32, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["mb1", "mb3", "mb3_scaled"])
+def test_transducer_out_head_matches_reference_fixture(tag, golden_dir):
+    """The HIP loss head against values recorded from the REFERENCE's TransducerOut.train_step at delay_scale = 0
+    (tests/golden/transducer_out.npz <- gen_golden_transducer_out.py: rain/layers/attention_transducer.py:289-408 executed with
+    DelayTLoss bound to the reference's compiled CPU transducer): losses, d x, d W for 1 and 3 micro-batches, label
+    smoothing 0.1, and with the reference's scaler protocol (an object that only has .scale(loss))."""
+    from wav2vec_s_amd import transducer as tr
+    z = np.load(os.path.join(golden_dir, "transducer_out.npz"))
+    B, T, U, d, V = [int(v) for v in z["cfg"]]
+    proj = torch.nn.Linear(d, V, bias=False).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        proj.weight.copy_(torch.from_numpy(z["W"]))                       # bf16-representable values
+    head = tr.TransducerOut(proj, delay_scale=0.0, tokens_per_step=int(z[f"{tag}.tokens_per_step"]), blank=0, label_smoothing=0.1,
+                            delay_func="zero", pad=1, ce_scale=1.0, temperature=1.0)
+    up = torch.nn.Parameter(torch.from_numpy(z["x"]).to(torch.bfloat16).cuda())
+    scale = float(z[f"{tag}.loss_scale"])
+
+    class _Scaler:                                                         # attention_transducer.py:397-398 calls scaler.scale(loss)
+        def scale(self, loss):
+            return loss * scale
+    res = head.train_step(up * 1.0, torch.from_numpy(z["targets"]).cuda(), torch.from_numpy(z["src_len"]).cuda(),
+                          torch.from_numpy(z["tgt_len"]).cuda(), scaler=_Scaler() if scale != 1.0 else None)
+    for k in ("loss", "loss_prob", "nll_loss"):
+        np.testing.assert_allclose(float(res[k]), float(z[f"{tag}.{k}"]), rtol=2e-3)
+    assert res["sample_size"] == int(z[f"{tag}.sample_size"])
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))      # noqa: E731
+    assert rel(up.grad.float().cpu().numpy(), z[f"{tag}.dx"]) < 1e-2
+    assert rel(proj.weight.grad.float().cpu().numpy(), z[f"{tag}.dW"]) < 1e-2

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import rnnt_oracle as R
+from conftest import GOLDEN
 
 
 @pytest.fixture(scope="module")
@@ -165,3 +166,24 @@ def test_label_smoothed_ce_and_head_against_torch_autograd():
     np.testing.assert_allclose(dx, xt.grad.numpy(), atol=1e-10)
     np.testing.assert_allclose(dW, Wt.grad.numpy(), atol=1e-10)
     np.testing.assert_allclose(out["loss"], out["loss_prob"] + 0.7 * ce.item(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["mb1", "mb3", "mb3_scaled"])
+def test_transducer_out_oracle_matches_reference_fixture(tag):
+    """The loss head's oracle against the REFERENCE's TransducerOut.train_step (rain/layers/attention_transducer.py:289-408,
+    executed with its CUDA-only DelayTLoss bound to the reference's compiled CPU transducer: tests/golden/
+    gen_golden_transducer_out.py) at delay_scale = 0: total / transducer / cross-entropy losses, d x and d W, for 1 and 3
+    micro-batches and under a loss scaler.  Only the delay term itself stays unpinned."""
+    z = np.load(os.path.join(GOLDEN, "transducer_out.npz"))
+    out, dx, dW = R.transducer_out_step(z["x"], z["W"], z["targets"], z["src_len"], z["tgt_len"], delay_scale=0.0, temperature=1.0,
+                                        label_smoothing=0.1, pad=1, ce_scale=1.0, delay_func="zero",
+                                        loss_scale=float(z[f"{tag}.loss_scale"]), tokens_per_step=int(z[f"{tag}.tokens_per_step"]))
+    B, T, U = z["x"].shape[:3]
+    assert len(range(0, B, max(int(z[f"{tag}.tokens_per_step"]) // (T * U), 1))) == int(z[f"{tag}.micro_batches"])
+    np.testing.assert_allclose(out["loss"], float(z[f"{tag}.loss"]), rtol=2e-6)
+    np.testing.assert_allclose(out["loss_prob"], float(z[f"{tag}.loss_prob"]), rtol=2e-6)
+    np.testing.assert_allclose(out["nll_loss"], float(z[f"{tag}.nll_loss"]), rtol=2e-6)
+    assert int((z["targets"] != 1).sum()) == int(z[f"{tag}.sample_size"])
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))      # noqa: E731
+    assert rel(dx, z[f"{tag}.dx"]) < 1e-5 and rel(dW, z[f"{tag}.dW"]) < 1e-5,    # measured 2.2e-6 (the reference runs fp32)
+        (rel(dx, z[f"{tag}.dx"]), rel(dW, z[f"{tag}.dW"]))

@@ -377,7 +377,11 @@ class TransducerOut(Module):
         w16 = self._w16()
         wt16 = ops.transpose2d(w16) if train else None
         dw32 = torch.zeros(w16.shape, dtype=torch.float32, device=x.device) if train else None
-        loss_scale = float(scaler.get_scale()) if (scaler is not None and train) else 1.0
+        loss_scale = 1.0
+        if scaler is not None and train:
+            # the reference only calls scaler.scale(loss) (attention_transducer.py:397-398): a torch GradScaler has get_scale();
+            # anything else is asked what it does to a one
+            loss_scale = float(scaler.get_scale()) if hasattr(scaler, "get_scale") else float(scaler.scale(torch.ones(())))
         xs = x.detach()
         xs = (xs if xs.dtype == torch.bfloat16 else xs.to(torch.bfloat16)).contiguous()
         # the one host round trip of the step (the reference has one too: `.item()` on the token count, :402): the lengths decide
