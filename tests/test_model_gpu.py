@@ -207,6 +207,17 @@ def test_large_full_width_step_matches_oracle():
     _assert_parity(rep, grads, loss=1e-3, loss_free=1e-3, act=2e-2, bar_scale=1.7, median=4e-2)
 
 
+def test_large_full_length_step_matches_oracle():
+    """BASELINE configs[3] at its OWN length: 3 x 320 000 samples (T = 999 frames, N = 1 496 encoder tokens, R = 4 488 rows:
+    the four-wave attention instantiations, 160 x 256 / 8-phase tiles at that row count) at full width (d = 1024, 16 heads,
+    ffn 4096, final_dim 768, pre-LN, conv bias, 7 extractor LayerNorms) with 3 encoder layers - the CPU oracle's cost
+    is bounded by the layer count, every kernel shape of the 24-layer step occurs."""
+    kw = dict(BASE, encoder_layers=3, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
+              layer_norm_first=True, conv_bias=True, feature_grad_mult=1.0, final_dim=768)
+    rep, grads = _run_both(kw, B=3, L=320000, seed=14, m_ctx=16, r_ctx=8, loss_weights=(0.1, 0.0), tag="large_full_length")
+    _assert_parity(rep, grads, loss=1e-3, loss_free=1e-3, act=2e-2, bar_scale=1.7, median=4e-2)
+
+
 def test_large_style_model_step_matches_oracle():
     """pre-LN encoder, conv bias, LayerNorm in every conv layer (layer_norm_num=7), odd T, no grad mult."""
     kw = dict(BASE, encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,

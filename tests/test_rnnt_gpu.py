@@ -334,8 +334,14 @@ def test_fp64_entry_equals_the_fp32_entry():
     from wav2vec_s_amd import transducer as tr
     lib = tr._rnnt_lib()
     lib.compute_rnnt_loss_fp64.restype = C.c_int
+    _fp64_case(3, 7, 5, 11)                                              # 1155 elements: odd -> allocated activation staging
+    _fp64_case(3, 7, 5, 12)                                              # 1260 = 4 x 315: staged inside the gradient buffer, odd passes
+
+
+def _fp64_case(B, T, U, V):
+    from wav2vec_s_amd import transducer as tr
+    lib = tr._rnnt_lib()
     rng = np.random.default_rng(5)
-    B, T, U, V = 3, 7, 5, 11                                             # 1155 elements: odd
     acts = rng.standard_normal((B, T, U, V)).astype(np.float32)
     lab = rng.integers(1, V, size=(B, U - 1)).astype(np.int32)
     xl, yl = np.array([7, 5, 6], dtype=np.int32), np.array([4, 2, 3], dtype=np.int32)

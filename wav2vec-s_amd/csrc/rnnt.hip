@@ -606,8 +606,9 @@ rnntStatus_t get_workspace_size(int maxT, int maxU, int minibatch, bool gpu, siz
 // this entry needs fp32-sized steps and tolerances).  No allocation on the gradient path: the caller's fp64 gradient
 // buffer (8 n bytes) doubles as the staging area - fp32 gradients in its first half, the narrowed activations in its
 // second - and the gradients are widened in place, top half first (pass [ceil(hi/2), hi) writes bytes >= 4 hi, which
-// only holds values already widened or the dead activations).  Costs-only calls (gradients == NULL) have no such buffer
-// and allocate the activation staging.  Synchronous, like the reference's entry (costs land on the host).
+// only holds values already widened or the dead activations).  Costs-only calls (gradients == NULL) have no such buffer,
+// and an element count that is not a multiple of 4 leaves the second half misaligned for the kernels' 16-byte accesses:
+// those two cases allocate the activation staging.  Synchronous, like the reference's entry (costs land on the host).
 rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gradients, const int* const flat_labels,
                                     const int* const label_lengths, const int* const input_lengths, int alphabet_size,
                                     int minibatch, double* costs, void* workspace, rnntOptions options) {
@@ -618,8 +619,14 @@ rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gra
   const long n = (long)minibatch * options.maxT * options.maxU * alphabet_size;
   float* a32 = nullptr;
   float* g32 = nullptr;
-  if (gradients) { g32 = (float*)gradients; a32 = g32 + n; }
-  else if (hipMalloc((void**)&a32, sizeof(float) * n) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
+  // (the kernels take 16-byte aligned activations / gradients: the second half of the gradient buffer qualifies when n % 4 == 0)
+  bool own_a32 = true;
+  if (gradients) {
+    if ((uintptr_t)gradients & 15) return RNNT_STATUS_INVALID_VALUE;
+    g32 = (float*)gradients;
+    if ((n & 3) == 0) { a32 = g32 + n; own_a32 = false; }
+  }
+  if (own_a32 && hipMalloc((void**)&a32, sizeof(float) * n) != hipSuccess) return RNNT_STATUS_MEMOPS_FAILED;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks), dim3(256), 0, st, activations, a32, n);
   std::vector<float> c32((size_t)minibatch);
@@ -635,7 +642,7 @@ rnntStatus_t compute_rnnt_loss_fp64(const double* const activations, double* gra
   }
   if (rc == RNNT_STATUS_SUCCESS)
     for (int b = 0; b < minibatch; ++b) costs[b] = (double)c32[b];
-  if (!gradients) (void)hipFree(a32);
+  if (own_a32) (void)hipFree(a32);
   return rc;
 }
 
