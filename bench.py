@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--update-freq", type=int, default=1,
                     help="micro-batches per optimizer update (BASELINE configs[2] quotes 8); a timed 'step' stays ONE micro-batch "
                          "pass, so K steps = K micro-batches and K / update_freq updates + gradient exchanges")
+    ap.add_argument("--length-mix", action="store_true",
+                    help="--workload large only: Libri-light-shaped batches - every step draws its utterance lengths from "
+                         "U[160 000, 320 000] and crops to the batch minimum (raw_audio_dataset.py:131-151, pad=False)")
     ap.add_argument("--workload", default="pretrain", choices=["pretrain", "stream", "data", "rnnt", "caat", "large"],
                     help="pretrain (default) = the headline step; stream / data / rnnt = the SURVEY section 8 rows f1 / f3 / f4 "
                          "measurements (tools/bench_*.py) with their CPU baselines attached here")
@@ -204,6 +207,18 @@ def main():
     torch.manual_seed(1234)
     torch.cuda.manual_seed(1234)
     sample = {"net_input": {"source": source}}
+    mix_rng = np.random.RandomState(4321)       # its own stream: the host draws of the model keep theirs
+    audio_done = [0.0]
+
+    def next_sample():
+        """The fixed batch, or (--length-mix) a Libri-light-shaped one: B lengths from U[160 000, 320 000] cropped to their
+        minimum, as the reference's collater does with pad=False (fs/data/audio/raw_audio_dataset.py:131-151)."""
+        if not (large and args.length_mix):
+            audio_done[0] += B * L / SR
+            return sample
+        lmin = int(mix_rng.randint(160000, 320001, size=B).min())
+        audio_done[0] += B * lmin / SR
+        return {"net_input": {"source": source[:, :lmin].contiguous()}}
 
     def barrier():
         if dist is not None:
@@ -217,16 +232,24 @@ def main():
         as actually drawn - sampled contexts and LayerDrop change them -, last loss)."""
         for i in range(n_warm):
             model.set_num_updates(first_update + i)
-            step_fn(sample)
+            step_fn(next_sample())
         barrier()
         fl = 0.0
+        audio_done[0] = 0.0
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]   # per-step GPU time without a host sync
+        marks[0].record()
         t0 = time.perf_counter()
         for i in range(n_steps):
             model.set_num_updates(first_update + n_warm + i)
-            loss = step_fn(sample)
+            loss = step_fn(next_sample())
+            marks[i + 1].record()
             fl += flops_mod.step_flops_from_state(model._last_state)     # host arithmetic on the step's own draws
         barrier()
-        return time.perf_counter() - t0, fl, loss
+        el = time.perf_counter() - t0
+        per_step_ms[:] = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)]
+        return el, fl, loss
+
+    per_step_ms = []
 
     for i in range(args.warmup):
         model.set_num_updates(i)
@@ -240,7 +263,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
-    audio_s = B * L / SR
+    ms_median = float(np.median(per_step_ms)) if per_step_ms else None
+    audio_s = audio_done[0] / args.steps        # per step and GPU (== B * L / SR unless --length-mix)
     value = world * audio_s * args.steps / elapsed
     roof = ops.GEMM_TIMER.report(PEAK_BF16_TFLOPS)
     # step level: algorithmic FLOPs of the steps actually run / their time / the bf16 MFMA peak
@@ -268,6 +292,25 @@ def main():
                                     + os.path.basename(cands[-1]))
     except Exception:
         pass
+    # "a measured large-GEMM peak on the box" beside the vendor peak - one 8192^3 bf16 NT GEMM of the
+    # product's own kernel (automatic choice = the 8-phase 256 x 256 kernel), outside the timed region
+    if rank == 0:
+        try:
+            gx = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+            gw = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+            for _ in range(2):
+                ops.linear_fwd(gx, gw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.linear_fwd(gx, gw)
+            e1.record()
+            torch.cuda.synchronize()
+            roof["measured_gemm_peak_tflops"] = round(5 * 2.0 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+            roof["measured_gemm_peak_note"] = "w2vs_gemm_nt, 8192^3 bf16, random operands, same process, after the timed region"
+            del gx, gw
+        except Exception as e:          # noqa: BLE001
+            roof["measured_gemm_peak_note"] = "not measured: %r" % (e,)
     variants = {}
     if world == 1 and not args.no_variants:
         # also the constant (16, 8) context with LayerDrop off - the step-level roofline number
@@ -275,7 +318,7 @@ def main():
         el2, fl2, _ = timed(3, args.steps, args.warmup + args.steps)
         a2 = fl2 / el2 / 1e12
         variants["constant_context_layerdrop_0"] = {
-            "ms_per_step": round(el2 / args.steps * 1e3, 3), "value": round(audio_s * args.steps / el2, 2), "unit": "audio-s/s",
+            "ms_per_step": round(el2 / args.steps * 1e3, 3), "value": round(audio_done[0] / el2, 2), "unit": "audio-s/s",
             "flops_per_step": round(fl2 / args.steps / 1e12, 4), "achieved_tflops": round(a2, 1),
             "frac_of_bf16_peak": round(a2 / PEAK_BF16_TFLOPS, 4)}
         roof["step_constant_context_layerdrop_0"] = {"flops_per_step": round(fl2 / args.steps / 1e12, 4),
@@ -284,7 +327,8 @@ def main():
     out = {
         "metric": "audio-seconds/s/GPU, wav2vec-S %s pretrain step, 1/2/4/8 MI355X" % ("large" if large else "base"),
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": None if ms_median is None else round(ms_median, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("wav2vec-S large (24L d1024 pre-LN, 315M params, BASELINE configs[3]) pretrain step: fwd + InfoNCE/"
                                 "diversity loss + bwd%s%s (clip_norm 25); %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, "
@@ -297,6 +341,8 @@ def main():
                                    ("" if args.no_optimizer else " + fused Adam") + (
                                        "" if args.update_freq == 1 else " (update_freq %d: exchange + Adam every %d-th step)" % (
                                            args.update_freq, args.update_freq)), B, L, audio_s),
+                   "length_mix": ("Libri-light shape: per step B lengths from U[160 000, 320 000] cropped to their minimum "
+                                  "(raw_audio_dataset.py:131-151); %.1f audio-s per step on average" % audio_s) if (large and args.length_mix) else None,
                    "global_batch_samples": world * B * L, "per_gpu_audio_s_per_s": round(value / world, 2),
                    "last_loss_per_sample": round(float(loss_t) / max(1, st.B * st.M), 4),
                    "tokens_last_step": {"T": st.T, "N": st.N, "M": st.M, "m": st.m, "r": st.r}},

@@ -259,19 +259,25 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
 #pragma unroll
     for (int i = 2; i < 16; i += 2) mloc = fmaxf(fmaxf(mloc, S[i]), S[i + 1]);
     mloc = max_halves(mloc) * c;
-    // lazy rescale (attention.hip): keep the reference maximum while no query's maximum grew by more than 2^6.  The
-    // multiply by alpha (1 in the common case) is unconditional on purpose: with it inside a branch the compiler carried
-    // the accumulators in two register sets and paid 40 v_mov_b64 per sub-tile to move between them.
     float muse;
     {
       const bool keep = __all(mloc <= mrun + 6.0f);
-      const float mnew = keep ? mrun : fmaxf(mrun, mloc);
-      muse = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = keep ? 1.f : fast_exp2(mrun - muse);
-      mrun = mnew;
-      lrun *= alpha;
+      // lazy rescale (attention.hip): keep the reference maximum while no query's maximum grew by more than 2^6.  Round 3:
+      // the rescale sits under a wave-uniform branch (taken on the first sub-tile and then rarely) and the accumulators are
+      // pinned to ONE register set behind it by an empty asm - without the pin the compiler carried them in two sets and paid
+      // 40 v_mov_b64 per sub-tile, which is why round 2 multiplied by alpha = 1 unconditionally: 59 of the common path's 247
+      // instructions (the 32 multiplies and their bookkeeping) are gone
+      if (!keep) {
+        const float mnew = fmaxf(mrun, mloc);
+        const float mu = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = fast_exp2(mrun - mu);
+        mrun = mnew;
+        lrun *= alpha;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { O0[i] *= alpha; O1[i] *= alpha; }
+      }
+      asm volatile("" : "+v"(O0), "+v"(O1));
+      muse = (mrun == -INFINITY) ? 0.f : mrun;
     }
     float ls = 0.f;
 #pragma unroll
