@@ -298,7 +298,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         d.p_drop, d.p_attn = p_enc, p_att
         d.seed_attn, d.seed_drop1, d.seed_drop2 = seed(100 + 4 * li), seed(101 + 4 * li), seed(102 + 4 * li)
         d.kpad = kpad_ptr
-        wqkv, bqkv = _qkv_pack(W, pre)
+        wqkv, bqkv = packed[pre + "qkv"] if (pre + "qkv") in packed else _qkv_pack(W, pre)
         rec = dict(li=li, wqkv=wqkv, bqkv=bqkv)
         d.wqkv, d.bqkv = wqkv.data_ptr(), bqkv.data_ptr()
         if post_ln:

@@ -204,16 +204,7 @@ class _HotPath(torch.autograd.Function):
     def forward(ctx, model, source, padding_mask, mask, features_only, draws, *params):
         cfg = model.cfg
         names = model._param_names
-        W = {}
-        packed = model._flat.packed if model._flat is not None else None
-        for n, p in zip(names, params):
-            t = p.detach()
-            if t.dtype != BF16:
-                t = t.to(BF16)
-            if packed is not None and n in packed:
-                W[n] = t                    # tap-major storage; the engine reads packed[n]
-            else:
-                W[n] = t.contiguous()
+        W, packed = model._weights_for_launch(names, params)
         src = source.detach()
         if src.dtype != BF16:
             src = src.to(BF16)
@@ -367,7 +358,59 @@ class Wav2Vec2Model(nn.Module):
 
     @property
     def _param_names(self):
-        return [n for n, _ in self.named_parameters()]
+        return self._named_params_cached()[0]
+
+    def _named_params_cached(self):
+        """(names, parameters) of the module tree, walked once: ``named_parameters()`` costs ~0.4 ms on this model, more than
+        the GPU work of a short streaming call.  Dropped when the tree changes (``remove_pretraining_modules``)."""
+        c = getattr(self, "_np_cache", None)
+        # re-walked whenever gradients are on (0.4 ms is nothing beside a training step, and a fine-tuning script may swap a
+        # Parameter object between steps); the no-grad inference calls - the streaming encoder - reuse the list
+        if c is None or torch.is_grad_enabled():
+            pairs = list(self.named_parameters())
+            c = self._np_cache = ([n for n, _ in pairs], [p for _, p in pairs])
+        return c
+
+    def _apply(self, fn, *a, **kw):          # .to() / .cuda() / .half(): parameters may be re-homed
+        self._np_cache = self._launch_cache = None
+        return super()._apply(fn, *a, **kw)
+
+    def _weights_for_launch(self, names, params):
+        """name -> bf16 contiguous device tensor for the kernels, plus the launch-side repacks (tap-major conv weights, the
+        fused [3E, E] q|k|v weight and bias of every layer).  Outside the flat-parameter trainer these were rebuilt on EVERY
+        forward (six transposes and twelve 3.5 MB concatenations: most of a streaming call's launches); they are kept while
+        no parameter changed - keyed by (data_ptr, _version, dtype) of every parameter, which any in-place update, load or
+        device / dtype move alters."""
+        if self._flat is not None:                       # flat storage: the packed forms ARE the storage (trainer.FlatParams)
+            packed = self._flat.packed
+            W = {}
+            for n, p in zip(names, params):
+                t = p.detach()
+                if t.dtype != BF16:
+                    t = t.to(BF16)
+                W[n] = t if n in packed else t.contiguous()
+            return W, packed
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+        c = getattr(self, "_launch_cache", None)
+        if c is not None and c[0] == key:
+            return c[1], c[2]
+        W = {}
+        for n, p in zip(names, params):
+            t = p.detach()
+            if t.dtype != BF16:
+                t = t.to(BF16)
+            W[n] = t.contiguous()
+        packed = {}
+        if W[names[0]].is_cuda:
+            for i in range(1, len(self.cfg.conv_layers)):
+                n = "feature_extractor.conv_layers.%d.0.weight" % i
+                packed[n] = ops.conv_pack_weight(W[n])
+            for li in range(self.cfg.encoder_layers):
+                pre = "encoder.layers.%d." % li
+                if pre + "self_attn.q_proj.weight" in W:
+                    packed[pre + "qkv"] = engine._qkv_pack(W, pre)
+        self._launch_cache = (key, W, packed)
+        return W, packed
 
     # ---- the reference's helper methods, same names ------------------------------------------------
     def sample_negatives(self, y, num):
@@ -409,7 +452,7 @@ class Wav2Vec2Model(nn.Module):
                             "(there is no CPU path; use oracle/ for CPU checks)")
         draws = self._draws if self._draws is not None else engine.Draws()
         self._draws = None
-        params = [p for _, p in self.named_parameters()]
+        params = self._named_params_cached()[1]
         out = _HotPath.apply(self, source, padding_mask, mask, features_only, draws, *params)
         st = self._last_state
         pm = padding_mask
@@ -450,6 +493,7 @@ class Wav2Vec2Model(nn.Module):
         return pen
 
     def remove_pretraining_modules(self):
+        self._np_cache = self._launch_cache = None
         self.quantizer = None
         self.project_q = None
         self.target_glu = None
