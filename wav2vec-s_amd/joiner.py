@@ -83,13 +83,33 @@ def _seed(base, k):
     return x ^ (x >> 29)
 
 
-def _lin_bwd(dy, x, w, need_dx=True):
-    """dy [R, N], x [R, K], w [N, K] -> dx [R, K] (or None), dw fp32 [N, K], db fp32 [N]."""
-    dw = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
-    db = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+def _lin_bwd(dy, x, w_t, dw, db, need_dx=True):
+    """dy [R, N], x [R, K], w_t = w.T contiguous [K, N] -> dx [R, K] (or None); dw [N, K] / db [N] (fp32 views of the layer
+    gradient slab, zero on entry) receive the weight and bias gradients."""
     ops.linear_wgrad(dy, x, dw, 1.0, db)
-    dx = ops.linear_dgrad(dy, ops.transpose2d(w)) if need_dx else None
-    return dx, dw, db
+    return ops.linear_dgrad(dy, w_t) if need_dx else None
+
+
+# order of a layer's gradients inside the flat fp32 slab (k and v weights adjacent: the fused [2D, D] k|v gradient is one view)
+_SLAB_ORDER = [0, 2, 4, 6, 8, 10, 1, 3, 5, 7, 9, 11, 12, 13, 14, 15]      # indices into _PER_LAYER
+
+
+def _launch_weights(net, params):
+    """bf16 parameters plus the launch-side repacks of every layer - fused k|v weight / bias and the transposed weights the
+    dgrad GEMMs read - rebuilt only when a parameter changed ((data_ptr, _version, dtype) key, as the encoder does)."""
+    key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+    c = getattr(net, "_launch_cache", None)
+    if c is not None and c[0] == key:
+        return c[1], c[2]
+    P16 = [p.detach().to(BF16).contiguous() for p in params]
+    packs = []
+    for li in range(len(net.layers)):
+        wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2 = P16[16 * li: 16 * li + 12]
+        wkv, bkv = torch.cat([wk, wv], 0), torch.cat([bk, bv], 0)
+        packs.append(dict(wkv=wkv, bkv=bkv, wq_t=ops.transpose2d(wq), wkv_t=ops.transpose2d(wkv), wo_t=ops.transpose2d(wo),
+                          w1_t=ops.transpose2d(w1), w2_t=ops.transpose2d(w2)))
+    net._launch_cache = (key, P16, packs)
+    return P16, packs
 
 
 class _JointFn(torch.autograd.Function):
@@ -104,7 +124,7 @@ class _JointFn(torch.autograd.Function):
         H = net.layers[0].enc_attn.num_heads
         if D // H != 64:
             raise W2vsError("MHAJointNet: head_dim must be 64 (jointer_embed_dim 256 / 4 heads in rain)")
-        P16 = [p.detach().to(BF16).contiguous() for p in params]
+        P16, packs = _launch_weights(net, params)
         nL = len(net.layers)
         x = dec_state.detach().to(BF16).contiguous()                       # [B, 1, U, D]
         # encoder frames arrive T x B x C (fairseq encoder-out); the kernels want [B, S, C]
@@ -133,7 +153,7 @@ class _JointFn(torch.autograd.Function):
                 n1 = xin2
             rec["n1"] = n1
             q = ops.linear_fwd(n1, wq, bq)                                                    # [R_in, D]
-            wkv, bkv = torch.cat([wk, wv], 0), torch.cat([bk, bv], 0)
+            wkv, bkv = packs[li]["wkv"], packs[li]["bkv"]
             kv = ops.linear_fwd(enc, wkv, bkv)                                                # [B*S, 2D]
             q_exp = ops.gather_rows(q, exp_idx, R) if Gin == 1 and G > 1 else q
             res_exp = ops.gather_rows(xin2, exp_idx, R) if Gin == 1 and G > 1 else xin2
@@ -160,31 +180,35 @@ class _JointFn(torch.autograd.Function):
             x = y.view(B, G, U, D)
             Gin = G
         ctx.saved = saved
-        ctx.misc = (net, P16, enc, kpad, idx_tb, exp_idx, (B, U, D, S, G, H, m_eff), [p.dtype for p in params],
+        ctx.misc = (net, P16, packs, enc, kpad, idx_tb, exp_idx, (B, U, D, S, G, H, m_eff), [p.dtype for p in params],
                     dec_state.dtype, enc_state.dtype)
         return x.clone() if ops.ARENA.active else x
 
     @staticmethod
     def backward(ctx, dy):
-        net, P16, enc, kpad, idx_tb, exp_idx, (B, U, D, S, G, H, m_eff), pdt, ddt, edt = ctx.misc
+        net, P16, packs, enc, kpad, idx_tb, exp_idx, (B, U, D, S, G, H, m_eff), pdt, ddt, edt = ctx.misc
         dev = dy.device
         d = dy.to(BF16).contiguous().view(B * G * U, D)
-        grads = [None] * len(P16)
+        nL = len(net.layers)
+        # ONE zeroed fp32 slab holds every parameter gradient of every layer (+ 2 D floats for the discarded dgamma / dbeta
+        # of the plain residual adds): views of it are what the weight-gradient GEMMs and LayerNorm backwards accumulate into
+        sizes = [P16[j].numel() for j in _SLAB_ORDER]
+        per_layer = sum(sizes)
+        gflat = torch.zeros(nL * per_layer + 2 * D, dtype=torch.float32, device=dev)
+        scr = gflat[nL * per_layer:]
+
+        def gview(li, j):                       # gradient view of parameter _PER_LAYER[j] of layer li
+            o = li * per_layer + sum(sizes[:_SLAB_ORDER.index(j)])
+            return gflat[o:o + P16[16 * li + j].numel()].view(P16[16 * li + j].shape)
+
         d_enc = None
-        scr = torch.zeros(2 * D, dtype=torch.float32, device=dev)          # discarded dgamma / dbeta of the plain residual adds
-
-        def put(i, g32):
-            grads[i] = g32 if grads[i] is None else grads[i] + g32
-
-        for li in range(len(net.layers) - 1, -1, -1):
-            rec = ctx.saved[li]
+        for li in range(nL - 1, -1, -1):
+            rec, pk = ctx.saved[li], packs[li]
             wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = P16[16 * li: 16 * li + 16]
             p_drop, p_att, p_act = rec["p"]
             sd, pre, Gin = rec["sd"], rec["pre"], rec["Gin"]
             R = B * G * U
-            k0 = 16 * li
-            dg1 = torch.zeros(D, dtype=torch.float32, device=dev); db1 = torch.zeros_like(dg1)
-            dg2 = torch.zeros(D, dtype=torch.float32, device=dev); db2 = torch.zeros_like(dg2)
+            dg1, db1, dg2, db2 = gview(li, 12), gview(li, 13), gview(li, 14), gview(li, 15)
             if pre:
                 # y = dropout(f) + s1
                 d_f, d_s1 = ops.ln_bwd(rec["s1"], g2, be2, rec["mean2"], rec["rstd2"], scr[:D], scr[D:], dy=None, dsum=d,
@@ -192,12 +216,10 @@ class _JointFn(torch.autograd.Function):
             else:
                 d_f, d_x1 = ops.ln_bwd(rec["s2"], g2, be2, rec["mean3"], rec["rstd3"], dg2, db2, dy=d, want_dres=True,
                                        p_drop=p_drop, seed=sd[3])
-            d_hd, dw2, dbb2 = _lin_bwd(d_f, rec["hd"], w2)
-            put(k0 + 10, dw2); put(k0 + 11, dbb2)
+            d_hd = _lin_bwd(d_f, rec["hd"], pk["w2_t"], gview(li, 10), gview(li, 11))
             d_h = ops.dropout(d_hd, p_act, sd[2]) if p_act > 0 else d_hd
             d_hpre = ops.relu_gate(d_h, rec["h"])
-            d_x1b, dw1, dbb1 = _lin_bwd(d_hpre, rec["x1"], w1)
-            put(k0 + 8, dw1); put(k0 + 9, dbb1)
+            d_x1b = _lin_bwd(d_hpre, rec["x1"], pk["w1_t"], gview(li, 8), gview(li, 9))
             if pre:
                 # n2 = LN_final(s1), s1 = dropout(a) + res
                 d_a, d_res = ops.ln_bwd(rec["s1"], g2, be2, rec["mean2"], rec["rstd2"], dg2, db2, dy=d_x1b, dsum=d_s1,
@@ -206,31 +228,44 @@ class _JointFn(torch.autograd.Function):
                 d_x1 = _add(d_x1, d_x1b)
                 d_a, d_res = ops.ln_bwd(rec["s1"], g1, be1, rec["mean2"], rec["rstd2"], dg1, db1, dy=d_x1, want_dres=True,
                                         p_drop=p_drop, seed=sd[1])
-            d_ctx, dwo, dbo = _lin_bwd(d_a, rec["ctx"].view(R, D), wo)
-            put(k0 + 6, dwo); put(k0 + 7, dbo)
+            d_ctx = _lin_bwd(d_a, rec["ctx"].view(R, D), pk["wo_t"], gview(li, 6), gview(li, 7))
             dq_exp, dkv = ops.group_attn_bwd(d_ctx.view(B, G * U, D), rec["q_exp"].view(B, G * U, D), rec["kv"].view(B, S, 2 * D),
                                              rec["ctx"], rec["lse"], H, m_eff, U, kpad=kpad, p_drop=p_att, seed=sd[0])
             expanded = Gin == 1 and G > 1
             dq = _sum_groups(dq_exp.view(B, G, U * D)) .view(B * U, D) if expanded else dq_exp.view(R, D)
             d_resin = _sum_groups(d_res.view(B, G, U * D)).view(B * U, D) if expanded else d_res
-            d_n1, dwq, dbq = _lin_bwd(dq, rec["n1"], wq)
-            put(k0 + 0, dwq); put(k0 + 1, dbq)
-            d_encl, dwkv, dbkv = _lin_bwd(dkv.view(B * S, 2 * D), enc, rec["wkv"])
-            put(k0 + 2, dwkv[:D]); put(k0 + 3, dbkv[:D]); put(k0 + 4, dwkv[D:]); put(k0 + 5, dbkv[D:])
+            d_n1 = _lin_bwd(dq, rec["n1"], pk["wq_t"], gview(li, 0), gview(li, 1))
+            # the fused k|v gradient lands in the ADJACENT k and v weight / bias views of the slab
+            o_w = li * per_layer + sum(sizes[:_SLAB_ORDER.index(2)])
+            o_b = li * per_layer + sum(sizes[:_SLAB_ORDER.index(3)])
+            d_encl = _lin_bwd(dkv.view(B * S, 2 * D), enc, pk["wkv_t"], gflat[o_w:o_w + 2 * D * D].view(2 * D, D),
+                              gflat[o_b:o_b + 2 * D])
             d_enc = d_encl if d_enc is None else _add(d_enc, d_encl)
             if pre:
                 xin2 = rec["x_in"].view(-1, D)
                 d_x, _ = ops.ln_bwd(xin2, g1, be1, rec["mean1"], rec["rstd1"], dg1, db1, dy=d_n1, dsum=d_resin)
             else:
                 d_x = _add(d_n1, d_resin)
-            put(k0 + 12, dg1); put(k0 + 13, db1); put(k0 + 14, dg2); put(k0 + 15, db2)
             d = d_x
         d_dec = d.view(B, U, D).to(ddt)
         # back to T x B x C
         d_enc16 = d_enc
         d_enc_tb = torch.empty(S * B, D, dtype=BF16, device=dev)
         ops.gather_rows(d_enc16, idx_tb, B * S, scatter=True, out=d_enc_tb)
-        out = [g.to(dt) if g is not None else None for g, dt in zip(grads, pdt)]
+        # hand the gradients over: one conversion of the whole slab when every parameter is bf16
+        if all(dt == BF16 for dt in pdt):
+            g16 = ops.f32_to_bf16(gflat[:nL * per_layer])
+            if ops.ARENA.active:
+                g16 = g16.clone()
+            src_flat = g16
+        else:
+            src_flat = gflat
+        out = []
+        for i, dt in enumerate(pdt):
+            li, j = divmod(i, 16)
+            o = li * per_layer + sum(sizes[:_SLAB_ORDER.index(j)])
+            g = src_flat[o:o + P16[i].numel()].view(P16[i].shape)
+            out.append(g if g.dtype == dt else g.to(dt))
         if ops.ARENA.active:
             d_dec, d_enc_tb = d_dec.clone(), d_enc_tb.clone()
         ctx.saved = None
