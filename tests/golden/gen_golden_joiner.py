@@ -43,5 +43,39 @@ for tag, pre_ln, layers, ds in (("pre", True, 2, 8), ("post", False, 2, 5), ("of
     for n, p in net.named_parameters():
         out[f"{tag}.P.{n}"] = p.detach().numpy()
         out[f"{tag}.G.{n}"] = p.grad.numpy()
+# ---- the decoding path: incremental_state (attention_transducer.py:607-674) with downsample = -1, as TransducerMHADecoder.forward
+# sets it (:901-902).  Four calls on one state dictionary: fresh; SAME prefix length with DIFFERENT frames (the cached
+# projections of the first call are reused - the reference only compares lengths); a longer prefix (recomputed); after a
+# beam reorder that duplicates hypothesis 1.
+torch.manual_seed(9)
+D, H, layers = 128, 2, 2
+args = argparse.Namespace(jointer_embed_dim=D, jointer_attention_heads=H, transducer_downsample=-1, jointer_layers=layers,
+                          attention_dropout=0.1, dropout=0.1, activation_dropout=0.1, activation_fn="relu",
+                          encoder_normalize_before=True, jointer_ffn_embed_dim=2 * D, step_mode="constant")
+net = J.MHAJointNet(args).eval()
+with torch.no_grad():
+    for n, p in net.named_parameters():
+        if "layer_norm" in n or n.endswith("bias"):
+            p.add_(torch.randn_like(p) * 0.1)
+        p.copy_(p.to(torch.bfloat16).float())
+    rb = lambda *shape: torch.randn(*shape).to(torch.bfloat16).float()       # noqa: E731
+    B = 2
+    encA, encB, encC = rb(20, B, D), rb(20, B, D), rb(28, B, D)
+    dec1, dec2, dec3 = rb(B, 3, D), rb(B, 4, D), rb(B, 5, D)
+    padA, padC = torch.zeros(B, 20, dtype=torch.bool), torch.zeros(B, 28, dtype=torch.bool)
+    state = {}
+    o1, _ = net({"encoder_out": [encA], "encoder_padding_mask": [padA]}, dec1, incremental_state=state)
+    o2, _ = net({"encoder_out": [encB], "encoder_padding_mask": [padA]}, dec2, incremental_state=state)
+    o3, _ = net({"encoder_out": [encC], "encoder_padding_mask": [padC]}, dec3, incremental_state=state)
+    order = torch.tensor([1, 1, 0])          # a different size than the cached batch: the reference reorders only then (:617-619)
+    for layer in net.layers:
+        layer.enc_attn.reorder_incremental_state(state, order)
+    o4, _ = net({"encoder_out": [encC.index_select(1, order)], "encoder_padding_mask": [padC.index_select(0, order)]}, dec3.index_select(0, order),
+                incremental_state=state)
+out.update({"inc.cfg": np.array([D, H, layers, B]), "inc.encA": encA.numpy(), "inc.encB": encB.numpy(), "inc.encC": encC.numpy(),
+            "inc.dec1": dec1.numpy(), "inc.dec2": dec2.numpy(), "inc.dec3": dec3.numpy(), "inc.o1": o1.numpy(), "inc.o2": o2.numpy(),
+            "inc.o3": o3.numpy(), "inc.o4": o4.numpy()})
+for n, p in net.named_parameters():
+    out[f"inc.P.{n}"] = p.detach().numpy()
 np.savez_compressed(os.path.join(HERE, "joiner.npz"), **out)
 print("wrote joiner.npz:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "joiner.npz")) // 1024, "KiB")

@@ -117,3 +117,38 @@ def test_joiner_caat_width_matches_oracle_and_feeds_the_head():
     for n, p in net_t.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad.float()).all(), n
     assert head.output_proj.weight.grad is not None
+
+
+def test_joiner_incremental_state_matches_reference_fixture():
+    """The decoding path (rain/layers/attention_transducer.py:607-674, 826-852 with downsample = -1 as TransducerMHADecoder sets
+    it, :901-902) against outputs recorded from the reference's own classes: a fresh call, a call with the SAME prefix length
+    but different frames (the cached projections are reused - only lengths are compared), a longer prefix (recomputed), and a
+    call after a beam reorder to three hypotheses."""
+    from wav2vec_s_amd import joiner
+    from wav2vec_s_amd._lib import W2vsError
+    z = np.load(os.path.join(GOLDEN, "joiner.npz"))
+    D, H, layers, B = [int(v) for v in z["inc.cfg"]]
+    net = joiner.MHAJointNet(_args(D, H, -1, layers, True, 2 * D))
+    net.load_state_dict({k[len("inc.P."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("inc.P.")})
+    net = net.to(BF).cuda().eval()
+    t = lambda n: torch.from_numpy(z["inc." + n]).to(BF).cuda()      # noqa: E731
+    pad = lambda S, b=B: torch.zeros(b, S, dtype=torch.bool).cuda()  # noqa: E731
+    state = {}
+    with torch.no_grad():
+        o1, g1 = net({"encoder_out": [t("encA")], "encoder_padding_mask": [pad(20)]}, t("dec1"), incremental_state=state)
+        assert len(state) == layers and all("prev_key" in v and tuple(v["prev_key"].shape) == (B, H, 20, D // H) for v in state.values())
+        o2, _ = net({"encoder_out": [t("encB")], "encoder_padding_mask": [pad(20)]}, t("dec2"), incremental_state=state)
+        o3, _ = net({"encoder_out": [t("encC")], "encoder_padding_mask": [pad(28)]}, t("dec3"), incremental_state=state)
+        assert all(v["prev_key"].shape[2] == 28 for v in state.values())
+        order = torch.tensor([1, 1, 0]).cuda()
+        net.reorder_incremental_state(state, order)
+        assert all(v["prev_key"].shape[0] == 3 for v in state.values())
+        o4, _ = net({"encoder_out": [t("encC").index_select(1, order)], "encoder_padding_mask": [pad(28, 3)]},
+                    t("dec3").index_select(0, order), incremental_state=state)
+    assert torch.equal(g1.cpu(), torch.ones(B, dtype=torch.long))
+    for got, want in ((o1, "o1"), (o2, "o2"), (o3, "o3"), (o4, "o4")):
+        assert tuple(got.shape) == z["inc." + want].shape
+        assert rel(got, torch.from_numpy(z["inc." + want])) < 1.5e-2, want
+    dec = t("dec1").requires_grad_(True)
+    with pytest.raises(W2vsError):                      # the cache is a decoding-time structure
+        net({"encoder_out": [t("encA")], "encoder_padding_mask": [pad(20)]}, dec, incremental_state={})

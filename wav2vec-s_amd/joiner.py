@@ -13,12 +13,13 @@ by design: the reference materialises group masks ``[B, G, S]`` of 0 / -inf and 
 prefix structure goes to the attention kernel as two integers (``w2vs_attn_desc`` cross mode: query row (g, u) sees the
 keys < (g + 1) * downsample), scores never exist, and activations are laid out ``[B, G, U, D]`` from the start (the
 reference permutes ``[G, U, B, D]`` at the end).  Forward and backward are explicit launch sequences behind ONE autograd
-node; there is no CPU path.  ``incremental_state`` (beam-search caching of k / v) is not built: this is the training /
-scoring path.
+node; there is no CPU path.  ``incremental_state`` (round 3): the decoding path's per-layer cache of the projected encoder
+frames, reused while the encoder prefix keeps its length, reorderable for beam search - same keys as the reference.
 """
 import ctypes as C  # noqa: F401
 import math
 import random
+import uuid
 from typing import Dict, List
 
 import torch
@@ -44,6 +45,44 @@ class ExpandMultiheadAttention(nn.Module):
         self.k_proj = nn.Linear(embed_dim, embed_dim)
         self.v_proj = nn.Linear(embed_dim, embed_dim)
         self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self._incremental_state_id = str(uuid.uuid4())      # fs/incremental_decoding_utils.py:17-21 (with_incremental_state)
+
+    # ---- incremental state (:607-640): the projected encoder frames are cached per module, keyed like fairseq's mixin does;
+    # "prev_key" / "prev_value" are [B, H, S, head_dim] as in the reference, "w2vs_kv" is the packed [B*S, 2D] the kernels read
+    def _full_key(self, key):
+        return "{}.{}".format(self._incremental_state_id, key)
+
+    def get_incremental_state(self, incremental_state, key):
+        fk = self._full_key(key)
+        if incremental_state is None or fk not in incremental_state:
+            return None
+        return incremental_state[fk]
+
+    def set_incremental_state(self, incremental_state, key, value):
+        if incremental_state is not None:
+            incremental_state[self._full_key(key)] = value
+        return incremental_state
+
+    def _get_input_buffer(self, incremental_state):
+        result = self.get_incremental_state(incremental_state, "attn_state")
+        return result if result is not None else {}
+
+    def _set_input_buffer(self, incremental_state, buffer):
+        return self.set_incremental_state(incremental_state, "attn_state", buffer)
+
+    def reorder_incremental_state(self, incremental_state, new_order):
+        """:608-624: beam reordering - every cached tensor is index_select-ed along the batch, unless the first one already
+        has ``new_order``'s size (the reference's early exit)."""
+        buf = self._get_input_buffer(incremental_state)
+        if buf:
+            for k in buf.keys():                 # prev_key, prev_value, w2vs_kv: batch first, all three
+                t = buf[k]
+                if t is not None:
+                    if t.size(0) == new_order.size(0):
+                        break
+                    buf[k] = t.index_select(0, new_order)
+            incremental_state = self._set_input_buffer(incremental_state, buf)
+        return incremental_state
 
 
 class TransformerJointerLayer(nn.Module):
@@ -117,7 +156,7 @@ class _JointFn(torch.autograd.Function):
     Layout: activations [B, G, U, D] rows (b, g, u); encoder frames [B, S, D]."""
 
     @staticmethod
-    def forward(ctx, net, dec_state, enc_state, kpad, ds, G, training, base_seed, *params):
+    def forward(ctx, net, dec_state, enc_state, kpad, ds, G, training, base_seed, inc, *params):
         B, U, D = dec_state.shape
         S = enc_state.shape[0]
         dev = dec_state.device
@@ -154,7 +193,21 @@ class _JointFn(torch.autograd.Function):
             rec["n1"] = n1
             q = ops.linear_fwd(n1, wq, bq)                                                    # [R_in, D]
             wkv, bkv = packs[li]["wkv"], packs[li]["bkv"]
-            kv = ops.linear_fwd(enc, wkv, bkv)                                                # [B*S, 2D]
+            kv = None
+            if inc is not None:          # :658-666: reuse the cached projections when the encoder prefix has not grown
+                buf = layer.enc_attn._get_input_buffer(inc)
+                if buf.get("prev_key") is not None and buf["prev_key"].shape[2] == S and buf.get("w2vs_kv") is not None \
+                        and buf["w2vs_kv"].shape[0] == B:
+                    kv = buf["w2vs_kv"].view(B * S, 2 * D)
+            if kv is None:
+                kv = ops.linear_fwd(enc, wkv, bkv)                                            # [B*S, 2D]
+                if inc is not None:      # :670-674
+                    kv3 = kv.view(B, S, 2 * D)
+                    if ops.ARENA.active:
+                        kv3 = kv3.clone()
+                    layer.enc_attn._set_input_buffer(inc, {
+                        "prev_key": kv3[:, :, :D].reshape(B, S, H, D // H).transpose(1, 2),
+                        "prev_value": kv3[:, :, D:].reshape(B, S, H, D // H).transpose(1, 2), "w2vs_kv": kv3})
             q_exp = ops.gather_rows(q, exp_idx, R) if Gin == 1 and G > 1 else q
             res_exp = ops.gather_rows(xin2, exp_idx, R) if Gin == 1 and G > 1 else xin2
             ctxv, lse = ops.group_attn_fwd(q_exp.view(B, G * U, D), kv.view(B, S, 2 * D), H, m_eff, U, kpad=kpad,
@@ -269,7 +322,7 @@ class _JointFn(torch.autograd.Function):
         if ops.ARENA.active:
             d_dec, d_enc_tb = d_dec.clone(), d_enc_tb.clone()
         ctx.saved = None
-        return (None, d_dec, d_enc_tb.view(S, B, D).to(edt), None, None, None, None, None, *out)
+        return (None, d_dec, d_enc_tb.view(S, B, D).to(edt), None, None, None, None, None, None, *out)
 
 
 def _add(a, b):
@@ -317,8 +370,12 @@ class MHAJointNet(nn.Module):
         return G, (enc_len / self.downsample).ceil().long()
 
     def forward(self, encoder_out: Dict[str, List[Tensor]], decoder_state: Tensor, incremental_state=None):
-        if incremental_state is not None:
-            raise W2vsError("MHAJointNet: incremental_state (beam-search k/v caching) is not built")
+        """:826-852.  ``incremental_state`` (a dict, fairseq style): every layer's attention caches its projected encoder
+        frames there and reuses them while the encoder prefix keeps its length (:658-674) - the decoding path of
+        ``TransducerMHADecoder.forward`` / ``recalc_logits`` (:886-922), which also sets ``downsample = -1``.  Inference only."""
+        if incremental_state is not None and torch.is_grad_enabled() and (decoder_state.requires_grad or any(
+                p.requires_grad for p in self.parameters())):
+            raise W2vsError("MHAJointNet: incremental_state is the decoding path - call it under torch.no_grad()")
         enc = encoder_out["encoder_out"][0]                        # S x B x D
         pad = encoder_out["encoder_padding_mask"][0]               # B x S bool
         if not decoder_state.is_cuda:
@@ -336,5 +393,10 @@ class MHAJointNet(nn.Module):
         for layer in self.layers:
             sd = dict(layer.named_parameters())
             params += [sd[n] for n in _PER_LAYER]
-        x = _JointFn.apply(self, decoder_state, enc, kpad, ds, G, self.training, base, *params)
+        x = _JointFn.apply(self, decoder_state, enc, kpad, ds, G, self.training, base, incremental_state, *params)
         return x, group_lengths
+
+    def reorder_incremental_state(self, incremental_state, new_order):
+        for layer in self.layers:
+            layer.enc_attn.reorder_incremental_state(incremental_state, new_order)
+        return incremental_state
