@@ -223,3 +223,43 @@ def test_twin_frozen_extractor_and_no_padding_mask():
             assert g is None or float(g.abs().max()) == 0.0, n
         elif n.startswith("encoder.") or n.startswith("post_extract_proj.") or n == "layer_norm.weight":
             assert g is not None and rel(g, grads[1.0][n]) < 1e-5, n       # same numbers: only the extractor is cut off
+
+
+def test_inference_weight_cache_follows_every_kind_of_weight_change():
+    """The no-grad eval path reuses the launch-side weight repacks (tap-major conv weights, fused q|k|v) between calls.  A
+    load_state_dict, an in-place update of a Parameter, a train() / eval() round trip and ``invalidate_launch_cache()`` after a
+    write through ``.data`` must all be seen by the next call; and the cached call equals the uncached one bit for bit."""
+    from wav2vec_s_amd import streaming
+    kw = dict(extractor_mode="layer_norm", encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+              encoder_attention_heads=2, final_dim=128, quantize_targets=True, feature_grad_mult=0.1, dropout=0.0,
+              attention_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0, latent_vars=40,
+              conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2", main_context=8, right_context=4,
+              pos_type="sin", load_pretrained_model_from=None)
+    torch.manual_seed(3)
+    model = streaming.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(**kw)).to(BF).cuda().eval()
+    src = torch.randn(1, 16000).to(BF).cuda()
+
+    def run():
+        with torch.no_grad():
+            return model(src, None, None, True, True)["encoder_out"][0].float().clone()
+    a = run()
+    assert model._launch_cache is not None
+    assert torch.equal(run(), a)                                   # cached == uncached
+    conv_w = model.feature_extractor.conv_layers[2][0].weight      # a weight that only reaches the kernels through a repack
+    q_w = model.encoder.layers[0].self_attn.q_proj.weight
+    with torch.no_grad():
+        conv_w.mul_(1.5)                                           # in-place on the Parameter: _version moves
+    b = run()
+    assert not torch.equal(b, a)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["encoder.layers.0.self_attn.q_proj.weight"] = sd["encoder.layers.0.self_attn.q_proj.weight"] * 0.5
+    model.load_state_dict(sd)
+    c = run()
+    assert not torch.equal(c, b)
+    q_w.data.mul_(2.0)                                             # through .data: invisible to the version counter ...
+    model.invalidate_launch_cache()                                # ... the documented duty of whoever does that
+    d = run()
+    assert not torch.equal(d, c)
+    q_w.data.mul_(0.5)
+    model.train(); model.eval()                                    # a mode round trip drops the cache as well
+    assert torch.equal(run(), c)

@@ -135,10 +135,13 @@ _SLAB_ORDER = [0, 2, 4, 6, 8, 10, 1, 3, 5, 7, 9, 11, 12, 13, 14, 15]      # indi
 
 def _launch_weights(net, params):
     """bf16 parameters plus the launch-side repacks of every layer - fused k|v weight / bias and the transposed weights the
-    dgrad GEMMs read - rebuilt only when a parameter changed ((data_ptr, _version, dtype) key, as the encoder does)."""
-    key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+    dgrad GEMMs read; kept between no-grad eval calls while no parameter changed ((data_ptr, _version, dtype) key, as the encoder does)."""
+    # reused only on the no-grad eval path (decoding): an optimizer that writes through ``p.data`` (fairseq's Adam, fs/optim/adam.py:232)
+    # leaves ``p._version`` alone, so a training forward rebuilds the repacks every time
+    reuse = not torch.is_grad_enabled() and not net.training
+    key = tuple((p.data_ptr(), p._version, p.dtype) for p in params) if reuse else None
     c = getattr(net, "_launch_cache", None)
-    if c is not None and c[0] == key:
+    if reuse and c is not None and c[0] == key:
         return c[1], c[2]
     P16 = [p.detach().to(BF16).contiguous() for p in params]
     packs = []
@@ -147,7 +150,7 @@ def _launch_weights(net, params):
         wkv, bkv = torch.cat([wk, wv], 0), torch.cat([bk, bv], 0)
         packs.append(dict(wkv=wkv, bkv=bkv, wq_t=ops.transpose2d(wq), wkv_t=ops.transpose2d(wkv), wo_t=ops.transpose2d(wo),
                           w1_t=ops.transpose2d(w1), w2_t=ops.transpose2d(w2)))
-    net._launch_cache = (key, P16, packs)
+    net._launch_cache = (key, P16, packs) if reuse else None
     return P16, packs
 
 

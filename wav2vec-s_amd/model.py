@@ -324,6 +324,8 @@ class Wav2Vec2Model(nn.Module):
         self._after_forward = None           # trainer.TrainStep hook: called with sample_size once the forward is enqueued
         self._last_state = None
         self._draws = None
+        self._np_cache = self._launch_cache = None      # see _named_params_cached / _weights_for_launch
+        self.register_load_state_dict_post_hook(lambda m, _inc: m.invalidate_launch_cache())
         self.load_pretrained_model(cfg)
 
     def build_encoder(self, cfg):
@@ -390,9 +392,14 @@ class Wav2Vec2Model(nn.Module):
                     t = t.to(BF16)
                 W[n] = t if n in packed else t.contiguous()
             return W, packed
-        key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+        # Only the no-grad eval path (the streaming encoder) reuses the repacks: an optimizer that writes through ``p.data``
+        # (fairseq's Adam does, fs/optim/adam.py:232) changes the values without touching ``p._version``, so during training
+        # everything is rebuilt every forward, as before.  ``train()`` / ``eval()``, ``load_state_dict`` and ``.to()`` drop the
+        # cache; code that writes ``p.data`` between two inference calls must call ``invalidate_launch_cache()`` itself.
+        reuse = not torch.is_grad_enabled() and not self.training
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in params) if reuse else None
         c = getattr(self, "_launch_cache", None)
-        if c is not None and c[0] == key:
+        if reuse and c is not None and c[0] == key:
             return c[1], c[2]
         W = {}
         for n, p in zip(names, params):
@@ -409,8 +416,15 @@ class Wav2Vec2Model(nn.Module):
                 pre = "encoder.layers.%d." % li
                 if pre + "self_attn.q_proj.weight" in W:
                     packed[pre + "qkv"] = engine._qkv_pack(W, pre)
-        self._launch_cache = (key, W, packed)
+        self._launch_cache = (key, W, packed) if reuse else None
         return W, packed
+
+    def invalidate_launch_cache(self):
+        self._np_cache = self._launch_cache = None
+
+    def train(self, mode: bool = True):
+        self._launch_cache = None
+        return super().train(mode)
 
     # ---- the reference's helper methods, same names ------------------------------------------------
     def sample_negatives(self, y, num):
