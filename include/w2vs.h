@@ -273,6 +273,24 @@ int w2vs_nce_bwd(const w2vs_nce_desc* d, void* stream);
  * argmin==0)}; dlogits (optional) = softmax - onehot(0).                                          */
 int w2vs_ce_rows(const float* logits, int64_t R, int32_t W, float* out3, float* dlogits, void* stream);
 
+/* ---- the whole InfoNCE criterion in one launch -------------------------------------------------------
+ * fs/criterions/wav2vec_criterion.py:64-100: cross entropy as above, then (by the block that finishes last)
+ *   loss = ce + w_ppl * ((num_vars - prob_ppl) / num_vars) * sample_size + w_pen * features_pen * sample_size
+ * with features_pen = pen_acc[0] * pen_norm (wav2vec2.py:571) and the extra losses in the order of
+ * wav2vec2.py:669-679 (get_extra_losses).  loss[1] and vec[8] = {loss, ce, ppl term, pen term, correct
+ * (:141-151: #max0 - #both0), prob_perplexity, code_perplexity, features_pen}.  scratch: 4 words, zero on entry,
+ * zero again on exit (one buffer serves every launch of a stream).  dlogits optional, as for ce_rows.      */
+typedef struct w2vs_infonce_loss_desc {
+  const float* logits; int64_t R; int32_t W;
+  const float* pen_acc; const float* ppl;
+  float w_ppl, w_pen, num_vars, pen_norm, sample_size;
+  float* loss; float* vec; float* dlogits; float* scratch;
+} w2vs_infonce_loss_desc;
+int w2vs_infonce_loss(const w2vs_infonce_loss_desc* d, void* stream);
+/* its backward: dlogits[n] *= g[0] in place, dsc = {g * c_pen, g * c_ppl} - the gradients of features_pen and
+ * prob_perplexity for c_pen = w_pen * sample_size, c_ppl = -w_ppl * sample_size / num_vars               */
+int w2vs_infonce_loss_bwd(const float* g, float* dlogits, int64_t n, float c_pen, float c_ppl, float* dsc, void* stream);
+
 /* ---- small movers ------------------------------------------------------------------------------- */
 /* dst[i] = src[idx[i]] (scatter=0) or dst[idx[i]] = src[i] (scatter=1); rows of C bf16.
  * x[mask_indices] / unmasked_features[mask_indices] (wav2vec2.py:590-592, 641) and their grads.  */

@@ -50,7 +50,8 @@ for name, N, K, *rest in SHAPES:
         t1 = t_us(lambda: ops.linear_fwd(x, w, b))
         t2 = t_us(lambda: ops.linear_fwd(x, w, b, gelu=True, save_pre=True, save_grad=True))
         t3 = t_us(lambda: ops.linear_dgrad(x, w, mul_aux=aux))          # same shape class: [R,K] x [N,K]^T with EPI_MUL
+        t4 = t_us(lambda: ops.linear_dgrad(x, w, add_aux=aux))          # ... with EPI_ADD (the residual-add dgrads)
         fl = 2.0 * R * N * K
-        print("%-8s %-11s rel err %.1e   bias %6.1f us (%5.0f TF/s)   gelu+saveg %6.1f us   mul-aux %6.1f us" % (
-            name, cfg_name, err, t1, fl / t1 / 1e6, t2, t3), flush=True)
+        print("%-8s %-11s rel err %.1e   bias %6.1f us (%5.0f TF/s)   gelu+saveg %6.1f us   mul-aux %6.1f us   add-aux %6.1f us" % (
+            name, cfg_name, err, t1, fl / t1 / 1e6, t2, t3, t4), flush=True)
     ops.gemm_tune(-1, 0)

@@ -86,7 +86,13 @@ class CollateDesc(C.Structure):
                 ("partial", vp), ("B", i32), ("target", i32), ("width", i32), ("max_size", i32), ("normalize", i32), ("out_f32", i32)]
 
 
-_DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc, CollateDesc]
+class InfonceLossDesc(C.Structure):
+    _fields_ = [("logits", vp), ("R", i64), ("W", i32), ("pen_acc", vp), ("ppl", vp),
+                ("w_ppl", f32), ("w_pen", f32), ("num_vars", f32), ("pen_norm", f32), ("sample_size", f32),
+                ("loss", vp), ("vec", vp), ("dlogits", vp), ("scratch", vp)]
+
+
+_DESCS = [GemmDesc, LnFwdDesc, LnBwdDesc, EncPrologueDesc, AttnDesc, QuantDesc, NceDesc, LayerDesc, CollateDesc, InfonceLossDesc]
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_DGELU, EPI_F32, EPI_ADD, EPI_BIAS_GELU_SAVEG, EPI_MUL = range(9)
 
@@ -115,6 +121,8 @@ _SIGS = {
     "w2vs_nce_fwd": [C.POINTER(NceDesc), vp],
     "w2vs_nce_bwd": [C.POINTER(NceDesc), vp],
     "w2vs_ce_rows": [vp, i64, i32, vp, vp, vp],
+    "w2vs_infonce_loss": [C.POINTER(InfonceLossDesc), vp],
+    "w2vs_infonce_loss_bwd": [vp, vp, i64, f32, f32, vp, vp],
     "w2vs_gather_rows": [vp, vp, vp, i64, i32, i32, vp],
     "w2vs_gemm_tune": [i32, i32, i32],
     "w2vs_attn_tune": [i32],

@@ -62,6 +62,7 @@ class Wav2vecCriterion:
         self.loss_weights = loss_weights
         self.log_keys = [] if log_keys is None else log_keys
         self.training = True
+        self.fuse = True          # False: always compose the loss from framework ops (the reference's own sequence)
 
     def __call__(self, model, sample, reduce=True, sync_logging=True):
         return self.forward(model, sample, reduce, sync_logging)
@@ -69,7 +70,19 @@ class Wav2vecCriterion:
     def forward(self, model, sample, reduce=True, sync_logging=True):
         """sync_logging=False keeps the logged scalars as device tensors (no .item() host syncs);
         the reference always syncs (wav2vec_criterion.py:110, 128, 133, 151)."""
-        net_output = model(**sample["net_input"])
+        # Fast path: wav2vec-S's own configuration (two extra losses, both weighted, quantizer on) on this package's model -
+        # the cross entropy, the weighting below and their backward run inside the model's autograd node (w2vs_infonce_loss).
+        fused = (self.loss_weights is not None and len(self.loss_weights) == 2 and all(c != 0 for c in self.loss_weights)
+                 and getattr(model, "quantizer", None) is not None and hasattr(model, "_fused_loss") and self.fuse)
+        if fused:
+            model._fused_loss = (float(self.loss_weights[0]), float(self.loss_weights[1]))
+        try:
+            net_output = model(**sample["net_input"])
+        finally:
+            if fused:
+                model._fused_loss = None
+        if "_fused_loss" in net_output:
+            return self._fused_outputs(net_output, sample, sync_logging)
         if "_logits_bm" in net_output:
             logits = net_output["_logits_bm"]           # same rows as get_logits, (b, m) order; the sum is order free
         else:
@@ -103,6 +116,27 @@ class Wav2vecCriterion:
             logging_output["correct"] = int(out3[1].item()) - int(out3[2].item())
         else:
             logging_output["correct"] = (out3[1] - out3[2]).detach()
+        logging_output["count"] = float(sample_size)
+        return loss, sample_size, logging_output
+
+    def _fused_outputs(self, net_output, sample, sync_logging):
+        """(loss, sample_size, logging_output) from the fused launch: same keys and values as the composed path below."""
+        loss, vec = net_output["_fused_loss"].view(()), net_output["_loss_vec"]
+        sample_size = net_output["sample_size"]
+        host = vec.tolist() if sync_logging else None              # ONE device read for every logged scalar
+        val = (lambda i: host[i]) if sync_logging else (lambda i: vec[i])
+        nsent = sample["id"].numel() if "id" in sample else sample["net_input"]["source"].shape[0]
+        logging_output = {"loss": val(0), "ntokens": sample_size, "nsentences": nsent, "sample_size": sample_size}
+        keys = {"prob_perplexity": 5, "code_perplexity": 6, "features_pen": 7}
+        for lk in self.log_keys:
+            if lk in keys:
+                logging_output[lk] = val(keys[lk])
+            elif lk in net_output and lk not in ("logits", "target"):
+                v = net_output[lk]
+                logging_output[lk] = (float(v) if sync_logging else v) if torch.is_tensor(v) else float(v)
+        for i in range(3):
+            logging_output[f"loss_{i}"] = val(1 + i)
+        logging_output["correct"] = int(host[4]) if sync_logging else vec[4]
         logging_output["count"] = float(sample_size)
         return loss, sample_size, logging_output
 

@@ -31,6 +31,7 @@ int w2vs_sizeof(int which) {
     case 6: return (int)sizeof(w2vs_nce_desc);
     case 7: return (int)sizeof(w2vs_layer_desc);
     case 8: return (int)sizeof(w2vs_collate_desc);
+    case 9: return (int)sizeof(w2vs_infonce_loss_desc);
   }
   return -1;
 }
@@ -71,6 +72,10 @@ int w2vs_quant_bwd(const w2vs_quant_desc* d, void* s) { NONNULL(d); return quant
 int w2vs_nce_fwd(const w2vs_nce_desc* d, void* s) { NONNULL(d); return nce_fwd(*d, ST(s)); }
 int w2vs_nce_bwd(const w2vs_nce_desc* d, void* s) { NONNULL(d); return nce_bwd(*d, ST(s)); }
 int w2vs_ce_rows(const float* logits, int64_t R, int32_t W, float* out3, float* dl, void* s) { return ce_rows(logits, R, W, out3, dl, ST(s)); }
+int w2vs_infonce_loss(const w2vs_infonce_loss_desc* d, void* s) { NONNULL(d); return infonce_loss(*d, ST(s)); }
+int w2vs_infonce_loss_bwd(const float* g, float* dl, int64_t n, float c_pen, float c_ppl, float* dsc, void* s) {
+  return infonce_loss_bwd(g, dl, n, c_pen, c_ppl, dsc, ST(s));
+}
 int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, int32_t C, int32_t sc, void* s) {
   return gather_rows(src, idx, dst, R, C, sc, ST(s));
 }

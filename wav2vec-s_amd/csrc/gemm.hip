@@ -75,6 +75,128 @@ __device__ __forceinline__ void gelu_pair(float x, float& gv, float& dv) {
   dv = cdf + x * 0.3989422804014327f * e;
 }
 
+// ---- register-direct epilogue of the DMA kernels (operands swapped: the accumulators hold C^T fragments) --------------
+// Lane (fr, fq) owns, per 16-row block b of its wave's rows, row row0 + rel_row(b) and - from the two adjacent 16-column
+// tiles of column group u - the EIGHT consecutive columns col_of(u) .. +7: one 16-byte access per block and operand.
+// Everything goes through buffer instructions; a lane outside the matrix (row >= M, col >= N, or past c_elems) gets an
+// out-of-range offset, so its loads return zeros and its stores are dropped.  No exec branches: the side operand of EVERY
+// block (saved gelu' / residual, 16 B per lane and block) is requested before the first one is used.  With a branch per
+// block hipcc emitted load -> s_waitcnt vmcnt(0) -> store twenty times in a row: +10 us on an fc2 dgrad launch, +30-60 us on
+// the conv dgrads.  The accumulators are packed to bf16 first (the reference rounds the GEMM result before the pointwise
+// op as well), which frees the registers the outstanding loads land in.
+//   val(u, b, e): fp32 accumulator e (0..7) of column group u, block b.   Requires ldc <= 2^21 (host check).
+template <int EPI, int NU, int NB, bool BIAS_VEC, class ColOf, class RowBlk, class Val>
+__device__ __forceinline__ void epi_direct(const GemmP& p, int bz, int row0_, int fr_, ColOf col_of, RowBlk row_blk, Val val) {
+  static_assert(EPI != EPI_F32, "fp32 outputs keep their own loop");
+  // rows of block b: row0 + row_blk(b) + fr, row_blk(b) wave-uniform.  fr goes through an opaque asm so that nothing below can
+  // be hoisted in front of the K loop as a per-lane value: the 320-row 8-phase kernel has no register to spare there.
+  int fr = fr_;
+  asm volatile("" : "+v"(fr));
+  const int row0 = __builtin_amdgcn_readfirstlane(row0_);
+  const int ldc = (int)p.ldc;
+  const long base = (long)bz * p.sC + (long)row0 * p.ldc;               // wave-uniform element offset of (row0, 0)
+  long room = p.c_elems - (long)row0 * p.ldc;                          // valid elements of this batch from row0 on
+  room = room < 0 ? 0 : (room > 0x3FFFFFF8L ? 0x3FFFFFF8L : room);
+  const int lim = (int)room;
+  const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C + base, (uint32_t)lim * 2u);
+  const int rows_left = p.M - row0;
+  // byte offset of block (u, b) for this lane, or an out-of-range one; recomputed where it is used (3 VALU) rather than kept
+  auto offs = [&](int frx, int col, int b) -> uint32_t {
+    const int rb = row_blk(b);                                         // scalar
+    const int o = frx * ldc + col + rb * ldc;
+    const bool ok = frx < rows_left - rb && col < p.N && o + 8 <= lim;
+    return ok ? (uint32_t)o * 2u : 0x80000000u;
+  };
+  union V8 { bf16x8 h; u32x4 w; };
+  if constexpr (epi_is_dact(EPI) || EPI == EPI_ADD) {
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.aux + base, (uint32_t)lim * 2u);
+    V8 pk[NU][NB], ax[NU][NB];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[u][b].h[e] = f2bf(val(u, b, e));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) ax[u][b].w = __builtin_amdgcn_raw_buffer_load_b128(ra, offs(fr, col_of(u), b), 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    int fr2 = fr_;
+    asm volatile("" : "+v"(fr2));                                      // the store offsets are not kept from the load phase
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        V8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = bf2f(pk[u][b].h[e]), a = bf2f(ax[u][b].h[e]);
+          o8.h[e] = f2bf(EPI == EPI_ADD ? g + a : g * (EPI == EPI_MUL ? a : gelu_grad(a)));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o8.w, rc, offs(fr2, col_of(u), b), 0, 0);
+      }
+  } else {
+    __amdgpu_buffer_rsrc_t rc2 = rc;
+    if constexpr (epi_is_save(EPI)) rc2 = make_rsrc(p.C2 + base, (uint32_t)lim * 2u);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int col = col_of(u);
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if constexpr (epi_has_bias(EPI)) {
+        if (p.bias != nullptr && col < p.N) {
+          if constexpr (BIAS_VEC) {
+            const bf16x8 b8 = *(const bf16x8*)(p.bias + col);          // N % 8 == 0, bias 16-byte aligned (host check)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = bf2f(b8[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = bf2f(p.bias[col + e]); // N % 8 == 0 (host check)
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        V8 o8;
+        if constexpr (epi_is_gelu(EPI)) {
+          V8 pre;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = val(u, b, e) + bv[e];
+            pre.h[e] = f2bf(v);
+            float gv, dv;
+            gelu_pair(epi_is_save(EPI) ? bf2f(pre.h[e]) : v, gv, dv);  // the activation of the value that is saved
+            o8.h[e] = f2bf(gv);
+            if (EPI == EPI_BIAS_GELU_SAVEG) pre.h[e] = f2bf(dv);
+          }
+          if constexpr (epi_is_save(EPI)) __builtin_amdgcn_raw_buffer_store_b128(pre.w, rc2, offs(fr, col, b), 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8.h[e] = f2bf(val(u, b, e) + bv[e]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o8.w, rc, offs(fr, col, b), 0, 0);
+      }
+    }
+  }
+}
+
+template <int NU, int NB, class ColOf, class RowBlk, class Val>
+__device__ __forceinline__ void epi_direct_f32(const GemmP& p, int bz, int row0, int fr, ColOf col_of, RowBlk row_blk, Val val) {
+  float* Cf = p.Cf + (long)bz * p.sC;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int col = col_of(u);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int row = row0 + row_blk(b) + fr;
+      if (row >= p.M || col >= p.N) continue;
+      float* dst = Cf + (long)row * p.ldc + col;
+      *(f32x4*)dst = f32x4{val(u, b, 0) * p.alpha, val(u, b, 1) * p.alpha, val(u, b, 2) * p.alpha, val(u, b, 3) * p.alpha};
+      *(f32x4*)(dst + 4) = f32x4{val(u, b, 4) * p.alpha, val(u, b, 5) * p.alpha, val(u, b, 6) * p.alpha, val(u, b, 7) * p.alpha};
+    }
+  }
+}
+
 // SB = single LDS buffer: 34 KiB per block instead of 68, which lets THREE blocks share a CU (12 waves);
 // the tile for step kt+1 waits in registers while step kt computes, at the price of a second barrier.
 //   MODE 0: register-staged, double LDS buffer (2 blocks/CU)
@@ -251,60 +373,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? 3 : 2) void gemm_nt_kernel(GemmP p
   if (DMA) {
     // ---- epilogue straight from the registers: lane (fr, fq) holds row i*16+fr and, from tiles 2u / 2u+1, the eight
     // consecutive columns u*32 + fq*8 .. +7 of its wave's 64-column strip
-    const long cbase = (long)bz * p.sC;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int col = n0 + wn * 64 + u * 32 + fq * 8;
-      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (epi_has_bias(EPI)) {
-        if (p.bias != nullptr && col < p.N) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bv[e] = bf2f(p.bias[col + e]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * 64 + i * 16 + fr;
-        const long o = (long)row * p.ldc + col;
-        if (row >= p.M || col >= p.N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * u][e]; v[4 + e] = acc[i][2 * u + 1][e]; }
-        if (EPI == EPI_F32) {
-          *(f32x4*)(p.Cf + cbase + o) = f32x4{v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha};
-          *(f32x4*)(p.Cf + cbase + o + 4) = f32x4{v[4] * p.alpha, v[5] * p.alpha, v[6] * p.alpha, v[7] * p.alpha};
-          continue;
-        }
-        if (o + 8 > p.c_elems) continue;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
-        bf16x8 o8;
-        if (epi_is_gelu(EPI)) {
-          bf16x8 pre;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pre[e] = f2bf(v[e]);
-            float gv, dv;
-            gelu_pair(epi_is_save(EPI) ? bf2f(pre[e]) : v[e], gv, dv);   // the activation of the value that is saved
-            o8[e] = f2bf(gv);
-            if (EPI == EPI_BIAS_GELU_SAVEG) pre[e] = f2bf(dv);
-          }
-          if (epi_is_save(EPI)) *(bf16x8*)(p.C2 + cbase + o) = pre;
-        } else if (epi_is_dact(EPI)) {
-          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
-        } else if (EPI == EPI_ADD) {
-          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) + bf2f(a[e]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(v[e]);
-        }
-        *(bf16x8*)(p.C + cbase + o) = o8;
-      }
-    }
+    auto col_of = [&](int u) { return n0 + wn * 64 + u * 32 + fq * 8; };
+    auto row_blk = [&](int b) { return b * 16; };
+    auto val = [&](int u, int b, int e) { return acc[b][2 * u + (e >> 2)][e & 3]; };
+    if constexpr (EPI == EPI_F32) epi_direct_f32<2, 4>(p, bz, m0 + wm * 64, fr, col_of, row_blk, val);
+    else epi_direct<EPI, 2, 4, false>(p, bz, m0 + wm * 64, fr, col_of, row_blk, val);
     return;
   }
   // ---- epilogue: registers -> (fp32 math) -> LDS bf16 tile -> 16-B row-contiguous stores ----
@@ -741,60 +814,11 @@ __global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, 
     }
     // ---- epilogue straight from the registers: lane (fr, fq) holds row i*16+fr and, from tiles 2u / 2u+1, the
     // EIGHT consecutive columns u*32 + fq*8 .. +7 (one 16-byte store; dwordx2 stores are issue-bound)
-    const long cbase = (long)bz * p.sC;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int col = n0 + wn * 64 + u * 32 + fq * 8;
-      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (epi_has_bias(EPI)) {
-        if (p.bias != nullptr && col < p.N) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bv[e] = bf2f(p.bias[col + e]);   // N % 8 == 0 (host check)
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int row = m0 + wm * (MI * 16) + i * 16 + fr;
-        const long o = (long)row * p.ldc + col;
-        if (row >= p.M || col >= p.N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * u][e]; v[4 + e] = acc[i][2 * u + 1][e]; }
-        if (EPI == EPI_F32) {
-          *(f32x4*)(p.Cf + cbase + o) = f32x4{v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha};
-          *(f32x4*)(p.Cf + cbase + o + 4) = f32x4{v[4] * p.alpha, v[5] * p.alpha, v[6] * p.alpha, v[7] * p.alpha};
-          continue;
-        }
-        if (o + 8 > p.c_elems) continue;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
-        bf16x8 o8;
-        if (epi_is_gelu(EPI)) {
-          bf16x8 pre;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pre[e] = f2bf(v[e]);
-            float gv, dv;
-            gelu_pair(epi_is_save(EPI) ? bf2f(pre[e]) : v[e], gv, dv);   // the activation of the value that is saved
-            o8[e] = f2bf(gv);
-            if (EPI == EPI_BIAS_GELU_SAVEG) pre[e] = f2bf(dv);
-          }
-          if (epi_is_save(EPI)) *(bf16x8*)(p.C2 + cbase + o) = pre;
-        } else if (epi_is_dact(EPI)) {
-          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
-        } else if (EPI == EPI_ADD) {
-          const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) + bf2f(a[e]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = f2bf(v[e]);
-        }
-        *(bf16x8*)(p.C + cbase + o) = o8;
-      }
-    }
+    auto col_of = [&](int u) { return n0 + wn * 64 + u * 32 + fq * 8; };
+    auto row_blk = [&](int b) { return b * 16; };
+    auto val = [&](int u, int b, int e) { return acc[b][2 * u + (e >> 2)][e & 3]; };
+    if constexpr (EPI == EPI_F32) epi_direct_f32<2, MI>(p, bz, m0 + wm * (MI * 16), fr, col_of, row_blk, val);
+    else epi_direct<EPI, 2, MI, false>(p, bz, m0 + wm * (MI * 16), fr, col_of, row_blk, val);
   }
 }
 
@@ -1017,63 +1041,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
     // the other, each with one wave per SIMD - half the VALU / store issue rate of the CU.
     if (wr == 0) __builtin_amdgcn_s_barrier();
     const int m0 = tm * TBM, n0 = tn * 256;
-    const long cbase = (long)bz * p.sC;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int col = n0 + wc * 64 + u * 32 + fq * 8;
-      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (epi_has_bias(EPI)) {
-        if (p.bias != nullptr && col < p.N) {
-          const bf16x8 b8 = *(const bf16x8*)(p.bias + col);      // N % 8 == 0, bias 16-byte aligned (host check)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bv[e] = bf2f(b8[e]);
-        }
-      }
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int i = 0; i < MH; ++i) {
-          const int row = m0 + wr * WROWS + mh * HROWS + i * 16 + fr;
-          const long o = (long)row * p.ldc + col;
-          if (row >= p.M || col >= p.N) continue;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = acc[mh][i][2 * u][e]; v[4 + e] = acc[mh][i][2 * u + 1][e]; }
-          if (EPI == EPI_F32) {
-            *(f32x4*)(p.Cf + cbase + o) = f32x4{v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha};
-            *(f32x4*)(p.Cf + cbase + o + 4) = f32x4{v[4] * p.alpha, v[5] * p.alpha, v[6] * p.alpha, v[7] * p.alpha};
-            continue;
-          }
-          if (o + 8 > p.c_elems) continue;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bv[e];
-          bf16x8 o8;
-          if (epi_is_gelu(EPI)) {
-            bf16x8 pre;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              pre[e] = f2bf(v[e]);
-              float gv, dv;
-              gelu_pair(epi_is_save(EPI) ? bf2f(pre[e]) : v[e], gv, dv);   // the activation of the value that is saved
-              o8[e] = f2bf(gv);
-              if (EPI == EPI_BIAS_GELU_SAVEG) pre[e] = f2bf(dv);
-            }
-            if (epi_is_save(EPI)) *(bf16x8*)(p.C2 + cbase + o) = pre;
-          } else if (epi_is_dact(EPI)) {
-            const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) * (EPI == EPI_MUL ? bf2f(a[e]) : gelu_grad(bf2f(a[e]))));
-          } else if (EPI == EPI_ADD) {
-            const bf16x8 a = *(const bf16x8*)(p.aux + cbase + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = f2bf(bf2f(f2bf(v[e])) + bf2f(a[e]));
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = f2bf(v[e]);
-          }
-          *(bf16x8*)(p.C + cbase + o) = o8;
-        }
-    }
+    auto col_of = [&](int u) { return n0 + wc * 64 + u * 32 + fq * 8; };
+    auto row_blk = [&](int b) { return (b / MH) * HROWS + (b % MH) * 16; };
+    auto val = [&](int u, int b, int e) { return acc[b / MH][b % MH][2 * u + (e >> 2)][e & 3]; };
+    if constexpr (EPI == EPI_F32) epi_direct_f32<2, 2 * MH>(p, bz, m0 + wr * WROWS, fr, col_of, row_blk, val);
+    else epi_direct<EPI, 2, 2 * MH, true>(p, bz, m0 + wr * WROWS, fr, col_of, row_blk, val);
     if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 falls one barrier behind again
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's extra barrier in front of the tile loop
@@ -1797,6 +1769,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   if (d.epi == EPI_F32 ? !d.Cf : !d.C) return set_error("gemm_nt: null output");
   if ((d.ldc % 8) || (d.N % 8)) return set_error("gemm_nt: N and ldc must be multiples of 8");
   if (d.K % 8) return set_error("gemm_nt: K must be a multiple of 8");
+  if (d.ldc > (1L << 21)) return set_error("gemm_nt: ldc must be <= 2^21 (32-bit tile-relative output offsets)");
   if ((epi_is_dact(d.epi) || d.epi == EPI_ADD) && !d.aux) return set_error("gemm_nt: DGELU/MUL/ADD need aux");
   if (epi_is_save(d.epi) && !d.C2) return set_error("gemm_nt: GELU_SAVE / GELU_SAVEG need C2");
   GemmP p{};

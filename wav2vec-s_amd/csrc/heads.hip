@@ -226,12 +226,16 @@ static int quant_fill(const QuantDesc& d, QuantP& p) {
   return 0;
 }
 
+__global__ __launch_bounds__(256) void zero2_kernel(float* a, float* b, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { a[i] = 0.f; b[i] = 0.f; }
+}
+
 int quant_fwd(const QuantDesc& d, hipStream_t st) {
   QuantP p{};
   if (int e = quant_fill(d, p)) return e;
   if (!p.q || !p.idx || !p.hard_cnt || !p.prob_sum || !d.ppl_out) return set_error("quant_fwd: null pointer");
-  if (int e = hip_check(hipMemsetAsync(p.hard_cnt, 0, sizeof(float) * p.G * p.V, st), "memset")) return e;
-  if (int e = hip_check(hipMemsetAsync(p.prob_sum, 0, sizeof(float) * p.G * p.V, st), "memset")) return e;
+  // one small launch instead of two hipMemsetAsync (a fill kernel of ~5 us each for 2.5 KB)
+  hipLaunchKernelGGL(zero2_kernel, dim3(std::min((p.G * p.V + 255) / 256, 64)), dim3(256), 0, st, p.hard_cnt, p.prob_sum, (long)p.G * p.V);
   long rows = (long)p.R * p.G;
   int grid = (int)std::min<long>((rows + 3) / 4, 256);   // few blocks: the probability sums flush once per block
   hipLaunchKernelGGL(quant_kernel<false>, dim3(grid), dim3(256), 0, st, p);
@@ -606,7 +610,18 @@ int nce_bwd(const NceDesc& d, hipStream_t st) {
 // counters as the criterion computes them, and dlogits = softmax - onehot(0).
 // out[0] = loss sum, out[1] = #(argmax==0), out[2] = #(argmax==0 && argmin==0)
 // ================================================================================================
-__global__ __launch_bounds__(256) void ce_kernel(const float* logits, long R, int W, float* out, float* dlogits) {
+// TAIL: the block that finishes last also does the criterion's scalar arithmetic (fs/criterions/wav2vec_criterion.py:80-100),
+// which composed from framework ops is ~25 one-element launches per step:
+//   loss = ce + w_ppl * ((num_vars - prob_ppl) / num_vars) * sample_size + w_pen * features_pen * sample_size
+// and leaves the three accumulators and the ticket at zero again for the next launch.
+struct LossTail {
+  const float* pen_acc; const float* ppl;       // sum of squared features; {prob_perplexity, code_perplexity}
+  float w_ppl, w_pen, num_vars, pen_norm, sample_size;
+  float* loss; float* vec;                      // vec[8] = {loss, ce, ppl term, pen term, correct, prob_ppl, code_ppl, features_pen}
+  unsigned* ticket;
+};
+template <bool TAIL>
+__global__ __launch_bounds__(256) void ce_kernel(const float* logits, long R, int W, float* out, float* dlogits, LossTail tail) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   float loss_acc = 0.f, max0 = 0.f, both0 = 0.f;
@@ -639,6 +654,33 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* logits, long R, in
   if (lane == 0) { red[threadIdx.x >> 6][0] = loss_acc; red[threadIdx.x >> 6][1] = max0; red[threadIdx.x >> 6][2] = both0; }
   __syncthreads();
   if (threadIdx.x < 3) atomicAdd(&out[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+  if (TAIL) {
+    __shared__ int is_last;
+    if (threadIdx.x < 3) __threadfence();        // this block's three sums are out before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(tail.ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (is_last && threadIdx.x == 0) {
+      __threadfence();
+      const float ce = atomicExch(&out[0], 0.f), n_max0 = atomicExch(&out[1], 0.f), n_both0 = atomicExch(&out[2], 0.f);
+      atomicExch(tail.ticket, 0u);
+      const float prob_ppl = tail.ppl[0], code_ppl = tail.ppl[1];
+      const float pen = tail.pen_acc[0] * tail.pen_norm;
+      const float l1 = tail.w_ppl * ((tail.num_vars - prob_ppl) / tail.num_vars) * tail.sample_size;
+      const float l2 = tail.w_pen * pen * tail.sample_size;
+      const float loss = (ce + l1) + l2;
+      tail.loss[0] = loss;
+      tail.vec[0] = loss; tail.vec[1] = ce; tail.vec[2] = l1; tail.vec[3] = l2; tail.vec[4] = n_max0 - n_both0;
+      tail.vec[5] = prob_ppl; tail.vec[6] = code_ppl; tail.vec[7] = pen;
+    }
+  }
+}
+
+// dlogits *= g[0];  dsc = {g * c_pen, g * c_ppl}: everything the backward of the scalar arithmetic above hands on
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* g, float* dl, long n, float c_pen, float c_ppl, float* dsc) {
+  const float gv = g[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { dsc[0] = gv * c_pen; dsc[1] = gv * c_ppl; }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dl[i] *= gv;
 }
 
 int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hipStream_t st) {
@@ -646,8 +688,27 @@ int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hip
   if (R <= 0 || W <= 0) return set_error("ce_rows: bad shape");
   if (int e = hip_check(hipMemsetAsync(out3, 0, 3 * sizeof(float), st), "memset")) return e;
   int grid = (int)std::min<long>((R + 3) / 4, 256);
-  hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, st, logits, R, W, out3, dlogits);
+  hipLaunchKernelGGL(ce_kernel<false>, dim3(grid), dim3(256), 0, st, logits, R, W, out3, dlogits, LossTail{});
   return hip_check(hipGetLastError(), "ce_rows");
+}
+
+int infonce_loss(const InfonceLossDesc& d, hipStream_t st) {
+  if (!d.logits || !d.pen_acc || !d.ppl || !d.loss || !d.vec || !d.scratch) return set_error("infonce_loss: null pointer");
+  if (d.R <= 0 || d.W <= 0 || d.num_vars <= 0.f) return set_error("infonce_loss: bad shape");
+  LossTail t{};
+  t.pen_acc = d.pen_acc; t.ppl = d.ppl; t.w_ppl = d.w_ppl; t.w_pen = d.w_pen; t.num_vars = d.num_vars; t.pen_norm = d.pen_norm;
+  t.sample_size = d.sample_size; t.loss = d.loss; t.vec = d.vec; t.ticket = (unsigned*)(d.scratch + 3);
+  int grid = (int)std::min<long>((d.R + 3) / 4, 256);
+  hipLaunchKernelGGL(ce_kernel<true>, dim3(grid), dim3(256), 0, st, d.logits, (long)d.R, d.W, d.scratch, d.dlogits, t);
+  return hip_check(hipGetLastError(), "infonce_loss");
+}
+
+int infonce_loss_bwd(const float* g, float* dlogits, long n, float c_pen, float c_ppl, float* dsc, hipStream_t st) {
+  if (!g || !dlogits || !dsc) return set_error("infonce_loss_bwd: null pointer");
+  if (n <= 0) return set_error("infonce_loss_bwd: n must be positive");
+  const int grid = (int)std::min<long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid), dim3(256), 0, st, g, dlogits, n, c_pen, c_ppl, dsc);
+  return hip_check(hipGetLastError(), "infonce_loss_bwd");
 }
 
 // ================================================================================================

@@ -17,6 +17,7 @@ typedef w2vs_enc_prologue_desc EncPrologueDesc;
 typedef w2vs_attn_desc AttnDesc;
 typedef w2vs_quant_desc QuantDesc;
 typedef w2vs_nce_desc NceDesc;
+typedef w2vs_infonce_loss_desc InfonceLossDesc;
 
 int gemm_nt(const GemmDesc& d, hipStream_t s);
 int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s);
@@ -56,6 +57,8 @@ int quant_bwd(const QuantDesc& d, hipStream_t st);
 int nce_fwd(const NceDesc& d, hipStream_t st);
 int nce_bwd(const NceDesc& d, hipStream_t st);
 int ce_rows(const float* logits, long R, int W, float* out3, float* dlogits, hipStream_t st);
+int infonce_loss(const InfonceLossDesc& d, hipStream_t st);
+int infonce_loss_bwd(const float* g, float* dlogits, long n, float c_pen, float c_ppl, float* dsc, hipStream_t st);
 int gather_rows(const void* src, const int* idx, void* dst, long R, int C, int scatter, hipStream_t st);
 int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t st);
 int transpose_multi(const w2vs_transpose_item* items, int n, hipStream_t st);

@@ -222,9 +222,23 @@ class _HotPath(torch.autograd.Function):
         ctx.param_dtypes = [p.dtype for p in params]
         ctx.param_shapes = [tuple(p.shape) for p in params]
         model._last_state = st
+        ctx.fused = None
         if features_only:
             return st.out_x
         B, T, C0 = st.B, st.T, st.C0
+        fl = model._fused_loss
+        if fl is not None and st.qst is not None:
+            # criterion.Wav2vecCriterion asked for its own arithmetic on top (one launch instead of ~25 one-element ones):
+            # outputs are (loss [1], vec [8]); the logits never become an autograd tensor
+            w_ppl, w_pen = fl
+            ss = float(st.B * st.M)
+            nv = float(model.quantizer.num_vars * model.quantizer.groups)
+            loss, vec, dl = ops.infonce_loss(st.logits, st.pen_acc, st.qst.ppl, w_ppl=w_ppl, w_pen=w_pen, num_vars=nv,
+                                             pen_norm=1.0 / float(B * T * C0), sample_size=ss,
+                                             want_grad=any(ctx.needs_input_grad))
+            ctx.fused = (dl, w_pen * ss, -w_ppl * ss / nv)
+            ctx.mark_non_differentiable(vec)
+            return loss, vec
         pen = st.pen_acc.view(()) / float(B * T * C0)
         prob_ppl, code_ppl = st.qst.ppl[0].clone(), st.qst.ppl[1].clone()
         ctx.mark_non_differentiable(code_ppl)
@@ -245,6 +259,13 @@ class _HotPath(torch.autograd.Function):
             A = engine.Arena(engine.grad_shapes(st.cfg, st.W), st.feats.device)
         if st.features_only:
             engine.backward(st, A, d_out=grads[0].to(BF16).contiguous())
+        elif ctx.fused is not None:
+            dl, c_pen, c_ppl = ctx.fused
+            g = grads[0]
+            if g is None or dl is None:
+                raise W2vsError("fused criterion: no gradient arrived for the loss (or the forward ran without grad)")
+            dsc = ops.infonce_loss_bwd(g.detach().float().reshape(1).contiguous(), dl, c_pen, c_ppl)
+            engine.backward(st, A, d_logits=dl, d_pen=dsc[0:1], d_prob_ppl=dsc[1:2], on_ready=model._on_grad_ready)
         else:
             d_logits, d_pen, d_ppl = grads[0], grads[1], grads[2]
             d_logits = torch.zeros_like(st.logits) if d_logits is None else d_logits.float().contiguous()
@@ -322,6 +343,7 @@ class Wav2Vec2Model(nn.Module):
         self._flat = None                    # trainer.FlatParams when flat storage is active
         self._on_grad_ready = None           # trainer.GradExchange hook: overlap all-reduce with backward
         self._after_forward = None           # trainer.TrainStep hook: called with sample_size once the forward is enqueued
+        self._fused_loss = None              # criterion.Wav2vecCriterion: (w_ppl, w_pen) while its forward runs -> loss in the same node
         self._last_state = None
         self._draws = None
         self._np_cache = self._launch_cache = None      # see _named_params_cached / _weights_for_launch
@@ -474,6 +496,11 @@ class Wav2Vec2Model(nn.Module):
             pm = st.pad_frames.to(source.device)
         if features_only:
             return {"x": out, "padding_mask": pm}
+        if self._fused_loss is not None and len(out) == 2:
+            loss, vec = out
+            return {"_fused_loss": loss, "_loss_vec": vec, "sample_size": st.B * st.M, "padding_mask": pm,
+                    "prob_perplexity": vec[5], "code_perplexity": vec[6], "features_pen": vec[7],
+                    "num_vars": self.quantizer.num_vars * self.quantizer.groups, "temp": self.quantizer.curr_temp}
         logits, pen, prob_ppl, code_ppl = out
         B, M, K = st.B, st.M, st.K
         x = logits.view(B, M, K + 1).permute(2, 0, 1)              # (K+1) x B x M, wav2vec2.py:650

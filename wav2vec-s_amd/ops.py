@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_ADD, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_SAVE, EPI_BIAS_GELU_SAVEG, EPI_DGELU, EPI_F32, EPI_MUL, EPI_NONE, AttnDesc,
-                   EncPrologueDesc, GemmDesc, LnBwdDesc, LnFwdDesc, NceDesc, QuantDesc, W2vsError)
+                   EncPrologueDesc, GemmDesc, InfonceLossDesc, LnBwdDesc, LnFwdDesc, NceDesc, QuantDesc, W2vsError)
 
 BF16 = torch.bfloat16
 
@@ -733,6 +733,39 @@ def ce_rows(logits, want_grad=True):
     dl = empty(logits.shape, logits.dtype, logits.device) if want_grad else None
     _lib.call("w2vs_ce_rows", _p(logits), R, W, _p(out3), _p(dl), _stream())
     return out3, dl
+
+
+_LOSS_SCRATCH = {}
+
+
+def infonce_loss(logits, pen_acc, ppl, *, w_ppl, w_pen, num_vars, pen_norm, sample_size, want_grad=True):
+    """The InfoNCE criterion's arithmetic in ONE launch (w2vs_infonce_loss): cross entropy of the fp32 logits [R, W] against
+    class 0, then loss = ce + w_ppl * ((num_vars - prob_ppl) / num_vars) * sample_size + w_pen * pen_acc * pen_norm * sample_size.
+    Returns (loss [1], vec [8] = loss, ce, ppl term, pen term, correct, prob_ppl, code_ppl, features_pen, dlogits or None).
+    loss and vec come from torch's allocator, not the step arena: they are handed to autograd / the caller's logging."""
+    _chk(logits, torch.float32, "logits"); _chk(pen_acc, torch.float32, "pen_acc"); _chk(ppl, torch.float32, "ppl")
+    R, W = logits.shape
+    dev = logits.device
+    scratch = _LOSS_SCRATCH.get(dev)
+    if scratch is None:
+        scratch = _LOSS_SCRATCH[dev] = torch.zeros(4, dtype=torch.float32, device=dev)   # the kernel leaves it zero
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    vec = torch.empty(8, dtype=torch.float32, device=dev)
+    dl = empty(logits.shape, logits.dtype, dev) if want_grad else None
+    d = InfonceLossDesc()
+    d.logits, d.R, d.W, d.pen_acc, d.ppl = _p(logits), R, W, _p(pen_acc), _p(ppl)
+    d.w_ppl, d.w_pen, d.num_vars, d.pen_norm, d.sample_size = w_ppl, w_pen, num_vars, pen_norm, sample_size
+    d.loss, d.vec, d.dlogits, d.scratch = _p(loss), _p(vec), _p(dl), _p(scratch)
+    _lib.call("w2vs_infonce_loss", C.byref(d), _stream())
+    return loss, vec, dl
+
+
+def infonce_loss_bwd(g, dlogits, c_pen, c_ppl):
+    """dlogits *= g in place; returns dsc [2] = (g * c_pen, g * c_ppl): the gradients of features_pen and prob_perplexity."""
+    _chk(g, torch.float32, "g"); _chk(dlogits, torch.float32, "dlogits")
+    dsc = empty((2,), torch.float32, dlogits.device)
+    _lib.call("w2vs_infonce_loss_bwd", _p(g), _p(dlogits), dlogits.numel(), c_pen, c_ppl, _p(dsc), _stream())
+    return dsc
 
 
 def dropout(x, p, seed):
