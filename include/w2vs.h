@@ -323,6 +323,10 @@ int w2vs_sumsq(const float* x, int64_t n, float* out, void* stream);
  * out3[0] is what w2vs_adam_step takes as scale_dev; a non-finite norm gives scale 0 and flag 1
  * (the reference raises FloatingPointError, fs/trainer.py:791-793; the caller reads the flag when it chooses to). */
 int w2vs_clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, void* stream);
+/* The same, for a training loop that calls it once per update: additionally resets *sumsq to 0 (the next w2vs_sumsq needs
+ * no separate clear) and, when bad_acc is given, adds the non-finite flag to bad_acc[0] (a sticky count of skipped updates). */
+int w2vs_clip_scale_acc(float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, float* bad_acc,
+                        void* stream);
 /* out[n] += sum_m in[m, n] : bias gradients */
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* stream);
 

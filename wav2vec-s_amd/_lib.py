@@ -136,6 +136,7 @@ _SIGS = {
     "w2vs_adam_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, vp],
     "w2vs_sumsq": [vp, i64, vp, vp],
     "w2vs_clip_scale": [vp, vp, f32, f32, vp, vp],
+    "w2vs_clip_scale_acc": [vp, vp, f32, f32, vp, vp, vp],
     "w2vs_batch_by_size": [vp, i64, i64, i64, i32, vp, vp],
     "w2vs_collate_chunks": [i32],
     "w2vs_collate": [C.POINTER(CollateDesc), vp],

@@ -104,5 +104,8 @@ int w2vs_sumsq(const float* x, int64_t n, float* out, void* s) { return sumsq(x,
 int w2vs_clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, void* s) {
   return clip_scale(sumsq, scale_dev, scale_host, clip, out3, ST(s));
 }
+int w2vs_clip_scale_acc(float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, float* bad_acc, void* s) {
+  return clip_scale_acc(sumsq, scale_dev, scale_host, clip, out3, bad_acc, ST(s));
+}
 int w2vs_colsum(const void* in, float* out, int64_t M, int32_t N, int64_t ld, void* s) { return colsum(in, out, M, N, ld, ST(s)); }
 }

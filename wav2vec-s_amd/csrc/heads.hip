@@ -936,7 +936,8 @@ int sumsq(const float* x, long n, float* out, hipStream_t st) {
 //   inv = scale_host * (scale_dev ? *scale_dev : 1)          the 1 / sample_size factor
 //   gnorm = sqrt(sumsq) * inv ;  coef = clip > 0 ? min(1, clip / (gnorm + 1e-6)) : 1
 //   out = {inv * coef (what Adam multiplies the arena with), gnorm, non-finite flag}; non-finite norm -> scale 0
-__global__ void clip_scale_kernel(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3) {
+__global__ void clip_scale_kernel(float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, float* bad_acc,
+                                  int consume) {
   const float inv = scale_dev ? scale_host * scale_dev[0] : scale_host;
   const float gnorm = sqrtf(sumsq[0]) * inv;
   const bool ok = isfinite(gnorm);
@@ -945,11 +946,19 @@ __global__ void clip_scale_kernel(const float* sumsq, const float* scale_dev, fl
   out3[0] = ok ? inv * coef : 0.f;
   out3[1] = gnorm;
   out3[2] = ok ? 0.f : 1.f;
+  if (consume) sumsq[0] = 0.f;                   // ready for the next update's w2vs_sumsq
+  if (bad_acc && !ok) bad_acc[0] += 1.f;         // sticky count of skipped updates
 }
 int clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, hipStream_t st) {
   if (!sumsq || !out3) return set_error("clip_scale: null pointer");
-  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq, scale_dev, scale_host, clip, out3);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, const_cast<float*>(sumsq), scale_dev, scale_host, clip, out3,
+                     (float*)nullptr, 0);
   return hip_check(hipGetLastError(), "clip_scale");
+}
+int clip_scale_acc(float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, float* bad_acc, hipStream_t st) {
+  if (!sumsq || !out3) return set_error("clip_scale_acc: null pointer");
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, st, sumsq, scale_dev, scale_host, clip, out3, bad_acc, 1);
+  return hip_check(hipGetLastError(), "clip_scale_acc");
 }
 
 // out[n] += sum_m in[m][n]  (bf16 in, fp32 atomics out): bias gradients

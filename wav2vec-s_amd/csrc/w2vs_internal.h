@@ -74,6 +74,7 @@ int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n,
               float wd, int step, const float* scale_dev, float scale_host, hipStream_t st);
 int sumsq(const float* x, long n, float* out, hipStream_t st);
 int clip_scale(const float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, hipStream_t st);
+int clip_scale_acc(float* sumsq, const float* scale_dev, float scale_host, float clip, float* out3, float* bad_acc, hipStream_t st);
 int colsum(const void* in, float* out, long M, int N, long ld, hipStream_t st);
 
 }  // namespace w2vs

@@ -145,11 +145,29 @@ def _launch_weights(net, params):
         return c[1], c[2]
     P16 = [p.detach().to(BF16).contiguous() for p in params]
     packs = []
-    for li in range(len(net.layers)):
+    nL = len(net.layers)
+    dev = P16[0].device
+    D, F = P16[0].shape[0], P16[8].shape[0]                    # wq [D, D], w1 [F, D]
+    # every layer's k|v weight / bias through ONE multi-tensor copy and all 6 transposes per layer through ONE launch
+    # (12 torch.cat + 30 transposes before: a training forward rebuilds them every time)
+    wkv_all = torch.empty((2 * nL, D, D), dtype=BF16, device=dev)
+    bkv_all = torch.empty((2 * nL, D), dtype=BF16, device=dev)
+    src_w, src_b, items = [], [], []
+    for li in range(nL):
         wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2 = P16[16 * li: 16 * li + 12]
-        wkv, bkv = torch.cat([wk, wv], 0), torch.cat([bk, bv], 0)
-        packs.append(dict(wkv=wkv, bkv=bkv, wq_t=ops.transpose2d(wq), wkv_t=ops.transpose2d(wkv), wo_t=ops.transpose2d(wo),
-                          w1_t=ops.transpose2d(w1), w2_t=ops.transpose2d(w2)))
+        src_w += [wk, wv]
+        src_b += [bk, bv]
+        t = dict(wkv=wkv_all[2 * li:2 * li + 2].view(2 * D, D), bkv=bkv_all[2 * li:2 * li + 2].view(2 * D),
+                 wq_t=torch.empty((D, D), dtype=BF16, device=dev), wkv_t=torch.empty((D, 2 * D), dtype=BF16, device=dev),
+                 wo_t=torch.empty((D, D), dtype=BF16, device=dev), w1_t=torch.empty((D, F), dtype=BF16, device=dev),
+                 w2_t=torch.empty((F, D), dtype=BF16, device=dev))
+        kvt = t["wkv_t"].data_ptr()
+        items += [(wq.data_ptr(), t["wq_t"].data_ptr(), D, D), (wk.data_ptr(), kvt, D, D, D, 2 * D),
+                  (wv.data_ptr(), kvt + 2 * D, D, D, D, 2 * D), (wo.data_ptr(), t["wo_t"].data_ptr(), D, D),
+                  (w1.data_ptr(), t["w1_t"].data_ptr(), F, D), (w2.data_ptr(), t["w2_t"].data_ptr(), D, F)]
+        packs.append(t)
+    torch._foreach_copy_(list(wkv_all.unbind(0)) + list(bkv_all.unbind(0)), src_w + src_b)
+    ops.transpose_multi(items)
     net._launch_cache = (key, P16, packs) if reuse else None
     return P16, packs
 

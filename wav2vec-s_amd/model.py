@@ -434,10 +434,20 @@ class Wav2Vec2Model(nn.Module):
             for i in range(1, len(self.cfg.conv_layers)):
                 n = "feature_extractor.conv_layers.%d.0.weight" % i
                 packed[n] = ops.conv_pack_weight(W[n])
-            for li in range(self.cfg.encoder_layers):
-                pre = "encoder.layers.%d." % li
-                if pre + "self_attn.q_proj.weight" in W:
-                    packed[pre + "qkv"] = engine._qkv_pack(W, pre)
+            # fused [3E, E] q|k|v weights and [3E] biases of ALL layers through one multi-tensor copy (a training forward
+            # rebuilds them every time: 24 torch.cat launches before)
+            pres = ["encoder.layers.%d." % li for li in range(self.cfg.encoder_layers)]
+            pres = [pre for pre in pres if pre + "self_attn.q_proj.weight" in W]
+            if pres:
+                E = W[pres[0] + "self_attn.q_proj.weight"].shape[0]
+                dev = W[pres[0] + "self_attn.q_proj.weight"].device
+                wall = torch.empty((3 * len(pres), E, E), dtype=BF16, device=dev)
+                ball = torch.empty((3 * len(pres), E), dtype=BF16, device=dev)
+                src_w = [W[pre + "self_attn.%s_proj.weight" % c] for pre in pres for c in "qkv"]
+                src_b = [W[pre + "self_attn.%s_proj.bias" % c] for pre in pres for c in "qkv"]
+                torch._foreach_copy_(list(wall.unbind(0)) + list(ball.unbind(0)), src_w + src_b)
+                for i, pre in enumerate(pres):
+                    packed[pre + "qkv"] = (wall[3 * i:3 * i + 3].view(3 * E, E), ball[3 * i:3 * i + 3].view(3 * E))
         self._launch_cache = (key, W, packed) if reuse else None
         return W, packed
 

@@ -800,6 +800,14 @@ def clip_scale(sumsq_buf, out3, *, scale_host=1.0, scale_dev=None, clip=0.0):
     _lib.call("w2vs_clip_scale", _p(sumsq_buf), _p(scale_dev), scale_host, clip, _p(out3), _stream())
 
 
+def clip_scale_acc(sumsq_buf, out3, bad_acc, *, scale_host=1.0, scale_dev=None, clip=0.0):
+    """clip_scale that also clears ``sumsq_buf`` for the next update and adds the non-finite flag to ``bad_acc``
+    (w2vs_clip_scale_acc): one launch instead of three at the end of every update."""
+    _chk(sumsq_buf, torch.float32, "sumsq"); _chk(out3, torch.float32, "out3"); _chk(scale_dev, torch.float32, "scale_dev")
+    _chk(bad_acc, torch.float32, "bad_acc")
+    _lib.call("w2vs_clip_scale_acc", _p(sumsq_buf), _p(scale_dev), scale_host, clip, _p(out3), _p(bad_acc), _stream())
+
+
 def gather_rows(src, idx, R, scatter=False, out=None):
     """out[i] = src[idx[i]]  or (scatter) out[idx[i]] = src[i]; rows of bf16."""
     _chk(src, BF16, "src"); _chk(idx, torch.int32, "idx")

@@ -210,6 +210,7 @@ class TrainStep:
         self._bad_acc = torch.zeros(1, device=dev, dtype=torch.float32)   # sticky: number of skipped (non-finite) updates
         self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self._flag_event = None
+        self._one = None                  # cached d(loss)/d(loss)
         self._before_optimizer = None     # test hook: called right before the norm / Adam launches of an update
         # all per-step buffers come from one slab (see ops._StepArena); default 12 GiB of the 288 GB.  It hands out
         # memory only while a step runs: anything else in the process (validation forward, streaming twin) gets torch's.
@@ -252,7 +253,9 @@ class TrainStep:
         # only the closing micro-batch reports gradient milestones: earlier ones would all-reduce partial sums
         self.model._on_grad_ready = self.exchange.on_ready if (self.exchange is not None and last) else None
         loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
-        loss.backward()                           # milestones inside launch the bucketed all-reduces
+        if self._one is None or self._one.device != loss.device:
+            self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        torch.autograd.backward(loss, self._one)  # (a cached seed: loss.backward() fills a fresh one every step); milestones inside launch the bucketed all-reduces
         self.ss_acc += sample_size
         self.micro = 0 if last else self.micro + 1
         if not last:
@@ -281,11 +284,12 @@ class TrainStep:
                 # clip_grad_norm_ (fs/utils.py:341-386) on the gradient AFTER its division by sample_size
                 # (fs/trainer.py:769-774): norm, comparison and factor stay on the device; Adam reads the product
                 # (0 = non-finite norm = skip the update)
-                self.norm_buf.zero_()
+                # norm_buf is zero here: allocated so, and every clip_scale_acc leaves it so.  The same launch adds the
+                # non-finite flag to _bad_acc - sticky on the device: a copy that is skipped below loses nothing
                 ops.sumsq(f.arena.flat, self.norm_buf)
-                ops.clip_scale(self.norm_buf, self.clip_out, scale_host=scale, scale_dev=scale_dev, clip=self.clip)
+                ops.clip_scale_acc(self.norm_buf, self.clip_out, self._bad_acc, scale_host=scale, scale_dev=scale_dev,
+                                   clip=self.clip)
                 scale, scale_dev = 1.0, self.clip_out[0:1]
-                self._bad_acc += self.clip_out[2:3]          # sticky on the device: a copy that is skipped below loses nothing
                 if self._flag_host is not None and self._flag_event is None:
                     self._flag_host.copy_(self._bad_acc, non_blocking=True)
                     self._flag_event = torch.cuda.Event()
