@@ -60,18 +60,49 @@ def _draws(cfg, B, L, keep=None, seed=7):
     return lambda: engine.Draws(mask_indices=mask, neg_idx=neg, context=(8, 4), layer_keep=list(keep), gumbel_noise=noise)
 
 
-def _same_update(p1, p2, lr, arena):
-    """Two runs of the same update agree to 2e-5 in EVERY parameter element - except inside the ``k_proj.bias`` ranges, which are
-    named here: their gradient is analytically zero (the softmax does not see a per-query constant), what is computed is
-    summation noise whose float-atomic order has a few possible outcomes, and Adam's lr * g / (|g| + eps) turns those into moves
-    of up to ~lr (observed twice: 6.7e-4 on 1.3e-4 of all elements, every one of them a k_proj.bias element).  Any other
-    tensor that moves is a finding, not tolerance.  The attention kernels themselves are bitwise reproducible."""
+def _adam_dir(m, v, t, betas=(0.9, 0.98), eps=1e-6):
+    """The direction fairseq's Adam moves along after t updates, from its state (fs/optim/adam.py:205-229)."""
+    bc1, bc2 = 1.0 - betas[0] ** t, 1.0 - betas[1] ** t
+    return (bc2 ** 0.5 / bc1) * m.double() / (v.double().sqrt() + eps)      # eps is added to the UNcorrected sqrt(v) (:221-224)
+
+
+def _same_update(p1, p2, lr, arena, adam=None):
+    """Two runs of the same update must agree to 2e-5 in EVERY parameter element, except where Adam's own INPUTS differed.
+    lr * m / (sqrt(v) + eps) is ill-conditioned near g = 0: d(update)/dg = lr * eps / (|g| + eps)^2, so the run-to-run
+    differences a gradient legitimately carries (float-atomic summation order; bf16 re-rounding of atomically summed
+    intermediates - ~1e-6 at most) can move an element by up to ~lr.  Observed: 6.7e-4 on 1.3e-4 of all elements, all of them
+    ``k_proj.bias`` (analytically zero gradient: the softmax does not see a per-query constant - pure summation noise), and
+    once, in round 3, on ONE conv0 weight element.  With ``adam`` = ((m1, v1), (m2, v2), t) the allowance of an element is
+    what its two Adam states explain: 2e-5 + 1.05 lr |dir1 - dir2|; a stale master, a wrong range or a skipped element is
+    not explained by them and fails.  Without it the exception is by NAME: the k_proj.bias ranges, up to 2.1 lr.
+    The attention kernels themselves are bitwise reproducible."""
     diff = (p1.double() - p2.double()).abs()
     free = torch.zeros(diff.numel(), dtype=torch.bool, device=diff.device)
     for n, (off, numel, _) in arena.offsets.items():
         if n.endswith("k_proj.bias"):
             free[off:off + numel] = True
     assert int(free.sum()) > 0
+    if adam is not None:
+        (m1, v1), (m2, v2), t = adam
+        allow = 2e-5 + 1.05 * lr * (_adam_dir(m1, v1, t) - _adam_dir(m2, v2, t)).abs()
+        used = (diff > 2e-5) & ~free
+        print("elements outside k_proj.bias that needed their Adam-input allowance: %d of %d" % (int(used.sum()), diff.numel()))
+        if bool(used.any()):
+            names = {}
+            for i in torch.nonzero(used).view(-1).tolist():
+                for n, (off, numel, _) in arena.offsets.items():
+                    if off <= i < off + numel:
+                        names[n] = names.get(n, 0) + 1
+            print("  by tensor:", names, " worst |dm|/|m|:", float(((m1 - m2).abs() / (m1.abs() + 1e-12))[used].max()))
+        assert float(used.double().mean()) < 1e-3, "run-to-run gradient differences must stay rare"
+        bad = diff > allow
+        if bool(bad.any()):
+            idx = int(torch.nonzero(bad)[0])
+            owner = [n for n, (off, numel, _) in arena.offsets.items() if off <= idx < off + numel]
+            raise AssertionError("|dp| %.3g at element %d of %s is not explained by its Adam states (allowance %.3g; m %.3g vs %.3g)"
+                                 % (float(diff[idx]), idx, owner, float(allow[idx]), float(m1[idx]), float(m2[idx])))
+        assert float(diff.max()) <= 2.1 * lr
+        return True
     worst_named = float(diff[free].max())
     rest = diff[~free]
     assert worst_named <= 2.1 * lr, "k_proj.bias moved by %.3g (lr %.3g)" % (worst_named, lr)
@@ -113,13 +144,14 @@ def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
             assert (cov == 1).all(), "every arena element is reduced exactly once"
             assert len(step.exchange.launched) >= 3
         gn = step.grad_norm() if clip > 0 else None
-        res.append((step.flat.arena.flat.clone(), step.flat.p32.clone(), step.flat.m.clone(), step.flat.p16.clone(), gn))
+        res.append((step.flat.arena.flat.clone(), step.flat.p32.clone(), step.flat.m.clone(), step.flat.p16.clone(), gn,
+                    step.flat.v.clone()))
         ops.ARENA.deactivate()
-    (g1, p1, m1, q1, n1), (g2, p2, m2, q2, n2) = res
+    (g1, p1, m1, q1, n1, v1), (g2, p2, m2, q2, n2, v2) = res
     den = float(g1.double().norm())
     assert float((g1.double() - g2.double()).norm()) / den < 2e-4          # fp32-atomic ordering only
     assert float((m1.double() - m2.double()).norm()) / float(m1.double().norm()) < 2e-4
-    assert _same_update(p1, p2, 1e-3, step.flat.arena)
+    assert _same_update(p1, p2, 1e-3, step.flat.arena, adam=((m1, v1), (m2, v2), 1))
     assert float((q1.float() != q2.float()).float().mean()) < 1e-3        # bf16 images: a last-bit flip at most
     if clip > 0:
         assert abs(n1 - n2) / n1 < 1e-4
@@ -210,14 +242,19 @@ def test_load_state_dict_resyncs_master_and_optimizer_state_round_trips():
         step({"net_input": {"source": src}})
     torch.cuda.synchronize()
     # same weights, same draws: the two updates agree everywhere but in the named zero-gradient tensors (_same_update)
-    assert _same_update(step_a.flat.p32, step_b.flat.p32, 1e-3, step_a.flat.arena)
+    assert _same_update(step_a.flat.p32, step_b.flat.p32, 1e-3, step_a.flat.arena,
+                        adam=((step_a.flat.m, step_a.flat.v), (step_b.flat.m, step_b.flat.v), 1))
+    dmaster = (step_a.flat.p32.double() - step_b.flat.p32.double()).abs()
     for k, v in model_a.state_dict().items():
-        if "pos_conv" in k:
+        if "pos_conv" in k or k not in step_a.flat.arena.offsets:
             continue
-        # the LOADED weights survived the update: per tensor, agreement at the scale of the weights; only k_proj.bias may
-        # carry the ~2 lr of its noise-gradient update on top
-        slack = 2.1e-3 if k.endswith("k_proj.bias") else 1e-6
-        assert float((v.float() - model_b.state_dict()[k].float()).abs().max()) <= 2e-2 * float(v.float().abs().max()) + slack, k
+        # the LOADED weights survived the update, and what the module holds is the bf16 image of its (checked) master: two
+        # images differ by no more than their masters do plus one bf16 rounding each
+        off, numel, _ = step_a.flat.arena.offsets[k]
+        bound = float(dmaster[off:off + numel].max()) + 2.0 ** -7 * float(v.float().abs().max()) + 1e-12
+        assert float((v.float() - model_b.state_dict()[k].float()).abs().max()) <= bound, k
+        ref = sd[k].float().cuda()
+        assert bool(((v.float() - ref).abs() <= 1.1e-3 + 2.0 ** -7 * ref.abs()).all()), k   # one update of <= ~lr (+ a bf16 rounding) on the LOADED values
     # optimizer state round trip: a third trainer resumes from (a) and takes the same second step
     osd = step_a.flat.state_dict()
     w, cfg, model_c, crit_c = _build(SMALL, seed=9)
@@ -228,7 +265,8 @@ def test_load_state_dict_resyncs_master_and_optimizer_state_round_trips():
         model.inject_draws(mk())
         step({"net_input": {"source": src}})
     torch.cuda.synchronize()
-    assert _same_update(step_a.flat.p32, step_c.flat.p32, 1e-3, step_a.flat.arena)
+    assert _same_update(step_a.flat.p32, step_c.flat.p32, 1e-3, step_a.flat.arena,
+                        adam=((step_a.flat.m, step_a.flat.v), (step_c.flat.m, step_c.flat.v), 2))
     with pytest.raises(ValueError):
         bad = dict(osd, layout={})
         step_c.flat.load_state_dict(bad)

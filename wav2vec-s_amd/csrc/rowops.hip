@@ -699,6 +699,8 @@ int ln_bwd(const LnBwdDesc& d, hipStream_t st) {
   } else {
     grid = std::min(grid, 256);   // no workspace: per-block atomics, keep their number down
   }
+  static const int atomic_env = [] { const char* e = getenv("W2VS_LN_BWD_ATOMIC"); return e ? atoi(e) : 0; }();   // A/B: N > 0 = atomics from N blocks
+  if (atomic_env > 0) { part = nullptr; grid = std::min<long>((p.rows + NW - 1) / NW, atomic_env); }
   if (full) hipLaunchKernelGGL((ln_bwd_kernel<true, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);
   else hipLaunchKernelGGL((ln_bwd_kernel<false, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);
   if (part) {
