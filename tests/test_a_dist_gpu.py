@@ -158,6 +158,60 @@ def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
         assert n1 > clip                                                   # the case does clip
 
 
+def test_update_divides_by_the_sample_size_summed_over_ranks(nccl_group):
+    """The round-2 review: on a 1-rank group the division by the sum of sample_size over ranks is an identity.  Here a stub
+    process group plays a SECOND rank with its own sample_size and its own gradient (0.5 x this rank's, so the sum is 1.5 g):
+    the update must be Adam's on 1.5 g / (ss_local + ss_peer) - fs/trainer.py:769-774 (multiply_grads(world / sample_size) after the
+    SUM all-reduce of gradients and of the logging outputs' sample_size) - with clipping applied to THAT gradient."""
+    from wav2vec_s_amd import trainer, ops
+    B, L, lr, clip, ss_peer = 2, 16000, 1e-3, 0.02, 37.0
+
+    class _Work:
+        def wait(self):
+            pass
+
+    class _Peer:
+        class ReduceOp:
+            SUM = 0
+
+        def __init__(self):
+            self.scalars = []
+
+        def all_reduce(self, t, op=None, group=None, async_op=False):
+            if t.numel() == 1:
+                self.scalars.append(float(t))
+                t += ss_peer
+            else:
+                t *= 1.5
+            return _Work()
+
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    w, cfg, model, crit = _build(SMALL)
+    step = trainer.TrainStep(model, crit, world_size=2, lr=lr, clip_norm=clip, arena_gib=1.0)
+    peer = _Peer()
+    step.dist = peer
+    step.exchange.dist = peer
+    step.exchange.bucket = 50_000
+    p0 = step.flat.p32.clone()
+    model.inject_draws(_draws(cfg, B, L)())
+    step({"net_input": {"source": src}})
+    torch.cuda.synchronize()
+    assert len(peer.scalars) == 1 and peer.scalars[0] == float(step.ss_acc)     # this rank contributed its own sample_size
+    g = step.flat.arena.flat.double()                    # the arena after the exchange: 1.5 x the local gradient
+    inv = 1.0 / (peer.scalars[0] + ss_peer)
+    gnorm = float(g.norm()) * inv
+    assert abs(step.grad_norm() - gnorm) / gnorm < 1e-5
+    assert gnorm > clip                                   # the case does clip
+    gs = g * inv * min(1.0, clip / (gnorm + 1e-6))
+    b1, b2, eps, wd = step.betas[0], step.betas[1], step.eps, step.wd
+    m, v = (1 - b1) * gs, (1 - b2) * gs * gs
+    want = p0.double() - lr * ((1 - b2) ** 0.5 / (1 - b1) * m / (v.sqrt() + eps) + wd * p0.double())   # fs/optim/adam.py:205-229
+    err = (step.flat.p32.double() - want).abs()
+    assert float(err.max()) < 2e-6, float(err.max())
+    assert float((step.flat.m.double() - m).abs().max()) <= 1e-6 * float(m.abs().max()) + 1e-12
+    ops.ARENA.deactivate()
+
+
 def test_clip_norm_on_device_matches_reference_formula():
     """clip_grad_norm_ after the division by sample_size (fs/utils.py:341-386 after fs/trainer.py:769-774), then fairseq
     Adam (fs/optim/adam.py:205-229), recomputed with torch from the raw arena of an optimizer-less twin step."""
