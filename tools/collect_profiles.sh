@@ -22,3 +22,9 @@ python tools/attn_probe.py > gpurun_out/final_attention_probe.txt 2>/dev/null
   for d in 1 2 3; do W2VS_TN8=1 W2VS_TN8_DBG=$d python tools/wgrad_group_probe.py 6544; done
   W2VS_TN8=1 W2VS_TN8_S=1 python tools/wgrad_group_probe.py 6544 ) > gpurun_out/final_wgrad_group_probe.txt 2>/dev/null
 tail -3 gpurun_out/final_wgrad_group_probe.txt
+
+# the rows around the headline path: large configuration, config-5 step, streaming encoder call
+python bench.py --workload large --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final_bench_large.json
+python bench.py --workload caat 2>/dev/null | tail -1 > gpurun_out/final_bench_caat.json
+python bench.py --workload stream 2>/dev/null | tail -1 > gpurun_out/final_bench_stream.json
+tail -c 200 gpurun_out/final_bench_caat.json
