@@ -221,9 +221,18 @@ typedef struct w2vs_layer_desc {
    * d_in = dL/d x_in, d_stream_in = dL/d stream_in. */
   const void* stream_in; const void* d_stream_out; void* d_stream_in;
   void* drop_bits;   /* optional: w2vs_attn_desc.drop_bits of this layer's attention (written by fwd, read by bwd) */
+  /* 1 (needs ws_e3, no sel_idx): layer_bwd does NOT launch the four weight gradients; their operands stay in ws_f (d fc1-out),
+   * ws_e0 (d fc2-out), ws_qkv (d qkv), ws_e3 (d out_proj-out) until the caller passes this descriptor to w2vs_layer_wgrads -
+   * the next layer's backward must therefore run on OTHER ws_f / ws_e0 / ws_qkv / ws_e3 buffers */
+  int32_t defer_wgrads;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);
+/* The weight gradients (+ bias gradients) of n = 1 or 2 layers whose layer_bwd ran with defer_wgrads = 1, as ONE grouped
+ * launch.  Two base-model layers are 216 output tiles of 256 x 256 with full-length K loops: no K split, no exchange between
+ * workgroups - a single layer's 108 tiles need the split to fill the chip.  Falls back to one launch per layer when the pair
+ * does not fit one workgroup per CU. */
+int w2vs_layer_wgrads(const w2vs_layer_desc* layers, int32_t n, void* stream);
 
 /* ---- Gumbel vector quantizer ---------------------------------------------------------------------
  * fs/modules/gumbel_vector_quantizer.py:141-202 after the weight_proj GEMM: hard argmax +

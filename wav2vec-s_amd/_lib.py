@@ -78,7 +78,8 @@ class LayerDesc(C.Structure):
                     "g_ln2_g", "g_ln2_b", "ws_e0", "ws_e1", "ws_e2", "ws_f", "ws_qkv", "wt_scratch", "delta",
                     "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64), ("sel_idx", vp), ("n_sel", i32),
                                                                             ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp), ("ws_e3", vp),
-                                                                            ("stream_in", vp), ("d_stream_out", vp), ("d_stream_in", vp), ("drop_bits", vp)])
+                                                                            ("stream_in", vp), ("d_stream_out", vp), ("d_stream_in", vp), ("drop_bits", vp),
+                                                                            ("defer_wgrads", i32)])
 
 
 class CollateDesc(C.Structure):
@@ -116,6 +117,7 @@ _SIGS = {
     "w2vs_attn_bwd": [C.POINTER(AttnDesc), vp],
     "w2vs_layer_fwd": [C.POINTER(LayerDesc), vp],
     "w2vs_layer_bwd": [C.POINTER(LayerDesc), vp],
+    "w2vs_layer_wgrads": [vp, i32, vp],
     "w2vs_quant_fwd": [C.POINTER(QuantDesc), vp],
     "w2vs_quant_bwd": [C.POINTER(QuantDesc), vp],
     "w2vs_nce_fwd": [C.POINTER(NceDesc), vp],

@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(768) void gemm_tn_group_kernel(TnGroupP g) {
 // issue-bound, not operand-bound like the 256 x 128 kernel; a one-sided hand-off (256 KB slab, plain stores + release
 // fence, last arriver combines) cost ~30 us per launch and erased the gain, hence the symmetric write-through form.
 // ---------------------------------------------------------------------------------------------
-struct Tn8GroupP { GemmP p[4]; int first[5]; int S; float* slab; long slab_bytes; unsigned* cnt; int dbg; };   // dbg: timing-only ablations
+struct Tn8GroupP { GemmP p[8]; int first[9]; int S; float* slab; long slab_bytes; unsigned* cnt; int dbg; };   // up to 8 GEMMs: two layers' weight gradients   // dbg: timing-only ablations
 // the tr read as inline asm: behind the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the first read of every loop
 // iteration (an LDS read without a memory operand "may alias" every LDS-DMA in flight), which drains the staging pipeline.
 // The wave waits for these reads itself: s_waitcnt lgkmcnt(0) + sched_barrier behind the phase's first barrier.
@@ -1451,9 +1451,9 @@ __global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
     tile = id / g.S; sp = id - tile * g.S;     // (split-major ids - pairs on different XCDs, more shared panels per XCD - measured the same)
   }
   int pi = 0;
-  if (tile >= g.first[1]) pi = 1;
-  if (tile >= g.first[2]) pi = 2;
-  if (tile >= g.first[3]) pi = 3;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (tile >= g.first[i]) pi = i;
   pi = __builtin_amdgcn_readfirstlane(pi);
   const GemmP& p = g.p[pi];
   const int t = tile - g.first[pi];
@@ -1990,9 +1990,27 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
 // n <= 4 weight-gradient GEMMs in one launch (see gemm_tn_group_kernel).  Falls back to one gemm_tn per problem when the
 // group does not qualify (alignment, batching, more tiles than CUs, tiny K).
 int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
-  if (!ds || n < 1 || n > 4) return set_error("gemm_tn_group: 1..4 problems");
+  if (!ds || n < 1 || n > 8) return set_error("gemm_tn_group: 1..8 problems");
   const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
+  if (n > 4) {
+    // more than four problems (two layers' weight gradients): only the 8-phase kernel takes them as ONE launch, and only when
+    // their 256^2 tiles fit one workgroup per CU WITHOUT a K split; otherwise two groups, as before
+    static const int tn8_env2 = [] { const char* e = getenv("W2VS_TN8"); return e ? atoi(e) : 1; }();
+    int t8 = 0;
+    bool ok8 = tn8_env2 != 0;
+    for (int i = 0; i < n; ++i) {
+      const GemmDesc& d = ds[i];
+      t8 += ((d.N + 255) / 256) * ((d.M + 255) / 256);
+      ok8 = ok8 && d.Cf && (d.M % 8) == 0 && (d.N % 8) == 0 && (d.batch <= 1) && d.sC == 0 && (d.ldc % 4) == 0 &&
+            ((uintptr_t)d.Cf % 16) == 0 && d.K >= 8 * TK;
+    }
+    if (!ok8 || t8 > ncu || t8 * 8 < ncu * 5) {
+      if (int e = gemm_tn_group(ds, 4, num_cu_hint, s)) return e;
+      return gemm_tn_group(ds + 4, n - 4, num_cu_hint, s);
+    }
+  }
   TnGroupP g{};
+  GemmP gp[8] = {};
   int tiles = 0;
   double flops = 0;
   bool ok = true;
@@ -2001,7 +2019,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
     if (int e = check_common(d)) return e;
     if (!d.Cf) return set_error("gemm_tn: needs an fp32 accumulation target");
     if ((d.M % 8) || (d.N % 8)) return set_error("gemm_tn: M and N must be multiples of 8");
-    GemmP& p = g.p[i];
+    GemmP& p = gp[i];
     p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.Cf = d.Cf;
     p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.a_off = d.a_off; p.alpha = d.alpha;
     p.colsum = d.colsum;
@@ -2010,19 +2028,19 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
     if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_tn: operand extent must be < 2 GiB per batch");
     p.a_bytes = (uint32_t)a_ext; p.b_bytes = (uint32_t)b_ext;
     p.k_split = ((d.K + TK - 1) / TK) * TK; p.n_split = 1;
-    g.first[i] = tiles;
+    if (i < 4) { g.p[i] = p; g.first[i] = tiles; }      // the single-writer kernel's table holds four (a larger group never reaches it)
     tiles += ((d.N + 127) / 128) * ((d.M + 255) / 256);
     flops += 2.0 * d.M * d.N * d.K;
     ok = ok && (d.batch <= 1) && d.sC == 0 && (d.ldc % 4) == 0 && ((uintptr_t)d.Cf % 16) == 0 && d.K >= 8 * TK;
   }
-  for (int i = n; i <= 4; ++i) g.first[i] = tiles;
+  for (int i = std::min(n, 4); i <= 4; ++i) g.first[i] = tiles;
   // Round 3: 256 x 256 tiles + split K over workgroup pairs (gemm_tn8_group_kernel) when that fills the chip better
   static const int tn8_env = [] { const char* e = getenv("W2VS_TN8"); return e ? atoi(e) : 1; }();
   if (ok && tn8_env) {
     Tn8GroupP g8{};
     int t8 = 0;
-    for (int i = 0; i < n; ++i) { g8.p[i] = g.p[i]; g8.first[i] = t8; t8 += ((ds[i].N + 255) / 256) * ((ds[i].M + 255) / 256); }
-    for (int i = n; i <= 4; ++i) g8.first[i] = t8;
+    for (int i = 0; i < n; ++i) { g8.p[i] = gp[i]; g8.first[i] = t8; t8 += ((ds[i].N + 255) / 256) * ((ds[i].M + 255) / 256); }
+    for (int i = n; i <= 8; ++i) g8.first[i] = t8;
     int minK = ds[0].K;
     for (int i = 1; i < n; ++i) minK = std::min(minK, ds[i].K);
     int S = std::max(1, std::min(2, ncu / std::max(1, t8)));
@@ -2051,6 +2069,10 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
       prof_end(pe, 13, flops, s);                  // id 13: the 8-phase grouped weight-gradient launch
       return hip_check(hipGetLastError(), "gemm_tn8_group launch");
     }
+  }
+  if (n > 4) {                                     // (the pre-check above makes this unreachable; never run the 4-entry kernel on 8)
+    if (int e = gemm_tn_group(ds, 4, num_cu_hint, s)) return e;
+    return gemm_tn_group(ds + 4, n - 4, num_cu_hint, s);
   }
   static const int grp_env = [] { const char* e = getenv("W2VS_TN_GROUP"); return e ? atoi(e) : 1; }();
   // grouped only when it fills >= 3/4 of the chip AND leaves some slack: with exactly one workgroup per CU a single CU that is

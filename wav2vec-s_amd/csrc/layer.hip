@@ -58,6 +58,15 @@ static GemmDesc wgrad_desc(const void* dy, const void* x, float* dw, float* db, 
 
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
 
+// the four weight gradients of a layer whose backward kept their operands alive (ws_e3 given, full rows)
+static void layer_wgrad_descs(const w2vs_layer_desc& L, GemmDesc* g) {
+  const int R = L.B * L.N, E = L.E, F = L.F;
+  g[0] = wgrad_desc(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, L.tn_ws, L.tn_ws_bytes);             // fc1   [F,E]
+  g[1] = wgrad_desc(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, L.tn_ws, L.tn_ws_bytes);             // fc2   [E,F]
+  g[2] = wgrad_desc(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, L.tn_ws, L.tn_ws_bytes); // qkv   [3E,E]
+  g[3] = wgrad_desc(L.ws_e3, L.ctx, L.g_wo, L.g_bo, R, E, E, L.tn_ws, L.tn_ws_bytes);           // out_proj [E,E]
+}
+
 static int layer_check(const w2vs_layer_desc& L) {
   if (L.B <= 0 || L.N <= 0 || L.E <= 0 || L.F <= 0 || L.H <= 0) return set_error("layer: bad dims");
   if (L.E % 8 || L.F % 8 || L.E / L.H != 64) return set_error("layer: need E%8==0, F%8==0, head_dim 64");
@@ -202,15 +211,27 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   // post-LN: x_in is also the residual -> + d_res; pre-LN: x_in = LN(s_in) feeds the projection only, d_res went to d_stream_in
   TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, L.post_ln ? d_res : nullptr, R, 3 * E, E,
                 L.post_ln ? EPI_ADD : EPI_NONE, s));
-  if (defer) {
-    const GemmDesc g[4] = {
-        wgrad_desc(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, L.tn_ws, L.tn_ws_bytes),           // fc1   [F,E]
-        wgrad_desc(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, L.tn_ws, L.tn_ws_bytes),           // fc2   [E,F]
-        wgrad_desc(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, L.tn_ws, L.tn_ws_bytes),   // qkv [3E,E]
-        wgrad_desc(L.ws_e3, ctx, L.g_wo, L.g_bo, R, E, E, L.tn_ws, L.tn_ws_bytes)};          // out_proj [E,E]
+  if (L.defer_wgrads && !defer) return set_error("layer_bwd: defer_wgrads needs ws_e3 and no sel_idx");
+  if (defer && !L.defer_wgrads) {
+    GemmDesc g[4];
+    layer_wgrad_descs(L, g);
     TRY(gemm_tn_group(g, 4, cu, s));
   }
   return 0;
+}
+
+int layer_wgrads(const w2vs_layer_desc* Ls, int n, hipStream_t s) {
+  if (!Ls || n < 1 || n > 2) return set_error("layer_wgrads: 1 or 2 layers");
+  GemmDesc g[8];
+  for (int i = 0; i < n; ++i) {
+    const w2vs_layer_desc& L = Ls[i];
+    TRY(layer_check(L));
+    if (!L.ws_e3 || L.sel_idx || !L.ws_f || !L.ws_e0 || !L.ws_qkv || !L.g_wqkv || !L.g_bqkv || !L.g_wo || !L.g_bo || !L.g_w1 ||
+        !L.g_b1 || !L.g_w2 || !L.g_b2)
+      return set_error("layer_wgrads: the layer was not run with defer_wgrads (ws_e3, no sel_idx) or lacks gradient pointers");
+    layer_wgrad_descs(L, g + 4 * i);
+  }
+  return gemm_tn_group(g, 4 * n, Ls[0].num_cu > 0 ? Ls[0].num_cu : 256, s);
 }
 
 }  // namespace w2vs

@@ -468,6 +468,7 @@ SELECT_LAST_LAYER = True
 # W2VS_ATTN_KEEP_BITS=1: park the attention-dropout decisions as bits in the forward, read them in the backward
 KEEP_MASK_STORE = os.environ.get("W2VS_ATTN_KEEP_BITS", "0") == "1"
 # the four weight gradients of a post-LN layer as one grouped launch (w2vs_gemm_tn_group); W2VS_GROUP_WGRADS=0 disables
+PAIR_WGRADS = os.environ.get("W2VS_PAIR_WGRADS", "1") != "0"     # A/B: 0 = every layer launches its own weight gradients
 GROUP_WGRADS = os.environ.get("W2VS_GROUP_WGRADS", "1") != "0"
 
 _POS_TABLES = {}
@@ -620,6 +621,17 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
             o += n_
         d_in_bufs = [offs["d_in_a"], None]
         e3 = ops.empty((R, E), BF16, dev) if GROUP_WGRADS else None    # fourth [R,E] scratch: grouped weight gradients
+        # Weight gradients of TWO layers in one launch (w2vs_layer_wgrads): a base layer's four are 108 tiles of 256^2 and need a
+        # two-way K split with an exchange between workgroup pairs to fill the chip; two layers are 216 tiles with full-length
+        # K loops and no exchange.  The first layer of a pair keeps its dY operands (ws_f, ws_e0, ws_qkv, ws_e3) while the second
+        # one runs its backward on a second set of those four buffers.
+        pair = PAIR_WGRADS and e3 is not None and len(st.layers) > 1
+        set2 = None
+        if pair:
+            ws2 = ops.empty((R * (E + F + 3 * E + E),), BF16, dev)
+            p2 = ws2.data_ptr()
+            set2 = {"ws_e0": p2, "ws_f": p2 + 2 * R * E, "ws_qkv": p2 + 2 * R * (E + F), "ws_e3": p2 + 2 * R * (E + F + 3 * E)}
+        pending = None                                     # (layer descriptor, jj) whose weight gradients are still to be launched
         alt = ops.empty((R, E), BF16, dev)
         d_in_bufs[1] = alt.data_ptr()
         ds_bufs = [ops.empty((R, E), BF16, dev), ops.empty((R, E), BF16, dev)] if not post_ln else None
@@ -659,6 +671,11 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 setattr(d, f_, offs[f_])
             d.delta = delta.data_ptr()
             d.ws_e3 = e3.data_ptr() if e3 is not None else None
+            deferred = bool(pair and not d.sel_idx)
+            d.defer_wgrads = 1 if deferred else 0
+            if deferred and (jj & 1):                      # consecutive layers alternate between the two operand sets
+                for f_ in ("ws_e0", "ws_f", "ws_qkv", "ws_e3"):
+                    setattr(d, f_, set2[f_])
             off_w = A.offsets[pre + "self_attn.q_proj.weight"][0]
             off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
             fp = A.flat.data_ptr()
@@ -669,20 +686,34 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                            ("g_w2", pre + "fc2.weight"), ("g_b2", pre + "fc2.bias"), ("g_ln2_g", nb[0]), ("g_ln2_b", nb[1])):
                 setattr(d, f_, fp + 4 * A.offsets[n_][0])
             _lib.call("w2vs_layer_bwd", C.byref(d), stream)
-            # pre-LN: this call also finalised the NEXT norm's gradient (layer li+1's self_attn_layer_norm), so the arena
-            # is final from that layer's start only once this one is done - report one layer late
-            if post_ln:
-                ready(milestone_offset(A, pre))
-            elif jj > 0:
-                ready(milestone_offset(A, f"encoder.layers.{st.layers[len(st.layers) - jj]['li']}."))
+            launched = not deferred
+            if deferred:
+                if pending is None:
+                    pending = d
+                else:
+                    arr = (type(d) * 2)(pending, d)
+                    _lib.call("w2vs_layer_wgrads", arr, 2, stream)
+                    pending, launched = None, True
+            # a milestone is reported only once every gradient at or above it is final, i.e. never while a layer's weight
+            # gradients are pending.  pre-LN: this call also finalised the NEXT norm's gradient (layer li+1's
+            # self_attn_layer_norm), so the arena is final from that layer's start only once this one is done - one layer late
+            if launched:
+                if post_ln:
+                    ready(milestone_offset(A, pre))
+                elif jj > 0:
+                    ready(milestone_offset(A, f"encoder.layers.{st.layers[len(st.layers) - jj]['li']}."))
             if jj & 1:
                 cur = alt
             else:
                 cur = ws[(3 * R * E + R * F + 3 * R * E):(3 * R * E + R * F + 3 * R * E) + R * E].view(R, E)
             if not post_ln:
                 d_stream = ds_bufs[jj & 1]
+        if pending is not None:                             # an odd layer count: the last one goes alone (K split as before)
+            arr = (type(pending) * 1)(pending)
+            _lib.call("w2vs_layer_wgrads", arr, 1, stream)
+            pending = None
         dx = cur
-        st._bwd_ws = (ws, alt, delta, e3, ds_bufs)
+        st._bwd_ws = (ws, alt, delta, e3, ds_bufs, ws2 if pair else None)
     if post_ln:
         d_x0 = dx
     elif st.layers:
