@@ -502,6 +502,74 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
   }
 }
 
+// The encoder layers' form (dropout + residual + LayerNorm, no GELU, no penalty sum) with ONE row per wave and few enough
+// registers for seven waves per SIMD: every row of a 6544-row activation is in flight at once, where the general kernel above
+// (124 registers, four waves per SIMD) takes two rounds of dependent load -> reduce -> store chains.
+__global__ __launch_bounds__(256, 7) void ln_fwd_lean_kernel(LnP p) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int C = p.C, nch = C >> 3;
+  const bool two = lane + 64 < nch, one = lane < nch;
+  const bf16* xp = p.x + row * C;
+  u32x4 rx[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}}, rr[2] = {rx[0], rx[0]};
+  if (one) rx[0] = *(const u32x4*)(xp + lane * 8);
+  if (two) rx[1] = *(const u32x4*)(xp + (lane + 64) * 8);
+  if (p.res) {
+    const bf16* rp = p.res + row * C;
+    if (one) rr[0] = *(const u32x4*)(rp + lane * 8);
+    if (two) rr[1] = *(const u32x4*)(rp + (lane + 64) * 8);
+  }
+  const Drop D = make_drop(p.p_drop, p.seed);
+  float v[2][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float m[8];
+    if (p.p_drop > 0.f) drop8(D, (uint32_t)(row * nch + lane + 64 * h), m);
+    u32x4 packed;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a0 = __uint_as_float(rx[h][j] << 16), a1 = __uint_as_float(rx[h][j] & 0xFFFF0000u);
+      if (p.p_drop > 0.f) { a0 *= m[2 * j]; a1 *= m[2 * j + 1]; }
+      a0 += __uint_as_float(rr[h][j] << 16); a1 += __uint_as_float(rr[h][j] & 0xFFFF0000u);
+      if (p.sum_out) {          // the LN sees the value that is stored (bf16), as a two-kernel pipeline would
+        bf16x2 t; t[0] = f2bf(a0); t[1] = f2bf(a1);
+        packed[j] = __builtin_bit_cast(uint32_t, t);
+        a0 = __uint_as_float(packed[j] << 16); a1 = __uint_as_float(packed[j] & 0xFFFF0000u);
+      }
+      v[h][2 * j] = a0; v[h][2 * j + 1] = a1;
+      sum += a0 + a1;
+    }
+    if (p.sum_out && (h == 0 ? one : two)) *(u32x4*)(p.sum_out + row * C + (lane + 64 * h) * 8) = packed;
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (h == 0 ? one : two) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[h][e] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + LN_EPS);
+  if (lane == 0 && p.mean) { p.mean[row] = mean; p.rstd[row] = rstd; }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (h == 0 ? one : two) {
+      const int ch = lane + 64 * h;
+      const u32x4 g = *(const u32x4*)(p.g + ch * 8), b = *(const u32x4*)(p.b + ch * 8);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z0 = (v[h][2 * j] - mean) * rstd * __uint_as_float(g[j] << 16) + __uint_as_float(b[j] << 16);
+        const float z1 = (v[h][2 * j + 1] - mean) * rstd * __uint_as_float(g[j] & 0xFFFF0000u) + __uint_as_float(b[j] & 0xFFFF0000u);
+        bf16x2 t; t[0] = f2bf(z0); t[1] = f2bf(z1);
+        o[j] = __builtin_bit_cast(uint32_t, t);
+      }
+      *(u32x4*)(p.y + row * C + ch * 8) = o;
+    }
+}
+
 // dx = LNbwd(dy) [+ dsum];   dres = dx;   d(x) = dx * dropmask/(1-p)
 // `x` here must be the LN *input* (sum).  When gelu: dy is wrt gelu(LN(x)).
 // One wave per row; NW waves per block.  FULL = false is the lean encoder-layer form (no fused GELU, no
@@ -675,6 +743,11 @@ int ln_fwd(const LnFwdDesc& d, hipStream_t st) {
   if (p.y && !p.mean) return set_error("ln_fwd: mean/rstd buffers required");
   if (int e = ln_check(p, "ln_fwd")) return e;
   static const int cap = getenv("W2VS_LN_FWD_GRID") ? atoi(getenv("W2VS_LN_FWD_GRID")) : 256 * 4;   // ~1.6 rows per wave at the encoder size: measured best of 512 / 768 / 1024 / 2048
+  static const int lean_env = [] { const char* e = getenv("W2VS_LN_LEAN"); return e ? atoi(e) : 1; }();
+  if (lean_env && p.y && !p.sumsq && !p.gelu && p.rows >= 1024 && p.rows < (1L << 30)) {
+    hipLaunchKernelGGL(ln_fwd_lean_kernel, dim3((unsigned)((p.rows + 3) / 4)), dim3(256), 0, st, p);
+    return hip_check(hipGetLastError(), "ln_fwd");
+  }
   int grid = (int)std::min<long>((p.rows + 3) / 4, cap);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "ln_fwd");
