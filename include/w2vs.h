@@ -73,12 +73,16 @@ int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
  * 256 / 192 / 160; tn_lc: -1 auto, 0 the 128x128 atomics kernel, 1 the loader-consumer kernel.  Returns 0. */
 int w2vs_gemm_tune(int32_t nt_mode, int32_t lc_height, int32_t tn_lc);
 /* Measurement hooks: bracket every stride-th GEMM launch with HIP events on its own stream (0 = off).
- * id = NT epilogue (0..6) or 7 for gemm_tn; read returns summed launch time [ms], algorithmic FLOPs
- * and the number of launches timed since the last enable. */
+ * id = one kernel symbol family (NT: 16 * form + epilogue; weight gradients 10..13); read returns summed launch time [ms],
+ * algorithmic FLOPs and the number of launches timed since the last enable.  An event pair also times any gap in which the
+ * stream waited for the host to enqueue the launch: samples whose time per FLOP exceeds 3 x the family's median are left out
+ * of the totals (never with fewer than four samples). */
 int w2vs_prof_enable(int stride);
 int w2vs_prof_read(int id, double* total_ms, double* total_flops, int* launches);
-/* every launch of that kernel id since w2vs_prof_enable (the timed ones are a 1-in-stride sample of them) */
+/* every launch of that kernel id since w2vs_prof_enable (the timed ones are a 1-in-stride sample of them), and the algorithmic
+ * FLOPs of all of them (scales a sample's time to its whole family when the family mixes shapes) */
 int64_t w2vs_prof_launches(int id);
+double w2vs_prof_flops(int id);
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
 /* n <= 4 weight-gradient GEMMs (e.g. the four of one encoder layer: fused QKV, out_proj, fc1, fc2) as ONE launch without
  * a K split: together their 256x128 tiles fill the chip, every tile has a single writer (C += A^T B with plain stores:

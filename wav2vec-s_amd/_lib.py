@@ -105,6 +105,7 @@ _SIGS = {
     "w2vs_prof_enable": [i32],
     "w2vs_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)],
     "w2vs_prof_launches": [i32],          # returns a count, not a status (read through load(), not call())
+    "w2vs_prof_flops": [i32],             # returns a double (read through load(), restype set there)
     "w2vs_conv0_fwd": [vp] * 8 + [i32] * 5 + [vp],
     "w2vs_conv0_bwd": [vp] * 12 + [i32] * 5 + [vp],
     "w2vs_conv0_gn_fwd": [vp] * 7 + [i32] * 5 + [vp],
@@ -167,7 +168,7 @@ def load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = C.c_double if name == "w2vs_prof_flops" else C.c_int
     if lib.w2vs_abi_version() != 1:
         raise W2vsError("libw2vs ABI version mismatch")
     for i, d in enumerate(_DESCS):

@@ -38,6 +38,7 @@ int w2vs_sizeof(int which) {
 int w2vs_prof_enable(int stride) { prof_enable(stride); return 0; }
 int w2vs_prof_read(int id, double* ms, double* flops, int* n) { return prof_read(id, ms, flops, n); }
 int64_t w2vs_prof_launches(int id) { return prof_launches(id); }
+double w2vs_prof_flops(int id) { return prof_flops_all(id); }
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* s) { NONNULL(d); return gemm_nt(*d, ST(s)); }
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int cu, void* s) { NONNULL(d); return gemm_tn(*d, cu, ST(s)); }
 int w2vs_gemm_tn_group(const w2vs_gemm_desc* d, int32_t n, int32_t cu, void* s) { NONNULL(d); return gemm_tn_group(d, n, cu, ST(s)); }

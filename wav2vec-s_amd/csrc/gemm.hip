@@ -1711,12 +1711,14 @@ static std::vector<ProfSample> g_prof;
 static int g_prof_stride = 0;
 static long g_prof_count = 0;
 static long g_prof_launches[64] = {0};      // every launch per id since prof_enable (the sampled ones are a subset)
+static double g_prof_flops_all[64] = {0};   // algorithmic FLOPs of every launch per id (scales the sample to the whole family)
 void prof_enable(int stride) {
   for (auto& s : g_prof) { (void)hipEventDestroy(s.e0); (void)hipEventDestroy(s.e1); }
   g_prof.clear();
   g_prof_stride = stride;
   g_prof_count = 0;
   for (long& c : g_prof_launches) c = 0;
+  for (double& f : g_prof_flops_all) f = 0;
 }
 static inline hipEvent_t prof_begin(hipStream_t st, int own_stride = 0) {
   if (g_prof_stride <= 0) return nullptr;
@@ -1728,7 +1730,7 @@ static inline hipEvent_t prof_begin(hipStream_t st, int own_stride = 0) {
   return e;
 }
 static inline void prof_end(hipEvent_t e0, int id, double flops, hipStream_t st) {
-  if (g_prof_stride > 0 && id >= 0 && id < 64) ++g_prof_launches[id];
+  if (g_prof_stride > 0 && id >= 0 && id < 64) { ++g_prof_launches[id]; g_prof_flops_all[id] += flops; }
   if (!e0) return;
   hipEvent_t e1;
   if (hipEventCreate(&e1) != hipSuccess) return;
@@ -1736,15 +1738,31 @@ static inline void prof_end(hipEvent_t e0, int id, double flops, hipStream_t st)
   g_prof.push_back({e0, e1, id, flops});
 }
 long prof_launches(int id) { return (id >= 0 && id < 64) ? g_prof_launches[id] : 0; }
+double prof_flops_all(int id) { return (id >= 0 && id < 64) ? g_prof_flops_all[id] : 0.0; }
+// Totals over the timed samples of a family.  An event pair also times any gap in which the stream waited for the HOST to
+// enqueue the launch (a late launch thread: one 0.8 ms sample among seven once made a 45 us kernel look like 150 us), so samples
+// whose time per FLOP exceeds 3 x the family's median are left out - with fewer than four samples nothing is.
 int prof_read(int id, double* total_ms, double* total_flops, int* launches) {
-  double ms = 0, fl = 0;
-  int n = 0;
+  std::vector<std::pair<double, double>> v;      // (ms, flops)
   for (auto& s : g_prof) {
     if (s.id != id) continue;
     if (hipEventSynchronize(s.e1) != hipSuccess) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, s.e0, s.e1) != hipSuccess) continue;
-    ms += t; fl += s.flops; ++n;
+    v.emplace_back((double)t, s.flops);
+  }
+  double cut = 1e300;
+  if (v.size() >= 4) {
+    std::vector<double> r;
+    for (auto& x : v) r.push_back(x.first / std::max(x.second, 1.0));
+    std::nth_element(r.begin(), r.begin() + r.size() / 2, r.end());
+    cut = 3.0 * r[r.size() / 2];
+  }
+  double ms = 0, fl = 0;
+  int n = 0;
+  for (auto& x : v) {
+    if (x.first / std::max(x.second, 1.0) > cut) continue;
+    ms += x.first; fl += x.second; ++n;
   }
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;

@@ -27,6 +27,7 @@ void attn_tune(int variant);
 void prof_enable(int stride);
 int prof_read(int id, double* total_ms, double* total_flops, int* launches);
 long prof_launches(int id);
+double prof_flops_all(int id);
 int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, void* y,
               float* mean, float* rstd, int B, int L, int C, int k, int s, hipStream_t st);
 int conv0_bwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, const float* mean,

@@ -133,13 +133,16 @@ class _GemmTimer:
             ms, fl, n = C.c_double(), C.c_double(), C.c_int32()
             _lib.call("w2vs_prof_read", k, C.byref(ms), C.byref(fl), C.byref(n))
             if n.value:
-                groups[k] = (ms.value * 1e-3, fl.value, n.value, int(_lib.load().w2vs_prof_launches(k)))
+                groups[k] = (ms.value * 1e-3, fl.value, n.value, int(_lib.load().w2vs_prof_launches(k)),
+                             float(_lib.load().w2vs_prof_flops(k)))
         _lib.call("w2vs_prof_enable", 0)
         if not groups:
             return None
-        # dominant = largest ESTIMATED total (mean timed launch x every launch of that kernel), not largest sampled total:
-        # a 1-in-29 sample of a kernel launched 10 times a step is too thin to rank by
-        k, (t, fl, n, _) = max(groups.items(), key=lambda kv: kv[1][0] / kv[1][2] * max(kv[1][3], kv[1][2]))
+        # dominant = largest ESTIMATED total, not largest sampled total (a 1-in-29 sample of a kernel launched 10 times a step is
+        # too thin to rank by): the sample's time scaled by (FLOPs of ALL launches of the family / FLOPs of the timed ones) - a
+        # family mixes shapes (the fc2 dgrad and the conv dgrads share a symbol), so scaling by launch COUNT mis-ranked it
+        # whenever the sample happened to hold the big ones
+        k, (t, fl, n, _, _) = max(groups.items(), key=lambda kv: kv[1][0] * max(kv[1][4], kv[1][1]) / max(kv[1][1], 1.0))
         ach = fl / t / 1e12
         out = {"bound": "mfma", "kernel": names[k], "achieved": round(ach, 1), "peak": peak_tflops, "unit": "TFLOP/s",
                "frac": round(ach / peak_tflops, 4), "traffic": None, "launches_timed": n,
