@@ -62,6 +62,7 @@ for sync in (True, False):
 if os.environ.get("W2VS_CPROFILE") == "1":
     import cProfile
     import pstats
+    torch.autograd.set_multithreading_enabled(False)      # the backward nodes run on THIS thread: cProfile sees them
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(5):

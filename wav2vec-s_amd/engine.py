@@ -278,7 +278,7 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
     per32 = B * H * N + 4 * R + nbits
     slab32 = ops.empty((max(nk, 1) * per32,), torch.float32, dev)
     st.tmp = slab16[max(nk, 1) * per16:]
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    stream = ops._stream()
     kpad_ptr = st.kpad.data_ptr() if st.kpad is not None else None
     use_sel = SELECT_LAST_LAYER and not features_only and "token_idx" in st.up and nk > 0
     names = [f"encoder.layers.{li}." for li in st.kept]
@@ -455,7 +455,7 @@ def single_layer_forward(layer, x, padding_mask=None):
     d.lse = base
     d.mean1, d.rstd1 = base + 4 * (B * H * T), base + 4 * (B * H * T + R)
     d.mean2, d.rstd2 = base + 4 * (B * H * T + 2 * R), base + 4 * (B * H * T + 3 * R)
-    _lib.call("w2vs_layer_fwd", C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.call("w2vs_layer_fwd", C.byref(d), ops._stream())
     out = bufs["s2"] if pre_ln else bufs["x_out"]         # pre-LN: the layer's output is the stream itself
     res = torch.empty(T * B, E, dtype=BF16, device=dev)
     ops.gather_rows(out, idx.reshape(-1).contiguous(), B * T, scatter=True, out=res)
@@ -611,7 +611,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
     if st.layers:
         ws = ops.empty((R * (3 * E + F + 3 * E + E) + max(3 * E * E, E * F),), BF16, dev)
         delta = ops.empty((B * H * N,), torch.float32, dev)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = ops._stream()
         wp = ws.data_ptr()
         offs = {}
         o = 0

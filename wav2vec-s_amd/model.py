@@ -281,18 +281,41 @@ class _HotPath(torch.autograd.Function):
             # their memory (views of the recycled slab trip autograd's view/in-place check and would be overwritten)
             flat16 = flat16.clone()
         dropped = set(range(st.cfg.encoder_layers)) - set(st.kept)
+        offs = A.offsets
+        fo, no_ext = st.features_only, st.cfg.feature_grad_mult <= 0
+        no_mask = st.features_only and st.mask_np is None
         out = []
         for n, dt, shp in zip(names, ctx.param_dtypes, ctx.param_shapes):
-            if n not in A or _is_unused(n, st, dropped):
+            ent = offs.get(n)
+            if ent is None:
                 out.append(None)
                 continue
-            off, numel, ashp = A.offsets[n]
+            li, head, ext, conv_w = _name_kind(n)          # (the same decisions as _is_unused, without re-parsing the name)
+            if (li >= 0 and li in dropped) or (fo and head) or (no_ext and ext) or (no_mask and n == "mask_emb"):
+                out.append(None)
+                continue
+            off, numel, ashp = ent
             g = (flat16 if dt == BF16 else A.flat)[off:off + numel].view(ashp)
-            if len(ashp) == 3 and n.startswith("feature_extractor.conv_layers.") and n.endswith(".0.weight"):
+            if conv_w and len(ashp) == 3:
                 g = g.permute(0, 2, 1).contiguous()
             out.append(g if g.dtype == dt else g.to(dt))
         ctx.st = None
         return (None, None, None, None, None, None, *out)
+
+
+_NAME_KIND = {}
+
+
+def _name_kind(n):
+    """Static facts about a parameter name, parsed once: (encoder layer index or -1, head, extractor, conv weight to permute)."""
+    k = _NAME_KIND.get(n)
+    if k is None:
+        li = int(n.split(".")[2]) if n.startswith("encoder.layers.") else -1
+        head = n.startswith("quantizer.") or n.startswith("project_q.") or n.startswith("final_proj.")
+        ext = n.startswith("feature_extractor.")
+        conv_w = n.startswith("feature_extractor.conv_layers.") and n.endswith(".0.weight")
+        k = _NAME_KIND[n] = (li, head, ext, conv_w)
+    return k
 
 
 def _is_unused(n, st, dropped):

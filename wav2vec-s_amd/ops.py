@@ -76,7 +76,14 @@ def zeros(shape, dtype, device):
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() builds a Stream object
+    (~10 us of host time per call: 1 ms of a launch-bound step with 500 launches); the raw getter is a plain C call."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
