@@ -407,13 +407,14 @@ class MHAJointNet(nn.Module):
         else:
             G, ds = 1, -1
             group_lengths = decoder_state.new(decoder_state.shape[0]).long().fill_(1)
-        kpad = pad.to(torch.uint8).contiguous() if pad is not None and bool(pad.any()) else None
+        # (no `pad.any()` test: it is a device -> host round trip that stops the launch thread until the encoder has finished;
+        # an all-false mask costs the attention kernels one byte per key instead)
+        kpad = pad.to(torch.uint8).contiguous() if pad is not None else None
         self._calls += 1
         base = (torch.cuda.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
         params = []
         for layer in self.layers:
-            sd = dict(layer.named_parameters())
-            params += [sd[n] for n in _PER_LAYER]
+            params += [layer.get_parameter(n) for n in _PER_LAYER]
         x = _JointFn.apply(self, decoder_state, enc, kpad, ds, G, self.training, base, incremental_state, *params)
         return x, group_lengths
 
