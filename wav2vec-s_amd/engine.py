@@ -45,15 +45,18 @@ class Draws:
 class Arena:
     """Flat fp32 gradient arena with named views."""
 
-    def __init__(self, shapes: Dict[str, tuple], device, flat: Optional[torch.Tensor] = None):
-        self.offsets = {}
-        off = 0
-        for n, shp in shapes.items():
-            numel = int(np.prod(shp))
-            self.offsets[n] = (off, numel, shp)
-            off += (numel + 3) // 4 * 4  # keep 16-B alignment of every view
-        self.numel = off
-        self.flat = torch.zeros(off, device=device, dtype=torch.float32) if flat is None else flat
+    def __init__(self, shapes: Dict[str, tuple], device, flat: Optional[torch.Tensor] = None, layout=None):
+        if layout is not None:               # (offsets, numel) of an earlier arena with the same shapes: nothing to recompute
+            self.offsets, self.numel = layout
+        else:
+            self.offsets = {}
+            off = 0
+            for n, shp in shapes.items():
+                numel = int(np.prod(shp))
+                self.offsets[n] = (off, numel, shp)
+                off += (numel + 3) // 4 * 4  # keep 16-B alignment of every view
+            self.numel = off
+        self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32) if flat is None else flat
 
     def view(self, n):
         off, numel, shp = self.offsets[n]

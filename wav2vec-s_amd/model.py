@@ -256,7 +256,17 @@ class _HotPath(torch.autograd.Function):
         if flat_mode:
             A = model._flat.arena            # persistent fp32 arena the optimizer / all-reduce work on
         else:
-            A = engine.Arena(engine.grad_shapes(st.cfg, st.W), st.feats.device)
+            # the layout (216 names sorted into forward order, offsets) depends on the parameter set only: computed once
+            key = tuple(names)
+            lay = model._arena_layout if model._arena_layout is not None and model._arena_layout[0] == key else None
+            if lay is None:
+                A = engine.Arena(engine.grad_shapes(st.cfg, st.W), st.feats.device)
+                model._arena_layout = (key, (A.offsets, A.numel), {n: tuple(st.W[n].shape) for n in st.W})
+            elif lay[2] != {n: tuple(st.W[n].shape) for n in st.W}:
+                A = engine.Arena(engine.grad_shapes(st.cfg, st.W), st.feats.device)
+                model._arena_layout = (key, (A.offsets, A.numel), {n: tuple(st.W[n].shape) for n in st.W})
+            else:
+                A = engine.Arena(None, st.feats.device, layout=lay[1])
         if st.features_only:
             engine.backward(st, A, d_out=grads[0].to(BF16).contiguous())
         elif ctx.fused is not None:
@@ -367,6 +377,7 @@ class Wav2Vec2Model(nn.Module):
         self._on_grad_ready = None           # trainer.GradExchange hook: overlap all-reduce with backward
         self._after_forward = None           # trainer.TrainStep hook: called with sample_size once the forward is enqueued
         self._fused_loss = None              # criterion.Wav2vecCriterion: (w_ppl, w_pen) while its forward runs -> loss in the same node
+        self._arena_layout = None            # (parameter names, arena offsets) of the per-call gradient arena (non-flat training)
         self._last_state = None
         self._draws = None
         self._np_cache = self._launch_cache = None      # see _named_params_cached / _weights_for_launch
