@@ -11,9 +11,9 @@ for d in ('pmc_attn_a','pmc_attn_b'):
     rows=list(csv.DictReader(open('gpurun_out/%s/pmc_counter_collection.csv'%d)))
     agg=collections.defaultdict(lambda: collections.defaultdict(list)); dur=collections.defaultdict(list)
     for r in rows:
-        m=re.search(r'attn2_(\w+)_kernel<(\d)>',r['Kernel_Name'])
+        m=re.search(r'attn2_(\w+)_kernel<([^>]*)>',r['Kernel_Name'])
         if m:
-            key=m.group(1)+m.group(2)
+            key=m.group(1)+"<"+m.group(2)+">"
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
             dur[key].append(float(r['End_Timestamp'])-float(r['Start_Timestamp']))
     for k,v in agg.items():
