@@ -79,6 +79,8 @@ int w2vs_gemm_tune(int32_t nt_mode, int32_t lc_height, int32_t tn_lc);
  * of the totals (never with fewer than four samples). */
 int w2vs_prof_enable(int stride);
 int w2vs_prof_read(int id, double* total_ms, double* total_flops, int* launches);
+/* the same totals over ALL timed samples (no outlier filter): report both, and the difference in sample counts */
+int w2vs_prof_read_raw(int id, double* total_ms, double* total_flops, int* launches);
 /* every launch of that kernel id since w2vs_prof_enable (the timed ones are a 1-in-stride sample of them), and the algorithmic
  * FLOPs of all of them (scales a sample's time to its whole family when the family mixes shapes) */
 int64_t w2vs_prof_launches(int id);
@@ -89,6 +91,14 @@ int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
  * no partial-tile workspace, no summing launch, no atomics except the optional column sums).  Same result as n calls of
  * w2vs_gemm_tn; falls back to exactly that when the group does not qualify. */
 int w2vs_gemm_tn_group(const w2vs_gemm_desc* descs, int32_t n, int32_t num_cu_hint, void* stream);
+/* The 8-phase form of the grouped launch may split K over workgroup PAIRS that wait for each other's half tile; it does so
+ * only when the whole grid is co-resident (occupancy x CU count of the current device, queried once; num_cu_hint can only
+ * lower the count).  max_split = 1 forbids the pairs altogether - the training step sets it while a gradient all-reduce may
+ * hold CUs beside the backward (wav2vec-s_amd/trainer.py); 2 (the default) allows them.  Returns 0. */
+int w2vs_gemm_tn8_max_split(int32_t max_split);
+/* Which form the LAST w2vs_gemm_tn_group call on this thread's process took (tests): 0 one launch per problem, 12 the
+ * 256x128 single-writer group, 13 the 8-phase 256x256 group without a K split, 14 with the pairwise split. */
+int w2vs_gemm_last_group_form(void);
 
 /* ---- conv layer 0: Conv1d(1->C,k,s) + Fp32LayerNorm(C) + GELU ------------------------------
  * fs/models/wav2vec/wav2vec2.py:733-743, 773-781 (layer 0 of ConvFeatureExtractionModel).

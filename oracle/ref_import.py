@@ -326,6 +326,66 @@ def load_transducer_out():
     return _HEAD
 
 
+_OPTIM = None
+
+
+def load_optim():
+    """The reference's optimizer pieces, executable on the CPU:
+
+    * ``Adam`` - ``fs/optim/adam.py:103-229``, the plain-torch class FairseqAdam falls back to (and that FP16Optimizer drives
+      on the fp32 master copy, fs/optim/fp16_optimizer.py:205-218).  Its MODULE needs omegaconf (an ordinary
+      ModuleNotFoundError), the class itself only torch + math: its source lines are read from the file where it lies and
+      executed unchanged, as ``load_joiner`` does.
+    * ``clip_grad_norm_`` - ``fs/utils.py:341-386``: ``fairseq.utils`` imports as a real module (``load()``).
+    * ``PolynomialDecayLRSchedule`` - ``fs/optim/lr_scheduler/polynomial_decay_schedule.py:40-89``, class source executed
+      unchanged over a minimal ``FairseqLRScheduler`` base (cfg / optimizer / best: what fairseq_lr_scheduler.py:12-19 sets;
+      the real base's module needs omegaconf through ``fairseq.optim``) and an optimizer handle with ``set_lr`` / ``get_lr``.
+    Nothing is copied into the repository."""
+    global _OPTIM
+    if _OPTIM is not None:
+        return _OPTIM
+    ns0 = load()
+    import math
+
+    import torch
+
+    def _lines(path, first_prefix, stop_prefixes):
+        lines = open(path).read().split("\n")
+        start = next(i for i, l in enumerate(lines) if l.startswith(first_prefix))
+        stop = next((i for i in range(start + 1, len(lines)) if any(lines[i].startswith(sp) for sp in stop_prefixes)),
+                    len(lines))
+        return compile("\n" * start + "\n".join(lines[start:stop]), path, "exec")     # keeps the reference's line numbers
+
+    ns = dict(torch=torch, math=math)
+    exec(_lines(os.path.join(FS, "optim", "adam.py"), "class Adam(torch.optim.Optimizer)", ("class ", "def ", "@")), ns)
+
+    class FairseqLRScheduler(object):             # fs/optim/lr_scheduler/fairseq_lr_scheduler.py:12-19
+        def __init__(self, cfg, optimizer):
+            super().__init__()
+            self.cfg = cfg
+            self.optimizer = optimizer
+            self.best = None
+
+    ns2 = dict(FairseqLRScheduler=FairseqLRScheduler, PolynomialDecayLRScheduleConfig=object)   # the annotation only
+    exec(_lines(os.path.join(FS, "optim", "lr_scheduler", "polynomial_decay_schedule.py"),
+                "class PolynomialDecayLRSchedule(", ("class ", "def ", "@")), ns2)
+
+    class LrHandle:                               # FairseqOptimizer.get_lr / set_lr (fs/optim/fairseq_optimizer.py:78-85)
+        def __init__(self, opt):
+            self.opt = opt
+
+        def get_lr(self):
+            return self.opt.param_groups[0]["lr"]
+
+        def set_lr(self, lr):
+            for g in self.opt.param_groups:
+                g["lr"] = lr
+
+    _OPTIM = types.SimpleNamespace(Adam=ns["Adam"], clip_grad_norm_=ns0.utils.clip_grad_norm_,
+                                   PolynomialDecayLRSchedule=ns2["PolynomialDecayLRSchedule"], LrHandle=LrHandle)
+    return _OPTIM
+
+
 def make_cfg(ref, **overrides):
     """Wav2VecSConfig with the base yaml's model overrides
     (fairseq/examples/wav2vec/config/pretraining/wav2vec-S_base_librispeech.yaml:50-77)."""

@@ -218,11 +218,17 @@ def conv_feature_extractor(source: torch.Tensor, P: Dict[str, torch.Tensor], cfg
     return x
 
 
-def encoder_layer(x, P, pre, cfg: OracleCfg, add_mask, collect=None):
+def encoder_layer(x, P, pre, cfg: OracleCfg, add_mask, collect=None, drop=None):
     """TransformerSentenceEncoderLayer.forward, fs/models/wav2vec/wav2vec2.py:921-978,
     with MultiheadAttention's fast path (fs/modules/multihead_attention.py:161-193) spelt
     out: q scaled by head_dim**-0.5, additive mask, softmax, P.V, out_proj.
-    x: N x B x C.  add_mask: B x 1 x N x N additive fp32 (attn mask + key padding)."""
+    x: N x B x C.  add_mask: B x 1 x N x N additive fp32 (attn mask + key padding).
+    ``drop``: injected dropout decisions of a training-mode run, as MULTIPLICATIVE masks (0 or 1/(1-p)):
+    "attn" B x H x N x N on the softmax output (``dropout_p`` of F.multi_head_attention_forward,
+    multihead_attention.py:161-193), "drop1" N x B x C on the attention branch (dropout1, wav2vec2.py:945 / :966),
+    "drop3" N x B x C on the FFN output (dropout3, :953 / :974); dropout2 is ``activation_dropout`` = 0 in
+    the wav2vec-S yamls."""
+    drop = drop or {}
     N, B, C = x.shape
     H = cfg.encoder_attention_heads
     D = C // H
@@ -236,6 +242,8 @@ def encoder_layer(x, P, pre, cfg: OracleCfg, add_mask, collect=None):
         v = lin(t, "self_attn.v_proj").view(N, B, H, D).permute(1, 2, 0, 3)
         s = q @ k.transpose(-1, -2) + add_mask
         p = torch.softmax(s, dim=-1)
+        if "attn" in drop:
+            p = p * drop["attn"]
         o = (p @ v).permute(2, 0, 1, 3).reshape(N, B, C)
         if collect is not None:
             collect[pre + "attn_ctx"] = o
@@ -244,22 +252,27 @@ def encoder_layer(x, P, pre, cfg: OracleCfg, add_mask, collect=None):
     def ln(t, name):
         return F.layer_norm(t, (C,), P[f"{pre}{name}.weight"], P[f"{pre}{name}.bias"], 1e-5)
 
+    d1, d3 = drop.get("drop1", 1.0), drop.get("drop3", 1.0)
     if cfg.layer_norm_first:
-        x = x + attn(ln(x, "self_attn_layer_norm"))
+        x = x + attn(ln(x, "self_attn_layer_norm")) * d1
         h = F.gelu(lin(ln(x, "final_layer_norm"), "fc1").float())
-        x = x + lin(h, "fc2")
+        x = x + lin(h, "fc2") * d3
     else:
-        x = ln(x + attn(x), "self_attn_layer_norm")
+        x = ln(x + attn(x) * d1, "self_attn_layer_norm")
         h = F.gelu(lin(x, "fc1").float())
-        x = ln(x + lin(h, "fc2"), "final_layer_norm")
+        x = ln(x + lin(h, "fc2") * d3, "final_layer_norm")
     return x
 
 
 def blockwise_encoder(x, P, cfg: OracleCfg, main_context: int, right_context: int,
-                      padding_mask=None, layer_keep: Optional[List[bool]] = None, collect=None):
+                      padding_mask=None, layer_keep: Optional[List[bool]] = None, collect=None, drop=None):
     """BlockwiseTransformerEncoder.extract_features + TransformerEncoder.forward,
     fs/models/wav2vec/wav2vec_S.py:355-440, wav2vec2.py:828-834.  x: B x T x C (masked,
-    projected features).  Dropout is the identity here (parity runs use p=0)."""
+    projected features).  Dropout is the identity unless its decisions are injected through ``drop``
+    (multiplicative masks): "encoder" B x T' x C for F.dropout(x, p=self.dropout) of wav2vec_S.py:386 - applied
+    BEFORE gen_block_attn_mask appends the right-context copies, which therefore carry the same decisions -
+    and "layer{i}" -> the dict ``encoder_layer`` takes."""
+    drop = drop or {}
     B, T, C = x.shape
     if padding_mask is not None:
         x = x.masked_fill(padding_mask.unsqueeze(-1), 0.0)
@@ -282,6 +295,8 @@ def blockwise_encoder(x, P, cfg: OracleCfg, main_context: int, right_context: in
         else:
             pad = F.pad(pad, (0, pad_len), value=True)
     Tp = T + pad_len
+    if "encoder" in drop:
+        x = x * drop["encoder"]
     if collect is not None:
         collect["enc_in"] = x
     x = x.transpose(0, 1)  # T' x B x C
@@ -294,7 +309,7 @@ def blockwise_encoder(x, P, cfg: OracleCfg, main_context: int, right_context: in
         pad.view(B, 1, 1, -1), float("-inf"))
     for i in range(cfg.encoder_layers):
         if layer_keep is None or layer_keep[i]:
-            x = encoder_layer(x, P, f"encoder.layers.{i}.", cfg, add, collect)
+            x = encoder_layer(x, P, f"encoder.layers.{i}.", cfg, add, collect, drop.get(f"layer{i}"))
             if collect is not None:
                 collect[f"layer{i}"] = x
     x = x[:Tp].transpose(0, 1)
@@ -380,11 +395,17 @@ def forward_loss(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCf
                  mask_indices: torch.Tensor, neg_idx: torch.Tensor, main_context: int,
                  right_context: int, tau: float = 2.0, gumbel_noise: Optional[torch.Tensor] = None,
                  layer_keep: Optional[List[bool]] = None, collect: Optional[dict] = None,
-                 force_code_idx: Optional[torch.Tensor] = None):
+                 force_code_idx: Optional[torch.Tensor] = None, drop: Optional[dict] = None):
     """Wav2Vec2Model.forward (fs/models/wav2vec/wav2vec2.py:544-658) + criterion, with
     every host-RNG draw INJECTED (mask_indices B x T bool, neg_idx, context sizes,
-    gumbel noise, LayerDrop keeps) and all dropouts off, so that two implementations
-    can be compared on identical draws."""
+    gumbel noise, LayerDrop keeps) so that two implementations can be compared on identical
+    draws.  Dropouts are off unless their decisions are injected too,
+    through ``drop`` (multiplicative masks, 0 or 1/(1-p)): "input" B x T x C on the projected features
+    (dropout_input, wav2vec2.py:570, before apply_mask), "features" B x M x C0 on the quantizer's input
+    (dropout_features, :571 - the reference draws it for all B x T frames and then keeps the masked
+    ones, :590-595; only those decisions matter), and the encoder's own ("encoder", "layer{i}":
+    ``blockwise_encoder``)."""
+    drop = drop or {}
     feats = conv_feature_extractor(source, P, cfg, collect)
     if cfg.feature_grad_mult != 1.0:
         # GradMultiply (fs/modules/grad_multiply.py:9-18): identity fwd, grad * scale
@@ -400,11 +421,15 @@ def forward_loss(P: Dict[str, torch.Tensor], source: torch.Tensor, cfg: OracleCf
     else:
         x = feats
     B, T, C = x.shape
+    if "input" in drop:
+        x = x * drop["input"]
     x = torch.where(mask_indices.unsqueeze(-1), P["mask_emb"].view(1, 1, C).expand(B, T, C), x)
     y = unmasked[mask_indices].view(B, -1, C0)
+    if "features" in drop:
+        y = y * drop["features"]
     if collect is not None:
         collect.update(features=feats, x_masked=x, y_in=y)
-    x = blockwise_encoder(x, P, cfg, main_context, right_context, None, layer_keep, collect)
+    x = blockwise_encoder(x, P, cfg, main_context, right_context, None, layer_keep, collect, drop)
     q, idx, prob_ppl, code_ppl = gumbel_quantize(y, P, cfg, tau, gumbel_noise, force_code_idx)
     yq = F.linear(q, P["project_q.weight"], P["project_q.bias"])
     xm = x[mask_indices].view(B, -1, C)
@@ -435,6 +460,38 @@ def polynomial_decay_lr(num_updates: int, lr: float, warmup_updates: int, total_
 def clip_coef(total_norm: float, max_norm: float) -> float:
     """fs/utils.py:379-383: (max_norm / (total_norm + 1e-6)).clamp_(max=1)."""
     return min(1.0, max_norm / (total_norm + 1e-6)) if max_norm > 0 else 1.0
+
+
+def adam_update(p: torch.Tensor, m: torch.Tensor, v: torch.Tensor, g: torch.Tensor, step: int, lr: float,
+                betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.01):
+    """One step of the reference's plain-torch Adam on fp32 tensors, fs/optim/adam.py:205-229 (decoupled weight decay
+    scaled by lr, eps added to the un-corrected sqrt(v), bias corrections folded into the step size).  ``step`` counts from 1
+    (state["step"] after its increment, :206).  In place; returns (p, m, v)."""
+    b1, b2 = betas
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = v.sqrt().add_(eps)
+    step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    if weight_decay != 0:
+        p.add_(p, alpha=-weight_decay * lr)
+    p.addcdiv_(m, denom, value=-step_size)
+    return p, m, v
+
+
+def optimizer_update(p, m, v, g_sum, sample_size: float, num_updates: int, lr: float, clip_norm: float,
+                     betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.01):
+    """What fs/trainer.py:769-795 does with the summed gradient of an update: multiply_grads(1 / sample_size), the norm of
+    clip_grad_norm_ (fs/utils.py:341-386: returned for clip_norm 0 too; coefficient max_norm / (norm + 1e-6) clamped to 1),
+    no optimizer step when the norm is not finite (:791-793), else Adam with step = num_updates + 1.
+    Returns (gnorm, applied)."""
+    g = g_sum * (1.0 / sample_size)
+    gnorm = float(torch.norm(g, p=2, dtype=torch.float32))
+    if not math.isfinite(gnorm):
+        return gnorm, False
+    if clip_norm > 0:
+        g = g * min(1.0, clip_norm / (gnorm + 1e-6))
+    adam_update(p, m, v, g, num_updates + 1, lr, betas, eps, weight_decay)
+    return gnorm, True
 
 
 def frame_padding_mask(padding_mask: torch.Tensor, T: int) -> torch.Tensor:

@@ -114,7 +114,8 @@ def _same_update(p1, p2, lr, arena, adam=None):
 
 
 @pytest.mark.parametrize("clip,update_freq,keep", [
-    (0.0, 1, None), (0.05, 1, None), (0.05, 2, [True, False, True, True]), (0.0, 2, [True, True, False, True])])
+    (0.0, 1, None), (0.05, 1, None), (0.05, 2, [True, False, True, True]), (0.0, 2, [True, True, False, True]),
+    (0.05, 8, [True, True, False, True])])      # update_freq 8 = BASELINE configs[2] (one exchange + one Adam per 8 micro-batches)
 def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
     """TrainStep with the gradient exchange ACTIVE (world_size-2 code path on a 1-rank RCCL group: every all-reduce is an
     identity) must leave the same arena, the same Adam state and the same parameters as the plain single-GPU step on the
@@ -143,6 +144,7 @@ def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
                 cov[lo:hi] += 1
             assert (cov == 1).all(), "every arena element is reduced exactly once"
             assert len(step.exchange.launched) >= 3
+        assert step.flat.step == 1 and step.micro == 0              # ONE optimizer update closed the update_freq micro-batches
         gn = step.grad_norm() if clip > 0 else None
         res.append((step.flat.arena.flat.clone(), step.flat.p32.clone(), step.flat.m.clone(), step.flat.p16.clone(), gn,
                     step.flat.v.clone()))
@@ -385,4 +387,57 @@ def test_nonfinite_gradient_skips_the_update_and_raises(clip):
             model.inject_draws(mk())
             step({"net_input": {"source": src}})
             torch.cuda.synchronize()
+    ops.ARENA.deactivate()
+
+
+@pytest.mark.parametrize("clip", [25.0, 0.0])
+def test_trainstep_follows_the_reference_optimizer_trajectory(clip):
+    """Row f2 pinned at the level a trainer sees: TrainStep (sample_size division, device-side clip_grad_norm_, polynomial-decay
+    schedule, fused Adam, the skip of a non-finite update and its report) against tests/golden/optim.npz, the trajectory
+    recorded from the reference's own Adam / clip_grad_norm_ / PolynomialDecayLRSchedule in fs/trainer.py's order
+    (tests/golden/gen_golden_optim.py).  The model's backward runs as usual; right before the norm / Adam launches the first n
+    arena elements are overwritten with the recorded summed gradient (rescaled by this batch's sample_size over the recorded
+    one, so that the normalised gradient is the recorded one) and the rest is zeroed; the first n master elements start from
+    the recorded parameters."""
+    from conftest import GOLDEN
+    from wav2vec_s_amd import trainer, ops
+    fx = np.load(os.path.join(GOLDEN, "optim.npz"))
+    tag = "clip%d" % int(clip)
+    b1, b2, eps, wd, lr0, warmup, total = [float(x) for x in fx["hyper"]]
+    n = int(fx["n"])
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    w, cfg, model, crit = _build(SMALL)
+    sched = trainer.PolynomialDecayLRSchedule([lr0], warmup_updates=int(warmup), total_num_update=total)
+    step = trainer.TrainStep(model, crit, lr=lr0, betas=(b1, b2), eps=eps, weight_decay=wd, clip_norm=clip, arena_gib=1.0,
+                             lr_scheduler=sched)
+    f = step.flat
+    assert f.arena.numel > n
+    f.p32[:n] = torch.from_numpy(fx["p0"].copy()).cuda()
+    mk = _draws(cfg, B, L)
+    cur = {}
+
+    def plant(ts):
+        ts.flat.arena.flat.zero_()
+        ts.flat.arena.flat[:n] = torch.from_numpy(fx["grads"][cur["u"]].copy()).cuda() * (float(ts.ss_acc) / float(fx["sample_size"][cur["u"]]))
+    step._before_optimizer = plant
+    raised = []
+    for u in range(fx["grads"].shape[0]):
+        cur["u"] = u
+        model.inject_draws(mk())
+        step({"net_input": {"source": src}})
+        try:
+            step.check()
+        except FloatingPointError:
+            raised.append(u)
+        assert step.last_lr == pytest.approx(float(fx[tag + ".lr"][u]), rel=1e-12, abs=1e-18), u
+        assert f.step == int(fx[tag + ".num_updates"][u]), u           # a skipped update is taken back out of the count
+        if u not in raised:
+            assert abs(step.grad_norm() - float(fx[tag + ".gnorm"][u])) <= 1e-5 * float(fx[tag + ".gnorm"][u]), u
+        for name, t in (("p32", f.p32), ("m", f.m), ("v", f.v)):
+            want = torch.from_numpy(fx[f"{tag}.{name}"][u]).cuda()
+            assert float((t[:n] - want).abs().max()) <= 5e-6 * float(want.abs().max()) + 1e-12, (u, name)
+        assert torch.equal(f.p16[:n], f.p32[:n].to(BF))
+    assert raised == [3]                                               # reported once, for the Inf update only
+    step.check()                                                       # and not again
     ops.ARENA.deactivate()

@@ -1,6 +1,7 @@
 """Per-kernel parity: every C-ABI entry of libw2vs against the CPU oracle / fp32 torch math on
 the same seeded inputs.  Needs a real MI355X:  pytest -m gpu"""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -562,6 +563,47 @@ def test_fused_adam_matches_fairseq_formula(ops):
     assert abs(float(out) - float((grad ** 2).sum())) / float((grad ** 2).sum()) < 1e-5
 
 
+@pytest.mark.parametrize("clip", [25.0, 0.0])
+def test_adam_clip_kernels_follow_the_reference_trajectory(ops, clip):
+    """Row f2 pinned: w2vs_sumsq + w2vs_clip_scale_acc + w2vs_adam_step against tests/golden/optim.npz, the trajectory recorded
+    from the reference's own Adam (fs/optim/adam.py:103-229), clip_grad_norm_ (fs/utils.py:341-386) and polynomial-decay
+    schedule under fs/trainer.py's sequencing (tests/golden/gen_golden_optim.py): 7 updates over warm-up, decay and the floor,
+    two of them clipped (clip 25), one with an Inf gradient that must leave master, moments and bf16 image untouched."""
+    from conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "optim.npz"))
+    tag = "clip%d" % int(clip)
+    b1, b2, eps, wd = [float(x) for x in fx["hyper"][:4]]
+    n = int(fx["n"])
+    p32 = torch.from_numpy(fx["p0"].copy()).cuda()
+    p16, m, v = p32.to(BF), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    norm_buf, out3, bad = torch.zeros(1).cuda(), torch.zeros(3).cuda(), torch.zeros(1).cuda()
+    num_updates, n_skipped = 0, 0
+    for u in range(fx["grads"].shape[0]):
+        g = torch.from_numpy(fx["grads"][u].copy()).cuda()
+        before = [t.clone() for t in (p32, p16, m, v)]
+        ops.sumsq(g, norm_buf)
+        ops.clip_scale_acc(norm_buf, out3, bad, scale_host=1.0 / float(fx["sample_size"][u]), clip=clip)
+        assert float(norm_buf) == 0.0                                   # consumed: ready for the next update
+        ops.adam_step(p32, p16, m, v, g, lr=float(fx[tag + ".lr"][u]), beta1=b1, beta2=b2, eps=eps, weight_decay=wd,
+                      step=num_updates + 1, scale_host=1.0, scale_dev=out3[0:1])
+        if bool(fx[tag + ".skipped"][u]):
+            n_skipped += 1
+            assert float(out3[2]) == 1.0 and float(out3[0]) == 0.0 and not np.isfinite(float(out3[1]))
+            for a, b in zip(before, (p32, p16, m, v)):
+                assert torch.equal(a, b)
+        else:
+            num_updates += 1
+            assert float(out3[2]) == 0.0
+            assert abs(float(out3[1]) - float(fx[tag + ".gnorm"][u])) <= 2e-6 * float(fx[tag + ".gnorm"][u]), u
+        assert num_updates == int(fx[tag + ".num_updates"][u])
+        assert float(bad) == n_skipped
+        for name, t in (("p32", p32), ("m", m), ("v", v)):
+            want = torch.from_numpy(fx[f"{tag}.{name}"][u]).cuda()
+            assert float((t - want).abs().max()) <= 3e-6 * float(want.abs().max()) + 1e-12, (u, name)
+        assert torch.equal(p16, p32.to(BF))                              # _sync_fp32_params_to_fp16 (fp16_optimizer.py:218)
+    assert n_skipped == 1 and num_updates == 6
+
+
 def test_transpose_multi(ops):
     shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (40, 24), (65, 130)]
     xs = [dev(rnd(r, c, seed=20 + i)) for i, (r, c) in enumerate(shapes)]
@@ -711,6 +753,40 @@ def test_gemm_tn_group_equals_single_launches():
     w3, b3 = targets()
     ops.gemm_tn_group([dict(a=dys[2], b=xs[2], out_f32=w3[2], M=E, N=E, K=R, lda=E, ldb=E, ldc=E, alpha=0.5, colsum_out=b3[2])])
     assert torch.equal(w3[2], w1[2]) and rel(b3[2], b1[2]) < 1e-5     # the column sums arrive through atomics: order varies
+
+
+def test_gemm_tn_group_pair_split_needs_co_residency():
+    """The 8-phase grouped launch splits K over workgroup PAIRS that wait on each other's flag: that form (14) is taken only
+    when the whole grid is co-resident on THIS device (queried occupancy x CU count; a hint can only lower it) and the caller
+    has not forbidden it (w2vs_gemm_tn8_max_split(1): what the training step sets while an all-reduce may hold CUs).  Every
+    fallback computes the same sums."""
+    from wav2vec_s_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    R, E, F = 5584, 768, 3072
+    mk = lambda r, c: (torch.randn(r, c, generator=g) * 0.5).to(BF).cuda()      # noqa: E731
+    dys = [mk(R, E), mk(R, F), mk(R, E), mk(R, 3 * E)]
+    xs = [mk(R, F), mk(R, E), mk(R, E), mk(R, E)]
+
+    def run(num_cu, max_split):
+        lib.w2vs_gemm_tn8_max_split(max_split)
+        try:
+            ws = [torch.zeros(dy.shape[1], x.shape[1], device="cuda") for dy, x in zip(dys, xs)]
+            bs = [torch.zeros(dy.shape[1], device="cuda") for dy in dys]
+            ops.gemm_tn_group([dict(a=dy, b=x, out_f32=w, M=dy.shape[1], N=x.shape[1], K=R, lda=dy.shape[1], ldb=x.shape[1],
+                                    ldc=x.shape[1], colsum_out=b) for dy, x, w, b in zip(dys, xs, ws, bs)], num_cu=num_cu)
+            torch.cuda.synchronize()
+            return lib.w2vs_gemm_last_group_form(), ws, bs
+        finally:
+            lib.w2vs_gemm_tn8_max_split(2)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    form, w0, b0 = run(cus, 2)
+    assert form == 14 if cus >= 216 else form != 14            # 108 tiles of 256^2 x 2: needs 216 co-resident workgroups
+    for num_cu, max_split, forms in ((cus, 1, (0, 12)), (215, 2, (0, 12)), (100, 2, (0,)), (1 << 20, 2, (form,))):
+        f_, w_, b_ = run(num_cu, max_split)
+        assert f_ in forms, (num_cu, max_split, f_)
+        for a, b in zip(w0 + b0, w_ + b_):
+            assert rel(b, a) < 2e-5, (num_cu, max_split, rel(b, a))
 
 
 def test_group_attention_beyond_one_record_table(ops):

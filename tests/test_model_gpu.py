@@ -24,7 +24,7 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-def _setup(cfg_kw, B, L, seed, m_ctx, r_ctx, train=True):
+def _setup(cfg_kw, B, L, seed, m_ctx, r_ctx, train=True, keep=None):
     import wav2vec_s_amd as w
     from wav2vec_s_amd import engine, host_rng
     cfg = w.Wav2VecSConfig(**cfg_kw)
@@ -48,8 +48,8 @@ def _setup(cfg_kw, B, L, seed, m_ctx, r_ctx, train=True):
     neg = host_rng.sample_negative_indices(B, M, cfg.num_negatives)
     G, V = cfg.latent_groups, cfg.latent_vars
     noise = -torch.empty(B * M * G, V).exponential_(generator=g).log() if train else None
-    draws = engine.Draws(mask_indices=mask, neg_idx=neg, context=(m_ctx, r_ctx), layer_keep=[True] * cfg.encoder_layers,
-                         gumbel_noise=noise)
+    draws = engine.Draws(mask_indices=mask, neg_idx=neg, context=(m_ctx, r_ctx),
+                         layer_keep=list(keep) if keep is not None else [True] * cfg.encoder_layers, gumbel_noise=noise)
     return w, model, P, ocfg, source, draws, mask, neg, noise
 
 
@@ -83,8 +83,80 @@ GRAD_BARS = {"enc_misc": 0.045, "extractor_conv": 0.08, "extractor_norm": 0.055,
              "enc_weight": 0.055, "enc_bias": 0.06, "enc_ln": 0.045, "feature_ln": 0.11}
 
 
-def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
-    w, model, P, ocfg, source, draws, mask, neg, noise = _setup(cfg_kw, B, L, seed, m_ctx, r_ctx)
+def _inv_keep(p):
+    """The kernels' effective keep scale: 16-bit threshold of common.h's make_drop (p_eff = floor(p * 65536) / 65536)."""
+    thr16 = int(float(np.float32(p)) * 4294967296.0) >> 16
+    return 65536.0 / (65536.0 - thr16)
+
+
+def _row_keep(ops, rows, C, p, seed):
+    """Multiplicative mask [rows, C] (0 or 1/(1-p_eff)) of a row-dropout site: the decisions of w2vs_dropout on ones with the
+    site's seed - the same (seed, element index / 8) words every row kernel (LayerNorm family, encoder prologue) hashes."""
+    ones = torch.ones(rows, C, device="cuda", dtype=BF)
+    return (ops.dropout(ones, p, seed).float() > 0).float().cpu() * _inv_keep(p)
+
+
+_KR = [(i & 3) + 8 * (i >> 2) + 4 * w_ for i in range(16) for w_ in range(2)]     # key row of dword 2i + w (attn_common.h)
+
+
+def _attn_keep(ops, B, H, N, Tp, m, r, p, seed):
+    """Multiplicative mask [B, H, N, N] of a layer's attention dropout: the forward kernel parks its keep decisions as bits
+    (w2vs_attn_desc.drop_bits; test_attention_stored_keep_masks_equal_rehash shows they ARE the hashed decisions of the
+    plain launch) - decoded here.  Blocks no query can see are never written and stay 'keep' (their probabilities are 0)."""
+    qkv = torch.zeros(B, N, 3 * H * 64, device="cuda", dtype=BF)
+    bits = ops.attn_drop_bits(B, H, N)
+    bits.fill_(-1)
+    ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=seed, drop_bits=bits)
+    nT = (N + 31) // 32
+    w = bits.view(B * H, nT, nT, 32).long() & 0xFFFFFFFF
+    qb = (w.unsqueeze(-1) >> torch.arange(32, device="cuda")) & 1                  # [BH, qt, kt, dword, query bit]
+    inv = torch.empty(32, dtype=torch.long)
+    inv[torch.tensor(_KR)] = torch.arange(32)
+    qb = qb.index_select(3, inv.cuda())                                            # [BH, qt, kt, key row, query]
+    keep = qb.permute(0, 1, 4, 2, 3).reshape(B * H, nT * 32, nT * 32)[:, :N, :N]
+    return (keep.view(B, H, N, N).float() * _inv_keep(p)).cpu()
+
+
+def _drop_masks(st, cfg):
+    """Every dropout decision the HIP step made, as the multiplicative masks oracle.forward_loss(drop=...) takes."""
+    from wav2vec_s_amd import ops
+    p_in, p_feat, p_enc, p_att = st.p
+    B, T, Tp, N, E, C0 = st.B, st.T, st.Tp, st.N, cfg.encoder_embed_dim, st.C0
+    out = {}
+    if p_in > 0:
+        out["input"] = _row_keep(ops, B * T, E, p_in, st.seed(1)).view(B, T, E)
+    if p_feat > 0:
+        out["features"] = _row_keep(ops, B * st.M, C0, p_feat, st.seed(3)).view(B, st.M, C0)
+    if p_enc > 0:
+        enc = torch.ones(B, Tp, E)
+        enc[:, :T] = _row_keep(ops, B * T, E, p_enc, st.seed(2)).view(B, T, E)      # keyed by source frame b*T + t
+        out["encoder"] = enc
+    tok = st.token_idx.cpu().long() if hasattr(st, "token_idx") else None
+    for j, rec in enumerate(st.layers):
+        li = rec["li"]
+        d = {}
+        if p_att > 0:
+            d["attn"] = _attn_keep(ops, B, cfg.encoder_attention_heads, N, Tp, st.m, st.r, p_att, st.seed(100 + 4 * li))
+        if p_enc > 0:
+            for key, site in (("drop1", 101), ("drop3", 102)):
+                if rec["desc"].sel_idx:      # the last layer ran on the masked rows only: its row dropout is keyed by THEIR index
+                    full = torch.ones(B * N, E)
+                    full[tok] = _row_keep(ops, tok.numel(), E, p_enc, st.seed(site + 4 * li))
+                else:
+                    full = _row_keep(ops, B * N, E, p_enc, st.seed(site + 4 * li))
+                d[key] = full.view(B, N, E).transpose(0, 1)                            # oracle layers run N x B x C
+        out[f"layer{li}"] = d
+    return out
+
+
+# Direction / length bars next to the Frobenius ones (round 4): cosine >= 0.998 for every family but the two
+# cancellation-dominated ones (6 % orthogonal noise is a cosine of 0.9982 by itself), length within 2 %.
+COS_GAP = {"quant_proj": 0.003, "feature_ln": 0.003}
+NORM_DEV = 0.02
+
+
+def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag, keep=None):
+    w, model, P, ocfg, source, draws, mask, neg, noise = _setup(cfg_kw, B, L, seed, m_ctx, r_ctx, keep=keep)
     ocfg.loss_weights = tuple(loss_weights)
     model = model.cuda().train()
     model.inject_draws(draws)
@@ -92,17 +164,21 @@ def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
     loss, sample_size, log = crit(model, {"net_input": {"source": source.cuda()}})
     loss.backward()
     st = model._last_state
+    # dropouts on (the bench's configuration): the decisions the kernels made are read back and injected into the oracle
+    okw = dict(layer_keep=draws.layer_keep)
+    if any(p_ > 0 for p_ in st.p):
+        okw["drop"] = _drop_masks(st, model.cfg)
     # The code SELECTION is an argmax.  The HIP logits are fp32 sums (W2VS_EPI_F32), but their INPUT - the conv stack's
     # features - is bf16, so a near-tie of two codes can still flip against the fp32 oracle.  Two oracle runs:
     #  (1) un-pinned, forward only: its own argmax everywhere -> loss_unpinned (what a user of the CPU reference sees);
     #  (2) with the HIP selection pinned, forward + backward: everything downstream of the discrete choice comparable.
     with torch.no_grad():
         free = O.forward_loss({k: v.detach() for k, v in P.items()}, source.float(), ocfg, mask_indices=torch.from_numpy(mask),
-                              neg_idx=neg, main_context=m_ctx, right_context=r_ctx, tau=2.0, gumbel_noise=noise)
+                              neg_idx=neg, main_context=m_ctx, right_context=r_ctx, tau=2.0, gumbel_noise=noise, **okw)
     col = {}
     ref = O.forward_loss(P, source.float(), ocfg, mask_indices=torch.from_numpy(mask), neg_idx=neg, main_context=m_ctx,
                          right_context=r_ctx, tau=2.0, gumbel_noise=noise, collect=col,
-                         force_code_idx=st.qst.idx.cpu())
+                         force_code_idx=st.qst.idx.cpu(), **okw)
     ref["loss"].backward()
     rep = {"tag": tag, "loss_hip": float(loss), "loss_ref": float(ref["loss"]), "sample_size": sample_size}
     rep["loss_rel"] = abs(rep["loss_hip"] - rep["loss_ref"]) / abs(rep["loss_ref"])
@@ -138,7 +214,7 @@ def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
     rep["features_pen_rel"] = abs(float(st.pen_acc) / (B_ * T * st.C0) - float(ref["features_pen"])) / float(ref["features_pen"])
     rep["prob_ppl_rel"] = abs(float(st.qst.ppl[0]) - float(ref["prob_perplexity"])) / float(ref["prob_perplexity"])
     rep["correct"] = (log["correct"], ref["correct"])
-    grads = {}
+    grads, cos_by, ratio_by = {}, {}, {}
     for n, p in model.named_parameters():
         want = P[n].grad
         if want is None:
@@ -146,6 +222,14 @@ def _run_both(cfg_kw, B, L, seed, m_ctx, r_ctx, loss_weights, tag):
             continue
         assert p.grad is not None, n
         grads[n] = rel(p.grad, want) if float(want.norm()) > 1e-6 else float(p.grad.float().norm())
+        if float(want.norm()) > 1e-6 and "k_proj.bias" not in n:
+            # direction and length separately: a relative Frobenius error alone cannot tell rounding noise (orthogonal, cosine
+            # 1 - e^2/2, length unchanged) from a systematic scale error (cosine 1, length off by e)
+            g_, w_ = p.grad.detach().double().cpu().reshape(-1), want.double().reshape(-1)
+            fam = _grad_group(n)
+            cos_by[fam] = min(cos_by.get(fam, 1.0), float(g_ @ w_ / (g_.norm() * w_.norm())))
+            ratio_by[fam] = max(ratio_by.get(fam, 0.0), abs(float(g_.norm() / w_.norm()) - 1.0))
+    rep["grad_cos_by_group"], rep["grad_norm_ratio_dev_by_group"] = cos_by, ratio_by
     rep["grad_worst"] = sorted(grads.items(), key=lambda kv: -kv[1])[:8]
     by = {}
     for n, e in grads.items():
@@ -168,6 +252,32 @@ def test_base_model_step_matches_oracle():
     assert rep["logits_maxabs"] < 0.08, rep        # logits are cos/0.1 in [-10, 10]; measured 0.022
 
 
+YAML_DROP = dict(dropout=0.1, attention_dropout=0.1, dropout_input=0.1, dropout_features=0.1)   # wav2vec-S_base_librispeech.yaml:50-77
+
+
+def test_base_model_step_with_dropouts_and_layerdrop_matches_oracle():
+    """The configuration the bench times - the yaml's four dropouts at 0.1 and a LayerDrop-ped layer - end to end against the
+    oracle: the keep decisions of every site (dropout_input / dropout_features / encoder dropout, per layer the attention
+    dropout and dropout1 / dropout3: wav2vec2.py:570-571, 945-976, wav2vec_S.py:386, multihead_attention.py:161-193) are
+    read back from the kernels and injected into ``forward_loss(drop=...)``, whose injection semantics are pinned against the
+    reference in tests/test_oracle_vs_reference.py.  Same bars as the dropout-free runs."""
+    keep = [True] * 12
+    keep[5] = False
+    rep, grads = _run_both(dict(BASE, **YAML_DROP), B=2, L=24000, seed=21, m_ctx=16, r_ctx=8, loss_weights=(0.1, 10.0),
+                           tag="base_dropouts", keep=keep)
+    _assert_parity(rep, grads, loss_free=1e-3)
+
+
+def test_cfgB_step_with_dropouts_and_layerdrop_matches_oracle():
+    """The same at BASELINE configs[1], the bench batch (8 x 175 000, R = 6 544): dropouts 0.1, layers 3 and 8 dropped,
+    a sampled-style context (24, 12) instead of the constant (16, 8)."""
+    keep = [True] * 12
+    keep[3] = keep[8] = False
+    rep, grads = _run_both(dict(BASE, **YAML_DROP), B=8, L=175000, seed=22, m_ctx=24, r_ctx=12, loss_weights=(0.1, 10.0),
+                           tag="cfgB_dropouts", keep=keep)
+    _assert_parity(rep, grads, loss_free=1e-3)
+
+
 def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, bar_scale=1.0, median=3e-2):
     assert rep["loss_rel"] < loss, rep
     if loss_free is not None:
@@ -182,6 +292,12 @@ def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, bar_scale
     assert not rep["grad_nonfinite"], rep["grad_nonfinite"]
     over = {g: e for g, e in rep["grad_by_group"].items() if not e <= GRAD_BARS[g] * bar_scale}
     assert not over, (over, rep["grad_worst"])
+    # per family: worst cosine >= 1 - COS_GAP (x bar_scale^2: the gap of orthogonal noise grows with its square) and worst
+    # | ||g_hip|| / ||g_ref|| - 1 | <= NORM_DEV - a 5 % scale error in a 6 %-noise family passes the Frobenius bar, not these
+    low = {g: c for g, c in rep["grad_cos_by_group"].items() if not c >= 1.0 - COS_GAP.get(g, 0.002) * bar_scale ** 2}
+    assert not low, (low, rep["grad_worst"])
+    off = {g: d for g, d in rep["grad_norm_ratio_dev_by_group"].items() if not d <= NORM_DEV * bar_scale}
+    assert not off, (off, rep["grad_worst"])
     assert rep["grad_median"] < median, rep
 
 

@@ -68,3 +68,83 @@ def test_flat_params_master_sync_and_state_dict_cpu():
     flat3 = trainer.FlatParams(w.Wav2VecSModel(w.Wav2VecSConfig(**kw3)).to(torch.bfloat16))
     with pytest.raises(ValueError):
         flat3.load_state_dict(osd)
+
+
+# ------------------------------------------------------------------ row f2 pinned to the reference (tests/golden/optim.npz)
+def _optim_fixture():
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "optim.npz"))
+
+
+def _replay(fx, tag, clip, update_fn):
+    """Replays the recorded trainer sequence with ``update_fn(p, m, v, g_sum, ss, num_updates, lr) -> (gnorm, applied)`` and the
+    product's own PolynomialDecayLRSchedule; returns the per-update records."""
+    from wav2vec_s_amd.trainer import PolynomialDecayLRSchedule
+    b1, b2, eps, wd, lr0, warmup, total = [float(x) for x in fx["hyper"]]
+    sched = PolynomialDecayLRSchedule([lr0], warmup_updates=int(warmup), total_num_update=total)
+    p = torch.from_numpy(fx["p0"].copy())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    num_updates, out = 0, []
+    for u in range(fx["grads"].shape[0]):
+        lr = sched.step_update(num_updates)           # the rate of the update that follows num_updates completed ones
+        gnorm, applied = update_fn(p, m, v, torch.from_numpy(fx["grads"][u].copy()), float(fx["sample_size"][u]), num_updates, lr)
+        num_updates += int(applied)
+        out.append((lr, gnorm, p.clone(), m.clone(), v.clone(), not applied, num_updates))
+    return out
+
+
+@pytest.mark.parametrize("clip", [25.0, 0.0])
+def test_oracle_optimizer_matches_reference_trajectory(clip):
+    """oracle.optimizer_update / adam_update and the product's LR schedule against the trajectory recorded from the
+    reference's own Adam (fs/optim/adam.py:103-229), clip_grad_norm_ (fs/utils.py:341-386) and PolynomialDecayLRSchedule
+    (polynomial_decay_schedule.py:40-89): warm-up, decay, the floor, two clipped updates, one non-finite (skipped) update."""
+    fx = _optim_fixture()
+    tag = "clip%d" % int(clip)
+    b1, b2, eps, wd = [float(x) for x in fx["hyper"][:4]]
+    rec = _replay(fx, tag, clip, lambda p, m, v, g, ss, nu, lr: O.optimizer_update(p, m, v, g, ss, nu, lr, clip, (b1, b2), eps, wd))
+    assert [r[5] for r in rec] == [bool(x) for x in fx[tag + ".skipped"]] == [False, False, False, True, False, False, False]
+    assert [r[6] for r in rec] == [int(x) for x in fx[tag + ".num_updates"]]
+    for u, (lr, gnorm, p, m, v, skipped, _) in enumerate(rec):
+        assert lr == pytest.approx(float(fx[tag + ".lr"][u]), rel=1e-12, abs=1e-18), u
+        if skipped:
+            assert not np.isfinite(gnorm) and not np.isfinite(fx[tag + ".gnorm"][u])
+        else:
+            assert gnorm == pytest.approx(float(fx[tag + ".gnorm"][u]), rel=1e-6), u
+        for name, t in (("p32", p), ("m", m), ("v", v)):
+            want = torch.from_numpy(fx[f"{tag}.{name}"][u])
+            assert float((t - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-12, (u, name)
+    # clip 25 bit on updates 2 and 6 only; the clipped trajectories differ from the unclipped ones from update 2 on
+    g = fx["clip25.gnorm"]
+    assert g[1] > 25 and g[5] > 25 and all(x < 25 for i, x in enumerate(g) if i not in (1, 3, 5))
+    assert not np.allclose(fx["clip25.p32"][2], fx["clip0.p32"][2])
+
+
+def test_oracle_optimizer_matches_reference_live():
+    """The same comparison against the reference classes executed here (container only)."""
+    import ref_import
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    import types
+    R = ref_import.load_optim()
+    g = torch.Generator().manual_seed(3)
+    p_ref = torch.nn.Parameter(torch.randn(515, generator=g) * 0.2)
+    p = p_ref.detach().clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    opt = R.Adam([p_ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01)
+    cfg = types.SimpleNamespace(warmup_updates=3, total_num_update=9.0, end_learning_rate=1e-5, power=2.0, lr=[1e-3], force_anneal=None)
+    sched = R.PolynomialDecayLRSchedule(cfg, R.LrHandle(opt))
+    sched.step_update(0)
+    for u in range(10):
+        gs = torch.randn(515, generator=g) * (3000.0 if u % 3 == 1 else 20.0)
+        ss = 100.0 + u
+        lr = opt.param_groups[0]["lr"]
+        assert lr == pytest.approx(O.polynomial_decay_lr(u, 1e-3, 3, 9.0, 1e-5, 2.0), rel=1e-12, abs=1e-18)
+        p_ref.grad = gs * (1.0 / ss)
+        gn_ref = float(R.clip_grad_norm_([p_ref], 10.0))
+        opt.step()
+        sched.step_update(u + 1)
+        gn, applied = O.optimizer_update(p, m, v, gs, ss, u, lr, 10.0)
+        assert applied and gn == pytest.approx(gn_ref, rel=1e-6)
+        assert float((p - p_ref.detach()).abs().max()) <= 1e-6
+        assert float((m - opt.state[p_ref]["exp_avg"]).abs().max()) <= 1e-6 * float(m.abs().max())

@@ -104,6 +104,7 @@ _SIGS = {
     "w2vs_gemm_tn_group": [vp, i32, i32, vp],
     "w2vs_prof_enable": [i32],
     "w2vs_prof_read": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)],
+    "w2vs_prof_read_raw": [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)],
     "w2vs_prof_launches": [i32],          # returns a count, not a status (read through load(), not call())
     "w2vs_prof_flops": [i32],             # returns a double (read through load(), restype set there)
     "w2vs_conv0_fwd": [vp] * 8 + [i32] * 5 + [vp],
@@ -128,6 +129,8 @@ _SIGS = {
     "w2vs_infonce_loss_bwd": [vp, vp, i64, f32, f32, vp, vp],
     "w2vs_gather_rows": [vp, vp, vp, i64, i32, i32, vp],
     "w2vs_gemm_tune": [i32, i32, i32],
+    "w2vs_gemm_tn8_max_split": [i32],
+    "w2vs_gemm_last_group_form": [],
     "w2vs_attn_tune": [i32],
     "w2vs_attn_drop_bits_bytes": [i32, i32, i32, i32],     # returns a byte count (read through load())
     "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],

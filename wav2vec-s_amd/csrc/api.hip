@@ -37,6 +37,7 @@ int w2vs_sizeof(int which) {
 }
 int w2vs_prof_enable(int stride) { prof_enable(stride); return 0; }
 int w2vs_prof_read(int id, double* ms, double* flops, int* n) { return prof_read(id, ms, flops, n); }
+int w2vs_prof_read_raw(int id, double* ms, double* fl, int* n) { return prof_read_raw(id, ms, fl, n); }
 int64_t w2vs_prof_launches(int id) { return prof_launches(id); }
 double w2vs_prof_flops(int id) { return prof_flops_all(id); }
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* s) { NONNULL(d); return gemm_nt(*d, ST(s)); }
@@ -83,6 +84,8 @@ int w2vs_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t R, 
 }
 int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t batch, void* s) { return transpose2d(in, out, R, C, batch, ST(s)); }
 int w2vs_gemm_tune(int32_t nt_mode, int32_t lc_height, int32_t tn_lc) { gemm_tune(nt_mode, lc_height, tn_lc); return 0; }
+int w2vs_gemm_tn8_max_split(int32_t s) { gemm_tn8_max_split(s); return 0; }
+int w2vs_gemm_last_group_form(void) { return gemm_last_group_form(); }
 int w2vs_attn_tune(int32_t variant) { attn_tune(variant); return 0; }
 int64_t w2vs_attn_drop_bits_bytes(int32_t B, int32_t H, int32_t N, int32_t Nq) {
   const int64_t nq = ((Nq > 0 ? Nq : N) + 31) / 32, nk = (N + 31) / 32;

@@ -1473,7 +1473,11 @@ __global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
   const uint32_t a_j = (uint32_t)(32 * p.lda * 2), b_j = (uint32_t)(32 * p.ldb * 2);      // piece j = 1: 32 rows further
   const uint32_t a_kt = (uint32_t)(TK * p.lda * 2), b_kt = (uint32_t)(TK * p.ldb * 2);    // next K tile
   int kt_s = 0;
+#ifdef W2VS_ABLATION
   const bool live = !(g.dbg & 1);                 // dbg bit 0: every DMA out of range (zero fill, no memory traffic)
+#else
+  constexpr bool live = true;
+#endif
   bool ok_cur = nk > 0 && live, ok_prev = false;
   uint32_t a_cur = a_thr, b_cur = b_thr, a_prev = 0;
   auto advance = [&]() {
@@ -1548,7 +1552,9 @@ __global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
   auto mfma_q = [&](int mh, int nh, bf16x8 (&bb)[2][2], bool with_cs) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this phase's (inline-asm) fragment reads
     __builtin_amdgcn_sched_barrier(0);                     // ... and no MFMA may move above the wait
+#ifdef W2VS_ABLATION
     if (g.dbg & 2) return;                                 // dbg bit 1: no MFMAs
+#endif
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -1742,7 +1748,11 @@ double prof_flops_all(int id) { return (id >= 0 && id < 64) ? g_prof_flops_all[i
 // Totals over the timed samples of a family.  An event pair also times any gap in which the stream waited for the HOST to
 // enqueue the launch (a late launch thread: one 0.8 ms sample among seven once made a 45 us kernel look like 150 us), so samples
 // whose time per FLOP exceeds 3 x the family's median are left out - with fewer than four samples nothing is.
-int prof_read(int id, double* total_ms, double* total_flops, int* launches) {
+static int prof_read_impl(int id, bool filter, double* total_ms, double* total_flops, int* launches);
+int prof_read(int id, double* total_ms, double* total_flops, int* launches) { return prof_read_impl(id, true, total_ms, total_flops, launches); }
+// the same totals with NOTHING left out (bench.py prints both and the number of samples the filter dropped)
+int prof_read_raw(int id, double* total_ms, double* total_flops, int* launches) { return prof_read_impl(id, false, total_ms, total_flops, launches); }
+static int prof_read_impl(int id, bool filter, double* total_ms, double* total_flops, int* launches) {
   std::vector<std::pair<double, double>> v;      // (ms, flops)
   for (auto& s : g_prof) {
     if (s.id != id) continue;
@@ -1752,7 +1762,7 @@ int prof_read(int id, double* total_ms, double* total_flops, int* launches) {
     v.emplace_back((double)t, s.flops);
   }
   double cut = 1e300;
-  if (v.size() >= 4) {
+  if (filter && v.size() >= 4) {
     std::vector<double> r;
     for (auto& x : v) r.push_back(x.first / std::max(x.second, 1.0));
     std::nth_element(r.begin(), r.begin() + r.size() / 2, r.end());
@@ -2005,11 +2015,40 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   return hip_check(hipGetLastError(), "gemm_tn launch");
 }
 
+// What the device can hold, asked once per device: CU count and how many gemm_tn8_group_kernel workgroups can be resident
+// at once.  The S = 2 form of that kernel makes the two workgroups of a pair wait on each other's flag: it is only launched
+// when EVERY workgroup of the grid fits on the chip together (and never while something else - the gradient all-reduce - may
+// hold CUs: gemm_tn8_max_split, set by the training step when an exchange is active).
+struct DevFacts { int cus = 0; int tn8_resident = 0; unsigned* flags = nullptr; int next = 0; };
+static DevFacts* dev_facts() {
+  static DevFacts facts[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  DevFacts& f = facts[dev];
+  if (f.cus == 0) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return nullptr;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_tn8_group_kernel, 512, 0) != hipSuccess) per_cu = 0;
+    f.tn8_resident = per_cu * pr.multiProcessorCount;
+    f.cus = pr.multiProcessorCount;
+  }
+  return &f;
+}
+static int g_tn8_max_split = 2;
+static int g_last_group_form = 0;      // 0: one launch per problem, 12: 256x128 single-writer group, 13: 8-phase S = 1, 14: 8-phase S = 2
+void gemm_tn8_max_split(int s) { g_tn8_max_split = s < 1 ? 1 : (s > 2 ? 2 : s); }
+int gemm_last_group_form() { return g_last_group_form; }
+
 // n <= 4 weight-gradient GEMMs in one launch (see gemm_tn_group_kernel).  Falls back to one gemm_tn per problem when the
 // group does not qualify (alignment, batching, more tiles than CUs, tiny K).
 int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
   if (!ds || n < 1 || n > 8) return set_error("gemm_tn_group: 1..8 problems");
-  const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
+  DevFacts* df = dev_facts();
+  if (!df) return set_error("gemm_tn_group: cannot query the device");
+  // the caller's hint can only LOWER the count (tests, a partitioned device); the real CU count caps it
+  const int ncu = std::min(num_cu_hint > 0 ? num_cu_hint : df->cus, df->cus);
+  g_last_group_form = 0;
   if (n > 4) {
     // more than four problems (two layers' weight gradients): only the 8-phase kernel takes them as ONE launch, and only when
     // their 256^2 tiles fit one workgroup per CU WITHOUT a K split; otherwise two groups, as before
@@ -2061,25 +2100,29 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
     for (int i = n; i <= 8; ++i) g8.first[i] = t8;
     int minK = ds[0].K;
     for (int i = 1; i < n; ++i) minK = std::min(minK, ds[i].K);
-    int S = std::max(1, std::min(2, ncu / std::max(1, t8)));
-    while (S > 1 && (minK < 8 * TK * S || !ds[0].ws || ds[0].ws_bytes < (int64_t)t8 * (S - 1) * 65536 * 4 || ((uintptr_t)ds[0].ws % 16))) --S;
+    int S = std::max(1, std::min(g_tn8_max_split, ncu / std::max(1, t8)));
+    // a pair spins on its partner: S = 2 needs the WHOLE grid co-resident (occupancy x CUs of THIS device, not a constant)
+    while (S > 1 && (t8 * S > std::min(ncu, df->tn8_resident) || minK < 8 * TK * S || !ds[0].ws ||
+                     ds[0].ws_bytes < (int64_t)t8 * (S - 1) * 65536 * 4 || ((uintptr_t)ds[0].ws % 16))) --S;
     // worth it when the 256^2 grid keeps at least as many CUs busy as the 256 x 128 grid would (a base layer: 108 tiles x 2)
     if (t8 * S <= ncu && t8 * S * 8 >= ncu * 5 && t8 <= 1024) {
       // 16 regions x 1024 tiles x 2 exchange flags, used round-robin (launches in flight on different streams do not share
       // one); zero between launches: whoever polls a flag lowers it again
-      static unsigned* cnt_pool = nullptr;
-      static int cnt_next = 0;
-      if (!cnt_pool) {
-        if (hipMalloc((void**)&cnt_pool, 16 * 2048 * sizeof(unsigned)) != hipSuccess) return set_error("gemm_tn_group: flag allocation failed");
-        // on the launch stream: a memset on the null stream is not ordered with a kernel on a non-blocking stream
-        if (hipMemsetAsync(cnt_pool, 0, 16 * 2048 * sizeof(unsigned), s) != hipSuccess) return set_error("gemm_tn_group: flag memset failed");
+      // one pool PER DEVICE, zeroed synchronously when it is made (visible to every stream that launches later)
+      if (!df->flags) {
+        if (hipMalloc((void**)&df->flags, 16 * 2048 * sizeof(unsigned)) != hipSuccess) return set_error("gemm_tn_group: flag allocation failed");
+        if (hipMemset(df->flags, 0, 16 * 2048 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+          return set_error("gemm_tn_group: flag memset failed");
       }
-      static const int dbg_env = [] { const char* e = getenv("W2VS_TN8_DBG"); return e ? atoi(e) : 0; }();
       static const int s_env = [] { const char* e = getenv("W2VS_TN8_S"); return e ? atoi(e) : 0; }();
       if (s_env > 0) S = std::min(S, s_env);
+#ifdef W2VS_ABLATION      // timing-only ablations (results are WRONG by design): never in the product build
+      static const int dbg_env = [] { const char* e = getenv("W2VS_TN8_DBG"); return e ? atoi(e) : 0; }();
       g8.dbg = dbg_env;
+#endif
       g8.S = S; g8.slab = (float*)ds[0].ws; g8.slab_bytes = std::min<int64_t>(ds[0].ws_bytes, 0x7FFFFFF0L);
-      g8.cnt = cnt_pool + 2048 * (cnt_next++ & 15);
+      g8.cnt = df->flags + 2048 * (df->next++ & 15);
+      g_last_group_form = S == 2 ? 14 : 13;
       static const bool tn_log8 = getenv("W2VS_GEMM_LOG") != nullptr;
       if (tn_log8) fprintf(stderr, "gemm_tn_group -> 8-phase, %d tiles of 256x256, split K %d\n", t8, S);
       hipEvent_t pe = prof_begin(s, 5);
@@ -2100,6 +2143,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
       if (int e = gemm_tn(ds[i], num_cu_hint, s)) return e;
     return 0;
   }
+  g_last_group_form = 12;
   hipEvent_t pe = prof_begin(s, 5);                // ~10 launches per step: every 5th is timed (the global 1-in-29 would see 7 in a run)
   hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(tiles), dim3(768), 0, s, g);
   prof_end(pe, 12, flops, s);                      // id 12: the grouped weight-gradient launch

@@ -23,9 +23,12 @@ int gemm_nt(const GemmDesc& d, hipStream_t s);
 int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s);
 int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s);
 void gemm_tune(int nt_mode, int lc_height, int tn_lc);
+void gemm_tn8_max_split(int s);
+int gemm_last_group_form();
 void attn_tune(int variant);
 void prof_enable(int stride);
 int prof_read(int id, double* total_ms, double* total_flops, int* launches);
+int prof_read_raw(int id, double* total_ms, double* total_flops, int* launches);
 long prof_launches(int id);
 double prof_flops_all(int id);
 int conv0_fwd(const void* wave, const void* w, const void* cbias, const void* lnw, const void* lnb, void* y,

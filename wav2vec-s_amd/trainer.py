@@ -10,11 +10,52 @@ MI355X design: ONE flat bf16 parameter buffer, ONE flat fp32 master/m/v, ONE fla
 arena that the backward kernels accumulate into directly - the all-reduce and the optimizer each
 touch a single contiguous range, no per-tensor launches, no gradient copies.
 """
+import contextlib
+import ctypes
+import os
+
 import torch
 
 from . import engine, ops
 
 BF16 = torch.bfloat16
+
+
+class _Roctx:
+    """roctx ranges around the phases of an update - the names fairseq gives its own profiler ranges
+    (``torch.autograd.profiler.record_function`` in fs/trainer.py:754-795 "reduce-grads" / "multiply-grads" / "clip-grads" /
+    "optimizer", fs/tasks/fairseq_task.py:474-478 "forward" / "backward") - so that a rocprofv3 ``--marker-trace`` run can be
+    cut by phase.  Push/pop cost ~100 ns when no profiler listens; without the library (or with W2VS_ROCTX=0) they are no-ops."""
+
+    def __init__(self):
+        self.lib = None
+        if os.environ.get("W2VS_ROCTX", "1") != "0":
+            for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+                try:
+                    self.lib = ctypes.CDLL(name)
+                    self.lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    break
+                except OSError:
+                    self.lib = None
+
+    def push(self, name: str):
+        if self.lib is not None:
+            self.lib.roctxRangePushA(name.encode())
+
+    def pop(self):
+        if self.lib is not None:
+            self.lib.roctxRangePop()
+
+    @contextlib.contextmanager
+    def range(self, name: str):
+        self.push(name)
+        try:
+            yield
+        finally:
+            self.pop()
+
+
+ROCTX = _Roctx()
 
 
 class FlatParams:
@@ -197,6 +238,11 @@ class TrainStep:
                 tail = engine.milestone_offset(self.flat.arena, "encoder.")
             self.exchange = GradExchange(self.flat.arena.flat, dist, group=group,
                                          flush_at=tail if tail < self.flat.arena.numel else -1)
+            # The pairwise K split of the grouped weight-gradient launch has workgroups WAIT on their partner: sound only while
+            # the whole grid is co-resident, which nobody can promise once RCCL's kernels share the chip with the backward.
+            # An odd (LayerDrop-ped) layer then takes the 256 x 128 single-writer group instead (~10 us per step).
+            from . import _lib
+            _lib.call("w2vs_gemm_tn8_max_split", 1)
         dev = self.flat.p16.device
         # The reference computes the gradient norm on EVERY update (clip_grad_norm_ with max_norm 0 still returns the norm,
         # fs/trainer.py:781) and raises FloatingPointError before optimizer.step when it is not finite (:791-793).  Here the
@@ -226,19 +272,48 @@ class TrainStep:
             raise FloatingPointError("gradients are Nan/Inf")        # fs/trainer.py:791-793
         return gn
 
+    def _report_skipped(self, n_bad):
+        """A non-finite update was skipped on the device (nothing written).  The host had already counted it: take it back out
+        of Adam's step count (the reference never reaches optimizer.step / set_num_updates for it, fs/trainer.py:791-795), clear
+        the sticky device state so that the error is reported ONCE, and raise what the reference raises.  Updates enqueued
+        between the skipped one and this report ran with a step count (bias correction, scheduled rate) one too high - call
+        ``check()`` after every update when that matters (it is a sync)."""
+        self.flat.step = max(0, self.flat.step - int(n_bad))
+        self._bad_acc.zero_()
+        self.norm_buf.zero_()
+        self.clip_out[2:3].zero_()
+        self._flag_event = None
+        raise FloatingPointError("gradients are Nan/Inf")            # fs/trainer.py:791-793
+
+    def check(self):
+        """Synchronous form of the non-finite report: waits for the device, raises FloatingPointError if any update since the
+        last report was skipped.  Call it before checkpointing and at the end of training (a non-finite LAST update is otherwise
+        never looked at) - or after every update for the reference's exact abort-at-once behaviour."""
+        n_bad = float(self._bad_acc[0]) if self.use_optimizer and (self.clip > 0 or self.check_finite) else 0.0
+        if n_bad != 0.0:
+            self._report_skipped(n_bad)
+
+    finish = check
+
     def _raise_if_nonfinite(self):
         """Raise for an EARLIER update whose gradient norm was not finite, once its flag has reached the host (no wait)."""
         ev = self._flag_event
         if ev is not None and ev.query():
             self._flag_event = None
-            if float(self._flag_host[0]) != 0.0:
-                raise FloatingPointError("gradients are Nan/Inf")    # fs/trainer.py:791-793; that update was skipped on the device
+            n_bad = float(self._flag_host[0])
+            if n_bad != 0.0:
+                self._report_skipped(n_bad)    # that update was skipped on the device
 
     def __call__(self, sample):
         self._raise_if_nonfinite()
         ops.ARENA.activate(self.arena_bytes, self.flat.p16.device)
         try:
             return self._step(sample)
+        except BaseException:
+            # a step that died between w2vs_sumsq and w2vs_clip_scale_acc would leave its partial sum for the next update
+            self.norm_buf.zero_()
+            self.micro = 0
+            raise
         finally:
             ops.ARENA.suspend()
 
@@ -252,17 +327,20 @@ class TrainStep:
                 self.exchange.begin_step()
         # only the closing micro-batch reports gradient milestones: earlier ones would all-reduce partial sums
         self.model._on_grad_ready = self.exchange.on_ready if (self.exchange is not None and last) else None
-        loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
+        with ROCTX.range("forward"):
+            loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
         if self._one is None or self._one.device != loss.device:
             self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
-        torch.autograd.backward(loss, self._one)  # (a cached seed: loss.backward() fills a fresh one every step); milestones inside launch the bucketed all-reduces
+        with ROCTX.range("backward"):
+            torch.autograd.backward(loss, self._one)  # (a cached seed: loss.backward() fills a fresh one every step); milestones inside launch the bucketed all-reduces
         self.ss_acc += sample_size
         self.micro = 0 if last else self.micro + 1
         if not last:
             return loss.detach()
         total = self.ss_acc
         if self.exchange is not None:
-            self.exchange.finish()
+            with ROCTX.range("reduce-grads"):
+                self.exchange.finish()
             # the global sample_size: mask lengths can differ across ranks (own batches, own masks)
             # torch.full is a fill kernel with the value as a launch argument; torch.tensor([...], device=) would be a
             # synchronous pageable H2D copy on this stream, i.e. the host would wait for the whole backward every step
@@ -286,15 +364,17 @@ class TrainStep:
                 # (0 = non-finite norm = skip the update)
                 # norm_buf is zero here: allocated so, and every clip_scale_acc leaves it so.  The same launch adds the
                 # non-finite flag to _bad_acc - sticky on the device: a copy that is skipped below loses nothing
-                ops.sumsq(f.arena.flat, self.norm_buf)
-                ops.clip_scale_acc(self.norm_buf, self.clip_out, self._bad_acc, scale_host=scale, scale_dev=scale_dev,
-                                   clip=self.clip)
+                with ROCTX.range("clip-grads"):
+                    ops.sumsq(f.arena.flat, self.norm_buf)
+                    ops.clip_scale_acc(self.norm_buf, self.clip_out, self._bad_acc, scale_host=scale, scale_dev=scale_dev,
+                                       clip=self.clip)
                 scale, scale_dev = 1.0, self.clip_out[0:1]
                 if self._flag_host is not None and self._flag_event is None:
                     self._flag_host.copy_(self._bad_acc, non_blocking=True)
                     self._flag_event = torch.cuda.Event()
                     self._flag_event.record()
-            ops.adam_step(f.p32, f.p16, f.m, f.v, f.arena.flat, lr=lr, beta1=self.betas[0], beta2=self.betas[1],
-                          eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale, scale_dev=scale_dev)
+            with ROCTX.range("optimizer"):
+                ops.adam_step(f.p32, f.p16, f.m, f.v, f.arena.flat, lr=lr, beta1=self.betas[0], beta2=self.betas[1],
+                              eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale, scale_dev=scale_dev)
             self.last_lr = lr
         return loss.detach()
