@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--update-freq", type=int, default=1,
                     help="micro-batches per optimizer update (BASELINE configs[2] quotes 8); a timed 'step' stays ONE micro-batch "
                          "pass, so K steps = K micro-batches and K / update_freq updates + gradient exchanges")
+    ap.add_argument("--wire", default=os.environ.get("W2VS_WIRE", "fp32"), choices=["fp32", "bf16"],
+                    help="N > 1: dtype the gradient all-reduce moves (bf16 = half the xGMI bytes, the reference's model-dtype exchange)")
     ap.add_argument("--no-gemm-peak", action="store_true",
                     help="skip the 8192^3 calibration GEMM behind the timed region (profiler passes: its launches would be "
                          "pooled with the step's own launches of the same kernel symbol)")
@@ -195,7 +197,7 @@ def main():
                                 use_optimizer=not args.no_optimizer, update_freq=args.update_freq,
                                 lr=sched.current, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.01,
                                 clip_norm=25.0 if large else 0.0, arena_gib=40.0 if large else 12.0,
-                                check_finite=os.environ.get("W2VS_CHECK_FINITE", "1") == "1")
+                                check_finite=os.environ.get("W2VS_CHECK_FINITE", "1") == "1", wire_dtype=args.wire)
     B, L = args.batch, args.samples
     g = torch.Generator().manual_seed(1234 + rank)
     source = torch.randn(B, L, generator=g)
@@ -340,7 +342,7 @@ def main():
                                 "wav2vec-S base (12L d768, 90.3M params) pretrain step: fwd + InfoNCE/diversity/penalty loss + "
                                 "bwd%s%s; %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, LayerDrop 0.05, sampled "
                                 "block contexts; random-init weights; unread rows of the last encoder layer pruned (exact)") % (
-                                   " + RCCL grad all-reduce" if world > 1 else "",
+                                   (" + RCCL grad all-reduce (%s on the wire)" % args.wire) if world > 1 else "",
                                    ("" if args.no_optimizer else " + fused Adam") + (
                                        "" if args.update_freq == 1 else " (update_freq %d: exchange + Adam every %d-th step)" % (
                                            args.update_freq, args.update_freq)), B, L, audio_s),

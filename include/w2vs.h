@@ -66,6 +66,11 @@ typedef struct w2vs_gemm_desc {
   float* colsum;           /* TN only, optional: colsum[m] += alpha * sum_k A[k, m] (bias gradient fused in) */
   void* ws; int64_t ws_bytes; /* TN only, optional scratch (36 MB always suffices): split-K partial tiles are stored
                                  there and summed by a second launch instead of fp32 atomics into Cf */
+  /* NT only, optional promise about a STRUCTURAL zero block of B: B[n][k] == 0 for every n >= zk_col and k < zk_k (both
+   * multiples of 128; 0 = no promise).  Output tiles that lie wholly at columns >= zk_col then start their K loop at zk_k.
+   * The (3,2)-conv input gradient is such a product: pair p = [dY[p-1] | dY[p]] . [[W2, 0], [W0, W1]] - a quarter of its
+   * multiply-adds are with that zero block.  Results are identical with and without the promise when it is true. */
+  int32_t zk_col, zk_k;
 } w2vs_gemm_desc;
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
 /* Tests / tuning: force a kernel variant process-wide (not thread safe).  nt_mode: -1 auto, 0/1/2 the 128x128 forms
@@ -323,6 +328,9 @@ int w2vs_transpose2d(const void* in, void* out, int32_t R, int32_t C, int32_t ba
 typedef struct w2vs_transpose_item { const void* in; void* out; int32_t R, C; int64_t ld_in, ld_out; /* row strides in elements, 0 = dense (C / R) */ } w2vs_transpose_item;
 int w2vs_transpose_multi(const w2vs_transpose_item* items, int32_t n, void* stream);
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* stream);
+/* out[i] = float(in[i]) (bf16 -> fp32): with w2vs_f32_to_bf16 the pack / unpack pair of a bf16-compressed gradient exchange
+ * (the reference all-reduces gradients in the model dtype, fs/distributed/legacy_distributed_data_parallel.py:100-115) */
+int w2vs_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 /* out[i] = in[i] * keep(seed, i) / (1 - p) : nn.Dropout (dropout_features, wav2vec2.py:571);
  * the backward is the same call on the gradient with the same seed. */
 int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* stream);

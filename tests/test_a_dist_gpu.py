@@ -160,6 +160,44 @@ def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
         assert n1 > clip                                                   # the case does clip
 
 
+def test_rccl_bf16_wire_rounds_only_the_exchanged_gradient(nccl_group):
+    """GradExchange(wire_dtype="bf16") on RCCL: every range is packed into a bf16 image (w2vs_f32_to_bf16), all-reduced there
+    (half the bytes: the reference reduces in the model dtype, legacy_distributed_data_parallel.py:100-115) and unpacked into
+    the fp32 arena (w2vs_bf16_to_f32) - with gradient accumulation over two micro-batches (only the final sum is rounded) and a
+    LayerDrop-ped layer.  On a 1-rank group the result must be the bf16 rounding of the local fp32 gradient, element for
+    element covered exactly once; the update then follows from it."""
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    res = []
+    for world, wire in ((1, "fp32"), (2, "bf16")):
+        w, cfg, model, crit = _build(SMALL)
+        step = trainer.TrainStep(model, crit, world_size=world, lr=1e-3, update_freq=2, arena_gib=1.0, wire_dtype=wire)
+        if world == 2:
+            step.exchange.bucket = 50_000
+            assert step.exchange.wire is not None and step.exchange.wire.dtype == BF
+        mk = _draws(cfg, B, L, [True, False, True, True])
+        for _ in range(2):
+            model.inject_draws(mk())
+            step({"net_input": {"source": src}})
+        torch.cuda.synchronize()
+        if world == 2:
+            cov = np.zeros(step.flat.arena.numel, dtype=np.int32)
+            for lo, hi in step.exchange.launched:
+                cov[lo:hi] += 1
+            assert (cov == 1).all() and len(step.exchange.launched) >= 3
+        res.append((step.flat.arena.flat.clone(), step.flat.m.clone()))
+        ops.ARENA.deactivate()
+    (g1, m1), (g2, m2) = res
+    assert torch.equal(g2, g2.to(BF).float())                              # what came back IS a bf16 image
+    assert float((g2 == 0).float().mean()) < 0.5 and float(g2.abs().max()) > 0
+    # against the rounding of the local fp32 gradient: one bf16 ulp (2^-8 relative) + the run-to-run atomic-order noise
+    err = (g2.double() - g1.double()).abs()
+    assert float((err <= 2.0 ** -8 * g1.double().abs() + 2e-4 * float(g1.abs().max())).float().mean()) > 0.9999
+    assert float(err.norm() / g1.double().norm()) < 4e-3
+    assert float((m1.double() - m2.double()).norm() / m1.double().norm()) < 4e-3
+
+
 def test_update_divides_by_the_sample_size_summed_over_ranks(nccl_group):
     """The round-2 review: on a 1-rank group the division by the sum of sample_size over ranks is an identity.  Here a stub
     process group plays a SECOND rank with its own sample_size and its own gradient (0.5 x this rank's, so the sum is 1.5 g):

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, bucket, offsets, out_q):
+def _worker(rank, world, port, n, bucket, offsets, out_q, wire="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,7 +32,7 @@ def _worker(rank, world, port, n, bucket, offsets, out_q):
     if rank == 1:
         flat[n // 3: n // 2] = 0          # a LayerDrop-ped layer on one rank only: zeros still take part
         mine = flat.clone()
-    ex = GradExchange(flat, dist, bucket_elems=bucket)
+    ex = GradExchange(flat, dist, bucket_elems=bucket, wire_dtype=wire)
     for step in range(2):                  # two steps: state must reset between them
         flat.copy_(mine)
         ex.begin_step()
@@ -46,23 +46,32 @@ def _worker(rank, world, port, n, bucket, offsets, out_q):
         assert all(hi - lo >= min(bucket, n) or lo == 0 for lo, hi in ex.launched)
     gathered = [torch.zeros(n) for _ in range(world)]
     dist.all_gather(gathered, mine)
-    want = sum(gathered)
-    ok = bool(torch.allclose(flat, want, atol=1e-6))
+    if wire == "bf16":     # each rank's range is rounded to bf16, summed in bf16 on the wire, widened back (exactly representable)
+        bf = torch.bfloat16
+        want = (gathered[0].to(bf).float() + gathered[1].to(bf).float()).to(bf).float()
+        ok = bool(torch.equal(flat.to(bf).float(), flat)) and bool(((flat - want).abs() <= 2.0 ** -7 * want.abs() + 1e-30).all())
+        ok = ok and bool((flat[n // 3: n // 2] == gathered[0].to(bf).float()[n // 3: n // 2]).all())   # zeros of the other rank take part
+    else:
+        want = sum(gathered)
+        ok = bool(torch.allclose(flat, want, atol=1e-6))
     out_q.put((rank, ok, len(ex.launched)))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
 @pytest.mark.parametrize("n,bucket,offsets", [
     (10_000, 3_000, [9_500, 8_000, 6_100, 4_000, 2_500, 900, 0]),     # milestones as the backward reports them
     (10_000, 50_000, [9_000, 5_000, 0]),                              # bucket larger than the arena: one collective
     (4_097, 1_024, [4_000, 4_000, 10]),                               # repeated / missing final milestone
 ])
-def test_grad_exchange_gloo_world2(n, bucket, offsets):
+def test_grad_exchange_gloo_world2(n, bucket, offsets, wire):
+    """Both wire types: "fp32" all-reduces the arena in place; "bf16" packs each range into a bf16 image, all-reduces that (the
+    reference reduces in the model dtype, fs/distributed/legacy_distributed_data_parallel.py:100-115) and unpacks it."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, bucket, offsets, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, bucket, offsets, q, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(2)]

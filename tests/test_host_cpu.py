@@ -223,3 +223,40 @@ def test_criterion_reduce_metrics_known_answers():
     assert m.get("loss_0") == round(130.0 / 16 / math.log(2), 3) and m.get("loss_1") == round(30.0 / 16 / math.log(2), 3)
     assert m.get("prob_perplexity") == 310.0 and m.get("temp") == 2.0
     assert Wav2vecCriterion(infonce=True).logging_outputs_can_be_summed() is False
+
+
+def test_attention_dropout_hash_statistics_within_and_across_seeds():
+    """The attention-dropout keep decisions (numpy mirror of attn_common.h: pair_hash_pm): keep rate, neighbour correlations,
+    field-to-field correlation within a seed - and ACROSS seeds, at the alignment where the round-3 form (whole seed folded into an
+    additive offset of the index) produced identical shifted masks: two seeds whose low words differ by delta * K hash word i
+    and word i + delta from the same Weyl position; only the second seed word tells them apart."""
+    import hash_mirror as Hm
+    p = 0.1
+    thr = Hm.thr16(p)
+    idx = np.arange(1 << 20, dtype=np.uint64)
+
+    def fields(seed, off=0):
+        h = Hm.hash_words(seed, idx + np.uint64(off))
+        return ((h & np.uint64(0xFFFF)) >= thr).astype(np.float64), ((h >> np.uint64(16)) >= thr).astype(np.float64)
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean()))
+
+    lo, hi = fields(0x123456789ABCDEF)
+    assert abs(lo.mean() - (1 - thr / 65536.0)) < 1.5e-3 and abs(hi.mean() - (1 - thr / 65536.0)) < 1.5e-3
+    assert abs(corr(lo, hi)) < 5e-3                                   # the two decisions of a word
+    for sh in (1, 2, 3, 409, 818):                                    # neighbouring words / the next query row
+        assert abs(corr(lo[:-sh], lo[sh:])) < 5e-3 and abs(corr(lo[:-sh], hi[sh:])) < 5e-3, sh
+    # across seeds: same s0-alignment (s0' = s0 + delta*K  <=>  word i of seed' sits where word i + delta of seed sits), s1 differs
+    s0, delta = 0x89ABCDEF, 777
+    s0b = (s0 + delta * Hm.HASH_K) & Hm.M32
+    for s1a, s1b in ((0x12345678, 0x12345679), (1, 2), (0xDEADBEEF, 0x0BADF00D), (0, 1 << 31)):
+        a_lo, a_hi = fields((s1a << 32) | s0, off=delta)
+        b_lo, b_hi = fields((s1b << 32) | s0b)
+        assert abs(corr(a_lo, b_lo)) < 5e-3 and abs(corr(a_hi, b_hi)) < 5e-3, (hex(s1a), hex(s1b))
+        assert abs(float((a_lo == b_lo).mean()) - (0.9 * 0.9 + 0.1 * 0.1)) < 3e-3        # agreement of independent masks: 0.82
+    # the same s1 at that alignment IS the shifted sequence (what the site seeds must never produce: engine._site_seed mixes both words)
+    a_lo, _ = fields((5 << 32) | s0, off=delta)
+    b_lo, _ = fields((5 << 32) | s0b)
+    assert np.array_equal(a_lo, b_lo)

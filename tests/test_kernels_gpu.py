@@ -383,6 +383,30 @@ def test_attention_stored_keep_masks_equal_rehash(ops, Tp, m, r, H, nq):
     assert torch.equal(g2, g3)
 
 
+def test_attention_keep_decisions_equal_the_numpy_mirror(ops):
+    """The decisions the forward kernel parks in drop_bits (= the ones every attention kernel hashes) against
+    tests/hash_mirror.py, the numpy restatement of attn_common.h::pair_hash_pm whose statistics - within a seed and across
+    seeds - tests/test_host_cpu.py checks: every VISIBLE (query, key) pair of three shapes and two 64-bit seeds."""
+    import hash_mirror as Hm
+    for (B, H, Tp, m, r, p, seed) in ((2, 3, 130, 32, 16, 0.1, 0x1234567890ABCDEF), (1, 2, 546, 16, 8, 0.25, 77),
+                                      (2, 2, 96, 24, 6, 0.1, (0xFFFFFFFF << 32) | 5)):
+        N = Tp + ((Tp + m - 1) // m - 1) * r if r > 0 else Tp
+        from wav2vec_s_amd import host_rng
+        N = host_rng.block_layout(Tp, m, r).N
+        qkv = torch.zeros(B, N, 3 * H * 64, device="cuda", dtype=BF)
+        bits = ops.attn_drop_bits(B, H, N)
+        bits.fill_(-1)
+        ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=seed, drop_bits=bits)
+        got = Hm.decode_drop_bits(bits, B, H, N).cpu().numpy()
+        want = Hm.attn_keep(seed, B, H, N, p)
+        _, _, masked = O.block_structure(Tp, m, r)
+        vis = ~masked.numpy()                                   # [N, N] query x key
+        assert vis.shape == (N, N)
+        assert np.array_equal(got[:, :, vis], want[:, :, vis]), (B, H, Tp, m, r)
+        rate = want[:, :, vis].mean()
+        assert abs(rate - (1 - Hm.thr16(p) / 65536.0)) < 0.01
+
+
 def test_attention_dropout_consistency(ops):
     """fwd and the two bwd passes regenerate the same keep-mask: finite-difference style check
     through linearity in V (O is linear in V for a fixed mask) and dV == P_drop^T dO."""
@@ -722,6 +746,34 @@ def test_conv0_ln_gelu_with_conv_bias(ops):
     assert rel(db, bf_.grad) < 5e-3
     # d(conv bias) is a sum of the LayerNorm-backward output, which is zero-mean per frame: compare with an absolute floor
     assert float((dcb.cpu() - cbf.grad).abs().max()) < 5e-3 * max(1.0, float(cbf.grad.abs().max())) + 2e-2
+
+
+@pytest.mark.parametrize("mode,height", [(8, 256), (8, 320), (5, 256), (5, 160), (5, 1160), (-1, 0)])
+def test_gemm_nt_structural_zero_block_is_skipped_exactly(ops, mode, height):
+    """w2vs_gemm_desc.zk_col / zk_k: B[n][k] == 0 for n >= zk_col, k < zk_k (the [[W2, 0], [W0, W1]] operand of the (3,2)-conv
+    input gradient).  The persistent kernels start the K loop of the tiles at those columns at zk_k - a quarter of the
+    multiply-adds gone; adding exact zeros changes no fp32 sum, so the result must be BIT-identical to the plain product, over
+    several tiles per workgroup, batch planes and a ragged M.  A (true) promise the tile grid cannot honour - zk_col inside a tile, an odd number
+    of K tiles - is ignored, not mis-applied; a narrower true promise (zk_col 768) skips fewer tiles."""
+    Bz, M, N, K = 3, 21000, 1024, 1024          # 66 x 4 x 3 = 792 tiles of 320 x 256: three rounds of 256 workgroups, row groups straddle them
+    a = dev(rnd(Bz, M, K, seed=1))
+    b = rnd(N, K, seed=2, scale=0.05)
+    b[512:, :512] = 0
+    b = dev(b)
+    aux = dev(rnd(Bz, M, N, seed=3))
+    try:
+        ops.gemm_tune(nt_mode=mode, lc_height=height)
+        outs = []
+        for zk in (dict(), dict(zk_col=512, zk_k=512), dict(zk_col=576, zk_k=512), dict(zk_col=512, zk_k=448), dict(zk_col=768, zk_k=512)):
+            out = torch.empty(Bz, M, N, device="cuda", dtype=BF)
+            ops.gemm_nt(a, b, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, out=out, aux=aux, epi=8, batch=Bz, sA=M * K, sC=M * N, **zk)
+            outs.append(out)
+        ref = (a[1].float() @ b.float().t()) * aux[1].float()
+        assert rel(outs[0][1], ref) < 5e-3
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+    finally:
+        ops.gemm_tune()
 
 
 def test_gemm_tn_group_equals_single_launches():

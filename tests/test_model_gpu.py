@@ -96,25 +96,16 @@ def _row_keep(ops, rows, C, p, seed):
     return (ops.dropout(ones, p, seed).float() > 0).float().cpu() * _inv_keep(p)
 
 
-_KR = [(i & 3) + 8 * (i >> 2) + 4 * w_ for i in range(16) for w_ in range(2)]     # key row of dword 2i + w (attn_common.h)
-
-
 def _attn_keep(ops, B, H, N, Tp, m, r, p, seed):
     """Multiplicative mask [B, H, N, N] of a layer's attention dropout: the forward kernel parks its keep decisions as bits
     (w2vs_attn_desc.drop_bits; test_attention_stored_keep_masks_equal_rehash shows they ARE the hashed decisions of the
     plain launch) - decoded here.  Blocks no query can see are never written and stay 'keep' (their probabilities are 0)."""
+    import hash_mirror
     qkv = torch.zeros(B, N, 3 * H * 64, device="cuda", dtype=BF)
     bits = ops.attn_drop_bits(B, H, N)
     bits.fill_(-1)
     ops.attn_fwd(qkv, H, Tp, m, r, p_drop=p, seed=seed, drop_bits=bits)
-    nT = (N + 31) // 32
-    w = bits.view(B * H, nT, nT, 32).long() & 0xFFFFFFFF
-    qb = (w.unsqueeze(-1) >> torch.arange(32, device="cuda")) & 1                  # [BH, qt, kt, dword, query bit]
-    inv = torch.empty(32, dtype=torch.long)
-    inv[torch.tensor(_KR)] = torch.arange(32)
-    qb = qb.index_select(3, inv.cuda())                                            # [BH, qt, kt, key row, query]
-    keep = qb.permute(0, 1, 4, 2, 3).reshape(B * H, nT * 32, nT * 32)[:, :N, :N]
-    return (keep.view(B, H, N, N).float() * _inv_keep(p)).cpu()
+    return (hash_mirror.decode_drop_bits(bits, B, H, N).float() * _inv_keep(p)).cpu()
 
 
 def _drop_masks(st, cfg):

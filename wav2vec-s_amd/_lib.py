@@ -16,7 +16,7 @@ class GemmDesc(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
                 ("lda", i64), ("ldb", i64), ("ldc", i64), ("a_off", i64),
                 ("sA", i64), ("sB", i64), ("sC", i64), ("a_bytes", i64), ("b_bytes", i64), ("c_elems", i64),
-                ("epi", i32), ("alpha", f32), ("colsum", vp), ("ws", vp), ("ws_bytes", i64)]
+                ("epi", i32), ("alpha", f32), ("colsum", vp), ("ws", vp), ("ws_bytes", i64), ("zk_col", i32), ("zk_k", i32)]
 
 
 class LnFwdDesc(C.Structure):
@@ -136,6 +136,7 @@ _SIGS = {
     "w2vs_transpose2d": [vp, vp, i32, i32, i32, vp],
     "w2vs_transpose_multi": [vp, i32, vp],
     "w2vs_f32_to_bf16": [vp, vp, i64, f32, vp],
+    "w2vs_bf16_to_f32": [vp, vp, i64, vp],
     "w2vs_colsum": [vp, vp, i64, i32, i64, vp],
     "w2vs_dropout": [vp, vp, i64, f32, u64, vp],
     "w2vs_relu_gate": [vp, vp, vp, i64, vp],

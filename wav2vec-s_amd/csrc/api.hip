@@ -93,6 +93,7 @@ int64_t w2vs_attn_drop_bits_bytes(int32_t B, int32_t H, int32_t N, int32_t Nq) {
 }
 int w2vs_transpose_multi(const w2vs_transpose_item* items, int32_t n, void* s) { return transpose_multi(items, n, ST(s)); }
 int w2vs_f32_to_bf16(const float* in, void* out, int64_t n, float scale, void* s) { return f32_to_bf16(in, out, n, scale, ST(s)); }
+int w2vs_bf16_to_f32(const void* in, float* out, int64_t n, void* s) { return bf16_to_f32(in, out, n, ST(s)); }
 int w2vs_dropout(const void* in, void* out, int64_t n, float p, uint64_t seed, void* s) { return dropout(in, out, n, p, seed, ST(s)); }
 int w2vs_relu_gate(const void* x, const void* gate, void* out, int64_t n, void* s) { return relu_gate(x, gate, out, n, ST(s)); }
 int w2vs_adam_step(float* p32, void* p16, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,

@@ -177,9 +177,21 @@ constexpr uint32_t HASH_K = 0x9E3779B1u;
 // two decisions.  Checked on 2 x 419 k decisions per seed (numpy mirror, three seeds): keep rate within 6e-4 of 1 - p;
 // field-to-field, adjacent-column / -row / -diagonal and two-apart correlations all < 0.005 (the noise level of the
 // sample, as for the 32-bit form it replaces); 64-bin chi-square of the fields 65 - 84 (expected 63 +- 11).
+// Round 4: the second seed word enters NON-linearly.  Round 3 folded the whole 64-bit seed into the additive offset of the
+// index (x0 = idx * K + f(s0, s1)): with K odd, the masks of two seeds were the same 2^32-long sequence read at two offsets,
+// and the windows of two layers (2e7 words per layer and step) overlapped in about half of the steps - shifted IDENTICAL
+// attention-dropout masks.  Now s0 alone shifts the Weyl sequence and a mix of s1 is XOR-ed into the word before the 24-bit
+// multiply, whose carries make the result depend on it non-linearly: two seeds that land on the same x0 still draw different
+// words.  One more full-rate op per word (v_xor3 where the compiler fuses it).  tests/test_host_cpu.py mirrors this function
+// in numpy and checks keep rate, neighbour correlations AND cross-seed correlations at aligned offsets;
+// tests/test_kernels_gpu.py ties the mirror to the kernels' own decisions (drop_bits).
+__device__ __forceinline__ uint32_t seed_mix(uint32_t s1) {              // loop-invariant scalar work
+  uint32_t m = (s1 ^ (s1 >> 15)) * 0x85EBCA77u;
+  return m ^ (m >> 13);
+}
 __device__ __forceinline__ uint32_t pair_hash_pm(uint32_t s0, uint32_t s1, uint32_t idx_times_k) {
-  const uint32_t x0 = idx_times_k + (s0 + s1 * 0x85EBCA77u);          // the seed mix is loop-invariant scalar work
-  const uint32_t x = x0 ^ (x0 >> 16);
+  const uint32_t x0 = idx_times_k + s0;
+  const uint32_t x = x0 ^ (x0 >> 16) ^ seed_mix(s1);
   uint32_t h = __umul24(x, 0xB5352Du) + x0;                           // v_mad_u32_u24
   h ^= h >> 15;
   return h;

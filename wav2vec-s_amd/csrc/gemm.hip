@@ -57,6 +57,7 @@ struct GemmP {
   float* colsum;              // TN only: optional out[m] += sum_k A[k, m]  (bias gradient)
   float* slab;                // TN loader/consumer: partial tiles [grid.z][M][N] instead of atomics into Cf
   float alpha;
+  int zk_col, zk_kt;          // NT persistent kernels: tiles with n0 >= zk_col start at K tile zk_kt (B is zero before it); 0 = off
 };
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6,
@@ -668,6 +669,11 @@ __global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_lc_kernel(GemmP p)
 // ---------------------------------------------------------------------------------------------
 struct TileIter {   // tiles of one workgroup, in XCD-aware order: round r covers ids [r*G, (r+1)*G), the 32 workgroups
   int G, slot, total, ntm, ntn;   // of an XCD take a contiguous chunk of it, ids walk group-M inside a batch plane
+  // zk skip: cheap and full column tiles must alternate per workgroup, but 256 % (4 ntn) == 0 hands a workgroup the same
+  // column tile every round.  rot > 0: the column tile is rotated by (row group / rot + batch plane) - a function of the
+  // TILE alone (a bijection of the tile set: rotating by the round is not, it duplicates tiles where a row group straddles two
+  // rounds), and with rot = G / (4 ntn) it advances by one per round.
+  int rot = 0;
   __device__ __forceinline__ bool get(int r, int& bz, int& tm, int& tn) const {
     const long id = (long)r * G + slot;
     if (id >= total) return false;
@@ -679,13 +685,16 @@ struct TileIter {   // tiles of one workgroup, in XCD-aware order: round r cover
     // workgroup-uniform by construction; say so, or every LDS-DMA gets a waterfall loop around its descriptor
     bz = __builtin_amdgcn_readfirstlane(bz);
     tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsz);
-    tn = __builtin_amdgcn_readfirstlane(in_group / gsz);
+    tn = in_group / gsz;
+    if (rot) tn = (tn + group / rot + bz) % ntn;
+    tn = __builtin_amdgcn_readfirstlane(tn);
     return true;
   }
 };
 
 struct TileIter32 {   // the same order in 32-bit arithmetic (total tiles < 2^31): the 8-phase kernel calls it from its staging cursor
   int G, slot, total, ntm, ntn;
+  int rot = 0;
   __device__ __forceinline__ bool get(int r, int& bz, int& tm, int& tn) const {
     const unsigned id = (unsigned)r * (unsigned)G + (unsigned)slot;
     if (id >= (unsigned)total) return false;
@@ -694,7 +703,9 @@ struct TileIter32 {   // the same order in 32-bit arithmetic (total tiles < 2^31
     const unsigned gsz = min((unsigned)ntm - first_m, GM), in_group = t - group * per_group, q = in_group / gsz;
     bz = __builtin_amdgcn_readfirstlane((int)b);
     tm = __builtin_amdgcn_readfirstlane((int)(first_m + in_group - q * gsz));
-    tn = __builtin_amdgcn_readfirstlane((int)q);
+    unsigned tq = q;
+    if (rot) tq = (q + group / (unsigned)rot + b) % (unsigned)ntn;      // see TileIter::rot
+    tn = __builtin_amdgcn_readfirstlane((int)tq);
     return true;
   }
 };
@@ -713,7 +724,7 @@ __global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, 
   const int wm = (wid / WN) % WM, wn = wid % WN;
   const int nk = (p.K + BK - 1) / BK;
   TileIter it;
-  it.G = gridDim.x; it.total = total_tiles; it.ntm = ntm; it.ntn = ntn;
+  it.G = gridDim.x; it.total = total_tiles; it.ntm = ntm; it.ntn = ntn; it.rot = p.zk_kt > 0 ? max(1, (int)gridDim.x / (4 * ntn)) : 0;
   {
     const int g = blockIdx.x, G = gridDim.x, qd = G >> 3, rm = G & 7, xcd = g & 7;
     it.slot = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (g >> 3);
@@ -757,7 +768,8 @@ __global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, 
         }
       }
       const int kts = live ? nk : 2;
-      for (int kt = 0; kt < kts; ++kt) {
+      const int kb = (live && p.zk_kt > 0 && n0 >= p.zk_col) ? p.zk_kt : 0;     // B is zero before this K tile: skipped
+      for (int kt = kb; kt < kts; ++kt) {
         bf16* sbase = lds + stage * STAGE_EL;
 #pragma unroll
         for (int j = 0; j < LP; ++j) {
@@ -792,7 +804,7 @@ __global__ __launch_bounds__((WN * WM + 4) * 64) void gemm_nt_p_kernel(GemmP p, 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = (p.zk_kt > 0 && n0 >= p.zk_col) ? p.zk_kt : 0; kt < nk; ++kt) {
       const bf16* sa = lds + stage * STAGE_EL;
       const bf16* sb = sa + A_EL;
 #pragma unroll
@@ -871,7 +883,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
   const int wr = wid >> 2, wc = wid & 3, fr = lane & 15, fq = lane >> 4, l3 = lane >> 3, l7 = lane & 7;
   const int nk = p.K / BK, nk2 = (nk + 1) & ~1;          // K tiles per output tile, padded to a pair (pad = zeros)
   TileIter32 it;
-  it.G = gridDim.x; it.total = total_tiles; it.ntm = ntm; it.ntn = ntn;
+  it.G = gridDim.x; it.total = total_tiles; it.ntm = ntm; it.ntn = ntn; it.rot = p.zk_kt > 0 ? max(1, (int)gridDim.x / (4 * ntn)) : 0;
   {
     const int g = blockIdx.x, G = gridDim.x, qd = G >> 3, rm = G & 7, xcd = g & 7;
     it.slot = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (g >> 3);
@@ -913,9 +925,12 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
     int bz, tm, tn;
     live_s = it.get(r, bz, tm, tn);
     ok_cur = live_s;
+    kt_s = 0;
     if (live_s) {
-      a_cur = a_thr + (uint32_t)((p.a_off + (long)tm * TBM * p.lda) * 2);
-      b_cur = b_thr + (uint32_t)((long)tn * 256 * p.ldb * 2);
+      // zk skip (host: zk_kt even): a tile in the zero-block columns starts its K loop - cursor and compute loop alike - at zk_kt
+      kt_s = (p.zk_kt > 0 && tn * 256 >= p.zk_col) ? p.zk_kt : 0;
+      a_cur = a_thr + (uint32_t)((p.a_off + (long)tm * TBM * p.lda + (long)kt_s * BK) * 2);
+      b_cur = b_thr + (uint32_t)(((long)tn * 256 * p.ldb + (long)kt_s * BK) * 2);
       ra_cur = make_rsrc(p.A + (long)bz * p.sA, p.a_bytes);
       rb_cur = make_rsrc(p.B + (long)bz * p.sB, p.b_bytes);
     }
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
     a_prev = a_cur; ok_prev = ok_cur; ra_prev = ra_cur;
     ++kt_s;
     if (kt_s < nk2) { a_cur += 2 * BK; b_cur += 2 * BK; ok_cur = live_s && kt_s < nk; }
-    else { kt_s = 0; ++r_s; set_tile(r_s); }
+    else { ++r_s; set_tile(r_s); }
   };
   auto stage_A = [&](int buf, int h, __amdgpu_buffer_rsrc_t rs, uint32_t base, bool ok) {
 #pragma unroll
@@ -1031,7 +1046,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
       for (int i = 0; i < MH; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[mh][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kp = 0; kp < nk2; kp += 2) {
+    for (int kp = (p.zk_kt > 0 && tn * 256 >= p.zk_col) ? p.zk_kt : 0; kp < nk2; kp += 2) {
       ktile(std::integral_constant<int, 0>{});
       ktile(std::integral_constant<int, 1>{});
     }
@@ -1903,6 +1918,13 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   if (nt_log) fprintf(stderr, "gemm_nt M %d N %d K %d batch %d epi %d lda %ld -> mode %d tile %dx%d\n", d.M, d.N, d.K, (int)d.batch, d.epi,
                       (long)d.lda, mode, mode >= 3 ? lc_h : 128, (wide || mode == 8) ? 256 : 128);
   const dim3 grid8((d.N + (wide ? 255 : 127)) / (wide ? 256 : 128), (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
+  // structural zero block of B (w2vs_gemm_desc.zk_*): only the persistent kernels skip it, and only when their column tiles do
+  // not straddle zk_col and the skipped K range is a whole, EVEN number of K tiles (the 8-phase loop walks K tiles in pairs)
+  p.zk_col = 0; p.zk_kt = 0;
+  if (d.zk_k > 0 && d.zk_col > 0 && (mode == 8 || mode == 5 || mode == 6)) {
+    const int tw = (wide || mode == 8) ? 256 : 128;
+    if (d.zk_k % (2 * BK) == 0 && d.zk_k < d.K && d.zk_col % tw == 0 && d.zk_col < d.N) { p.zk_col = d.zk_col; p.zk_kt = d.zk_k / BK; }
+  }
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
     if (mode == 8) {                /* 8-phase, persistent: (lc_h) x 256 tiles */              \

@@ -830,10 +830,40 @@ __global__ void f32_to_bf16_kernel(const float* in, bf16* out, long n, float sca
     for (; i < n; ++i) out[i] = f2bf(in[i] * scale);
   }
 }
+// the same for ranges that do not start on a 16-byte boundary (a gradient-exchange bucket may start anywhere)
+__global__ void f32_to_bf16_scalar_kernel(const float* in, bf16* out, long n, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = f2bf(in[i] * scale);
+}
 int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st) {
   if (!in || !out || n <= 0) return set_error("f32_to_bf16: bad arguments");
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, in, (bf16*)out, n, scale);
+  if (((uintptr_t)in & 15) || ((uintptr_t)out & 7))
+    hipLaunchKernelGGL(f32_to_bf16_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, (bf16*)out, n, scale);
+  else
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, in, (bf16*)out, n, scale);
   return hip_check(hipGetLastError(), "f32_to_bf16");
+}
+// out = float(in): the way back of a bf16-compressed gradient exchange (trainer.GradExchange, wire_dtype = "bf16")
+__global__ void bf16_to_f32_kernel(const bf16* in, float* out, long n, bool vec) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * (vec ? 4 : 1);
+  if (vec && i + 3 < n) {
+    const bf16x4 v = *(const bf16x4*)(in + i);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = bf2f(v[e]);
+    *(f32x4*)(out + i) = o;
+  } else if (vec) {
+    for (; i < n; ++i) out[i] = bf2f(in[i]);
+  } else if (i < n) {
+    out[i] = bf2f(in[i]);
+  }
+}
+int bf16_to_f32(const void* in, float* out, long n, hipStream_t st) {
+  if (!in || !out || n <= 0) return set_error("bf16_to_f32: bad arguments");
+  const bool vec = !(((uintptr_t)out & 15) || ((uintptr_t)in & 7));
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + (vec ? 1023 : 255)) / (vec ? 1024 : 256))), dim3(256), 0, st,
+                     (const bf16*)in, out, n, vec);
+  return hip_check(hipGetLastError(), "bf16_to_f32");
 }
 
 // out = in * keep(seed, i) / (1-p) : standalone dropout (dropout_features), same call for the bwd

@@ -68,6 +68,7 @@ int gather_rows(const void* src, const int* idx, void* dst, long R, int C, int s
 int transpose2d(const void* in, void* out, int R, int C, int batch, hipStream_t st);
 int transpose_multi(const w2vs_transpose_item* items, int n, hipStream_t st);
 int f32_to_bf16(const float* in, void* out, long n, float scale, hipStream_t st);
+int bf16_to_f32(const void* in, float* out, long n, hipStream_t st);
 int dropout(const void* in, void* out, long n, float p, uint64_t seed, hipStream_t st);
 int relu_gate(const void* x, const void* gate, void* out, long n, hipStream_t st);
 // data.hip (row f3)

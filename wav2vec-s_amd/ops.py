@@ -5,6 +5,7 @@ hand-written HIP kernel.  Nothing falls back to torch ops or to the CPU: a missi
 rejected call raises ``W2vsError``.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -174,7 +175,7 @@ GEMM_TIMER = _GemmTimer()
 
 
 def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, bias=None, aux=None,
-            epi=EPI_NONE, a_off=0, batch=1, sA=0, sB=0, sC=0, a_bytes=0, b_bytes=0, c_elems=0, alpha=1.0):
+            epi=EPI_NONE, a_off=0, batch=1, sA=0, sB=0, sC=0, a_bytes=0, b_bytes=0, c_elems=0, alpha=1.0, zk_col=0, zk_k=0):
     d = GemmDesc()
     d.A, d.B, d.C, d.C2, d.Cf, d.bias, d.aux = _p(a), _p(b), _p(out), _p(out2), _p(out_f32), _p(bias), _p(aux)
     d.M, d.N, d.K, d.batch = M, N, K, batch
@@ -182,6 +183,7 @@ def gemm_nt(a, b, *, M, N, K, lda, ldb, ldc, out=None, out2=None, out_f32=None, 
     d.sA, d.sB, d.sC = sA, sB, sC
     d.a_bytes, d.b_bytes, d.c_elems = a_bytes, b_bytes, c_elems
     d.epi, d.alpha = epi, alpha
+    d.zk_col, d.zk_k = zk_col, zk_k
     ev = GEMM_TIMER.begin()
     _lib.call("w2vs_gemm_nt", C.byref(d), _stream())
     GEMM_TIMER.end(ev, epi, 2.0 * M * N * K * batch)
@@ -310,10 +312,18 @@ def transpose2d(x, batch=1):
     return out
 
 
-def f32_to_bf16(x, scale=1.0):
-    _chk(x, torch.float32, "x")
-    out = empty((x.shape), BF16, x.device)
+def f32_to_bf16(x, scale=1.0, out=None):
+    _chk(x, torch.float32, "x"); _chk(out, BF16, "out")
+    if out is None:
+        out = empty((x.shape), BF16, x.device)
     _lib.call("w2vs_f32_to_bf16", _p(x), _p(out), x.numel(), scale, _stream())
+    return out
+
+
+def bf16_to_f32(x, out):
+    """out[i] = float(x[i]): the unpack half of a bf16-compressed gradient exchange."""
+    _chk(x, BF16, "x"); _chk(out, torch.float32, "out")
+    _lib.call("w2vs_bf16_to_f32", _p(x), _p(out), x.numel(), _stream())
     return out
 
 
@@ -344,6 +354,7 @@ def conv_cl_fwd(x, w2, k, s, bias=None, *, gelu=True, save_pre=True, save_grad=F
 
 
 _DGRAD_W = {}
+CONV_DGRAD_SKIP = os.environ.get("W2VS_CONV_DGRAD_SKIP", "1") != "0"    # A/B: 0 = multiply with the structural zero block too
 
 
 def conv_dgrad_weight_items(key, w2, k, s):
@@ -401,9 +412,11 @@ def conv_cl_dgrad(dy, w2, k, s, Lin, *, dgelu_aux=None, mul_aux=None, wprep=None
             bt[0, :, 1] = wt3[0]
             bt[1, :, 1] = wt3[1]
         P = (Lin + 1) // 2
+        # the [0 | W1^T] row half: output columns >= Cin never see K indices < Cout (zk_*: those tiles skip half their K loop)
+        zk = dict(zk_col=Cin, zk_k=Cout) if (CONV_DGRAD_SKIP and Cin % 128 == 0 and Cout % 128 == 0) else {}
         gemm_nt(dy, bt, M=P, N=2 * Cin, K=2 * Cout, lda=Cout, ldb=2 * Cout, ldc=2 * Cin, out=dx, aux=dgelu_aux,
                 epi=epi, a_off=-Cout, batch=B, sA=Lout * Cout, sC=Lin * Cin, a_bytes=Lout * Cout * 2,
-                c_elems=Lin * Cin)
+                c_elems=Lin * Cin, **zk)
     else:
         raise W2vsError("conv dgrad is built for (k,s) in {(2,2),(3,2)}; got (%d,%d)" % (k, s))
     return dx

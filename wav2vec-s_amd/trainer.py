@@ -133,7 +133,8 @@ class GradExchange:
     so the per-collective latency of a ring over 8 GPUs is amortised.  SUM only - the division by the
     global sample_size happens once, inside the fused Adam kernel."""
 
-    def __init__(self, flat: torch.Tensor, dist_module, bucket_elems: int = 16 << 20, group=None, flush_at: int = -1):
+    def __init__(self, flat: torch.Tensor, dist_module, bucket_elems: int = 16 << 20, group=None, flush_at: int = -1,
+                 wire_dtype: str = "fp32"):
         self.flat, self.dist, self.bucket, self.group = flat, dist_module, int(bucket_elems), group
         self.on_launch = None   # optional callback(lo, hi, work): TrainStep chains the optimizer update of a range behind it
         # flush_at: once a milestone reaches this offset, everything pending goes out even if it is less than a bucket.
@@ -141,13 +142,23 @@ class GradExchange:
         # backward (~2 ms) remains then travels DURING that backward, and the collective left for after the backward is
         # the extractor's 4.2 M elements instead of up to a whole bucket.
         self.flush_at = int(flush_at)
+        # wire_dtype "bf16": each range is cast into a bf16 image of the arena (w2vs_f32_to_bf16), THAT is all-reduced -
+        # half the bytes on xGMI: 180.6 MB per update for the base model, what the reference moves, which reduces in the
+        # model dtype (fs/distributed/legacy_distributed_data_parallel.py:100-115) - and cast back into the fp32 arena once
+        # its collective is done.  Local accumulation (update_freq micro-batches, atomics) stays fp32 either way; only the
+        # cross-rank sum is rounded.  "fp32" (default) all-reduces the arena in place: exact sums, twice the bytes.
+        if wire_dtype not in ("fp32", "bf16"):
+            raise ValueError("wire_dtype must be 'fp32' or 'bf16'")
+        self.wire_dtype = wire_dtype
+        self.wire = torch.empty(flat.numel(), dtype=BF16, device=flat.device) if wire_dtype == "bf16" else None
         self.hi = flat.numel()
         self.works = []
+        self.unpack = []        # bf16 wire: (lo, hi, work) whose result is still in the bf16 image
         self.launched = []      # (lo, hi) ranges, for tests / tracing
 
     def begin_step(self):
         self.hi = self.flat.numel()
-        self.works, self.launched = [], []
+        self.works, self.launched, self.unpack = [], [], []
 
     def on_ready(self, offset: int):
         """Elements [offset, numel) are final.  Launch whole buckets; keep a remainder < bucket for later
@@ -163,10 +174,27 @@ class GradExchange:
             self._launch(offset, self.hi)
             self.hi = offset
 
+    def _cast(self, lo, hi, back):
+        src, dst = (self.wire, self.flat) if back else (self.flat, self.wire)
+        if self.flat.is_cuda:
+            (ops.bf16_to_f32 if back else ops.f32_to_bf16)(src[lo:hi], out=dst[lo:hi])
+        else:
+            dst[lo:hi].copy_(src[lo:hi])          # gloo / CPU tests: a converting copy
+
     def _launch(self, lo, hi):
         if hi <= lo:
             return
-        w = self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.wire is None:
+            w = self.dist.all_reduce(self.flat[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            # ranges whose collective has already finished are unpacked now, beside the backward, not after it
+            while self.unpack and self.unpack[0][2].is_completed():
+                l0, h0, w0 = self.unpack.pop(0)
+                w0.wait()
+                self._cast(l0, h0, back=True)
+            self._cast(lo, hi, back=False)
+            w = self.dist.all_reduce(self.wire[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.unpack.append((lo, hi, w))
         self.works.append(w)
         self.launched.append((lo, hi))
         if self.on_launch is not None:
@@ -177,7 +205,9 @@ class GradExchange:
         self.on_ready(0)
         for w in self.works:
             w.wait()
-        self.works = []
+        for lo, hi, _ in self.unpack:
+            self._cast(lo, hi, back=True)
+        self.works, self.unpack = [], []
 
 
 class PolynomialDecayLRSchedule:
@@ -218,7 +248,7 @@ class TrainStep:
 
     def __init__(self, model, criterion, world_size=1, use_optimizer=True, lr=5e-4, betas=(0.9, 0.98), eps=1e-6,
                  weight_decay=0.01, clip_norm=0.0, arena_gib=12.0, update_freq=1, lr_scheduler=None, group=None,
-                 check_finite=True):
+                 check_finite=True, wire_dtype="fp32"):
         self.model, self.criterion, self.world = model, criterion, world_size
         self.flat = FlatParams(model)
         self.use_optimizer = use_optimizer
@@ -237,7 +267,7 @@ class TrainStep:
             if tail >= self.flat.arena.numel:
                 tail = engine.milestone_offset(self.flat.arena, "encoder.")
             self.exchange = GradExchange(self.flat.arena.flat, dist, group=group,
-                                         flush_at=tail if tail < self.flat.arena.numel else -1)
+                                         flush_at=tail if tail < self.flat.arena.numel else -1, wire_dtype=wire_dtype)
             # The pairwise K split of the grouped weight-gradient launch has workgroups WAIT on their partner: sound only while
             # the whole grid is co-resident, which nobody can promise once RCCL's kernels share the chip with the backward.
             # An odd (LayerDrop-ped) layer then takes the 256 x 128 single-writer group instead (~10 us per step).
