@@ -205,6 +205,7 @@ int64_t w2vs_attn_drop_bits_bytes(int32_t B, int32_t H, int32_t N, int32_t Nq);
  * projection, block attention, out_proj, dropout+residual+LayerNorm, fc1+GELU, fc2,
  * dropout+residual+LayerNorm enqueued by ONE call (and the whole backward by one more), so the host
  * issues 2 calls per layer.  R = B*N rows.  Saved activations are written by fwd and read by bwd.
+ * hpre = NULL: inference form of the forward (gelu'(fc1 pre-activation) is not stored; layer_bwd then refuses the descriptor).
  * wqkv [3E,E] / bqkv [3E] = q,k,v projections stacked.  Scratch (bwd): ws_e0..2 [R,E], ws_f [R,F],
  * ws_qkv [R,3E], delta [B,H,N] fp32, wt_scratch >= max(3E*E, E*F) bf16.  Gradients accumulate.      */
 typedef struct w2vs_layer_desc {

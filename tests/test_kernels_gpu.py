@@ -639,7 +639,7 @@ def test_transpose_multi(ops):
 
 
 # ------------------------------------------------------------------------------------------ GEMM kernel variants
-NT_VARIANTS = [(0, 0), (1, 0), (2, 0), (3, 256), (3, 192), (3, 160), (5, 256), (5, 192), (5, 160),
+NT_VARIANTS = [(0, 0), (1, 0), (2, 0), (3, 256), (3, 192), (3, 160), (3, 64), (5, 256), (5, 192), (5, 160),
                (3, 1160), (5, 1160), (8, 256), (8, 320), (-1, 0)]     # 1160 = the 160 x 256 tile (round 2); 8 = the 8-phase
                                                                         # kernel (round 3; K % 64 == 0); (-1, 0) = automatic choice
 

@@ -263,3 +263,50 @@ def test_inference_weight_cache_follows_every_kind_of_weight_change():
     q_w.data.mul_(0.5)
     model.train(); model.eval()                                    # a mode round trip drops the cache as well
     assert torch.equal(run(), c)
+
+
+def test_streaming_calls_replay_a_graph_per_shape():
+    """Inference calls without a padding mask are captured once per input shape into a HIP graph and replayed
+    (BlockWiseWav2Vec2Model.graph_calls): the replay must equal the eager call bit for bit - on new audio of the same shape, on
+    a second shape, interleaved - must follow a weight change, and must not be used under autograd or with a padding mask."""
+    from wav2vec_s_amd import streaming
+    kw = dict(extractor_mode="layer_norm", encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+              encoder_attention_heads=2, final_dim=128, quantize_targets=True, feature_grad_mult=0.1, dropout=0.0,
+              attention_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0, latent_vars=40,
+              conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2", main_context=8, right_context=4,
+              pos_type="sin", load_pretrained_model_from=None)
+    torch.manual_seed(5)
+    model = streaming.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(**kw)).to(BF).cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    srcs = {L: [torch.randn(1, L, generator=g).to(BF).cuda() for _ in range(3)] for L in (16000, 24320)}
+
+    def run(src, graphs, finished=False):
+        model.graph_calls = graphs
+        try:
+            with torch.no_grad():
+                out = model(src, None, None, finished, True)
+            return out["encoder_out"][0].clone(), out["encoder_padding_mask"][0].clone()
+        finally:
+            model.graph_calls = True
+    eager = {(L, i): run(s, False) for L, ss in srcs.items() for i, s in enumerate(ss)}
+    for rep in range(2):
+        for i in range(3):
+            for L in (16000, 24320):                                   # shapes interleaved: each replays its own graph
+                x, pad = run(srcs[L][i], True)
+                assert torch.equal(x, eager[(L, i)][0]) and torch.equal(pad, eager[(L, i)][1]), (rep, i, L)
+    assert len([k for k in model._graphs if isinstance(k, tuple)]) == 2
+    xf, _ = run(srcs[16000][0], True, finished=True)                   # the trimming is outside the graph: same graph, r more frames
+    assert xf.shape[0] == eager[(16000, 0)][0].shape[0] + 4 and torch.equal(xf[:-4], eager[(16000, 0)][0])
+    with torch.no_grad():
+        model.encoder.layers[1].fc1.weight.mul_(1.25)                  # a weight changes: the next call must see it
+    e2 = run(srcs[16000][1], False)
+    x2, _ = run(srcs[16000][1], True)
+    assert torch.equal(x2, e2[0]) and not torch.equal(x2, eager[(16000, 1)][0])
+    # never under autograd, never with a padding mask
+    n_before = len([k for k in model._graphs if isinstance(k, tuple)])
+    out = model(srcs[16000][2], None, None, False, True)
+    assert out["encoder_out"][0].requires_grad
+    pm = torch.zeros(1, 16000, dtype=torch.bool, device="cuda")
+    with torch.no_grad():
+        out = model(srcs[16000][2], pm, None, False, True)
+    assert len([k for k in model._graphs if isinstance(k, tuple)]) == n_before

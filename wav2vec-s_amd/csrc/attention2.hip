@@ -28,6 +28,16 @@
 #include <vector>
 #include "attn_common.h"
 
+// Timing-only ablations of the forward kernel (make ablation ABL="-DW2VS_ATTN_ABL=n"; never in libw2vs.so; results WRONG):
+//   bit 0: no K / V global loads inside the loop (the first sub-tile's registers are reused)
+//   bit 1: no MFMAs            bit 2: no LDS round trip of K / V (fragments are read from whatever the tiles hold)
+//   bit 3: the loop body never runs (prologue + merge only)
+#if defined(W2VS_ABLATION) && defined(W2VS_ATTN_ABL)
+#define W2VS_AABL W2VS_ATTN_ABL
+#else
+#define W2VS_AABL 0
+#endif
+
 namespace w2vs {
 namespace {
 
@@ -231,25 +241,28 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qs + uswz(r32, (2 * s + hh) * 8));
-  while (pos < tl.nT) {
+  while (pos < tl.nT && !(W2VS_AABL & 8)) {
     const int k0 = tile_of(pos) * 32;
     const int nxt = pos + NW;
     // one register set: the V registers are free again once they sit in LDS, the K registers once S is issued - the next
     // sub-tile's loads go out right there and have the softmax and the P.V product to land
     asm volatile("" ::: "memory");
+    if (!(W2VS_AABL & 4)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *(u32x4*)(Kw + uswz(vrow + 8 * j, vch * 8)) = kr[j];
-      *(u32x4*)(Vw + vswz(vrow + 8 * j, vch * 8)) = vr[j];
+      for (int j = 0; j < 4; ++j) {
+        *(u32x4*)(Kw + uswz(vrow + 8 * j, vch * 8)) = kr[j];
+        *(u32x4*)(Vw + vswz(vrow + 8 * j, vch * 8)) = vr[j];
+      }
     }
-    if (nxt < tl.nT) load_kv(tile_of(nxt));
+    if (!(W2VS_AABL & 1) && nxt < tl.nT) load_kv(tile_of(nxt));
     f32x16 S;
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8 kfr = *(const bf16x8*)(Kw + uswz(r32, (2 * s + hh) * 8));
-      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[s], S, 0, 0, 0);
+      if (!(W2VS_AABL & 2)) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[s], S, 0, 0, 0);
+      else S[s] += bf2f(kfr[0]);
     }
     if (!(k0 + 32 <= wfull)) {          // wave-uniform: boundary / right-context / padded tiles only
       const uint32_t pb = (kp || k0 + 32 > N) ? pad_bits(kp, k0, N, r32) : 0u;
@@ -310,8 +323,10 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
       const int dcol = (g & 1) * 16 + 4 * tp;
       const bf16x8 a0 = tr_pair(Vw + vswz(krow, dcol), Vw + vswz(krow + 8, dcol));
       const bf16x8 a1 = tr_pair(Vw + vswz(krow, 32 + dcol), Vw + vswz(krow + 8, 32 + dcol));
-      O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pb, O0, 0, 0, 0);
-      O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb, O1, 0, 0, 0);
+      if (!(W2VS_AABL & 2)) {
+        O0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, pb, O0, 0, 0, 0);
+        O1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb, O1, 0, 0, 0);
+      } else { O0[s2] += bf2f(a0[0]) * bf2f(pb[0]); O1[s2] += bf2f(a1[0]); }
     }
     pos = nxt;
   }

@@ -468,7 +468,8 @@ template <int N> __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcn
   else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else { static_assert(N == 0, "add the immediate to wait_vm"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 }
 // ---------------------------------------------------------------------------------------------
 // NT with dedicated loader waves: 256 x 128 x 64 tiles, 12 waves per workgroup = 8 consumers (64x64 each, the
@@ -1898,6 +1899,18 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
       const double t = (double)((t8 + 255) / 256) * (nkt * tk[c] * fill + 7.5 + (epi_is_save(d.epi) ? 4.0 : 0.0));
       if (t < best) { best = t; mode = 3; lc_h = hs[c]; }
     }
+    // Round 4: 64 x 128 tiles (2 consumer waves + 4 loaders, 72 KiB of LDS: two workgroups per CU) for SHORT outputs - the
+    // streaming encoder's M = B x N' of a few hundred rows, where 160-row tiles leave three quarters of the chip idle behind a
+    // 48-K-tile loop (fc2 at a 10 s prefix: 30 tiles, 32 us).  Taken only below one chip's worth of 64-row tiles x 2.
+    static const int lc64_env = [] { const char* e = getenv("W2VS_LC64"); return e ? atoi(e) : 1; }();
+    {
+      const long t64 = (long)((d.N + 127) / 128) * ((d.M + 63) / 64) * nbz;
+      if (lc64_env && t64 <= 512) {
+        const double fill = std::max(0.5, std::min(1.0, (double)t64 / 512.0));
+        const double t = nkt * 0.42 * fill + 6.0 + (epi_is_save(d.epi) ? 2.0 : 0.0);
+        if (t < best) { best = t; mode = 3; lc_h = 64; }
+      }
+    }
   }
   if (mode_env >= 0) mode = mode_env;
   if (g_force_nt_mode >= 0) mode = g_force_nt_mode;
@@ -1913,7 +1926,8 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   if (mode == 8) {
     if (!p_ok || (d.K % 64) || ((uintptr_t)d.bias % 16)) return set_error("gemm_nt: the 8-phase kernel needs K % 64 == 0, N % 8 == 0, ldc % 8 == 0, 16-byte aligned outputs / bias");
     if (lc_h != 256 && lc_h != 320) return set_error("gemm_nt: 8-phase tile height must be 256 or 320");
-  } else if (lc_h != 256 && lc_h != 192 && lc_h != 160) return set_error("gemm_nt: tile height must be 256, 192 or 160");
+  } else if (lc_h == 64 && mode != 3) { lc_h = 160;        // the 64-row tile exists for the one-tile-per-workgroup kernel only
+  } else if (lc_h != 256 && lc_h != 192 && lc_h != 160 && lc_h != 64) return set_error("gemm_nt: tile height must be 256, 192, 160 or 64");
   static const bool nt_log = getenv("W2VS_GEMM_LOG") != nullptr;      // shapes and the form chosen for them, one line per launch
   if (nt_log) fprintf(stderr, "gemm_nt M %d N %d K %d batch %d epi %d lda %ld -> mode %d tile %dx%d\n", d.M, d.N, d.K, (int)d.batch, d.epi,
                       (long)d.lda, mode, mode >= 3 ? lc_h : 128, (wide || mode == 8) ? 256 : 128);
@@ -1943,6 +1957,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     } else if (mode == 3 && wide) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 2, 5, 4>), grid8, dim3(768), 0, s, p); \
     else if (mode == 3 && lc_h == 256) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 4, 4>), grid8, dim3(768), 0, s, p); \
     else if (mode == 3 && lc_h == 192) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 3, 4>), grid8, dim3(640), 0, s, p); \
+    else if (mode == 3 && lc_h == 64) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 1, 4>), grid8, dim3(384), 0, s, p); \
     else if (mode == 3) hipLaunchKernelGGL((gemm_nt_lc_kernel<E, 2, 5>), grid8, dim3(512), 0, s, p); \
     else if (mode == 2) hipLaunchKernelGGL((gemm_nt_kernel<E, 2>), grid, block, 0, s, p);     \
     else if (mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<E, 1>), grid, block, 0, s, p);     \

@@ -74,7 +74,7 @@ static int layer_check(const w2vs_layer_desc& L) {
   if (!L.x_in || !L.wqkv || !L.bqkv || !L.wo || !L.bo || !L.w1 || !L.b1 || !L.w2 || !L.b2 || !L.ln1_g || !L.ln1_b ||
       !L.ln2_g || !L.ln2_b)
     return set_error("layer: null weight/input pointer");
-  if (!L.qkv || !L.ctx || !L.lse || !L.s1 || !L.mean1 || !L.rstd1 || !L.x1 || !L.hpre || !L.h || !L.s2 || !L.mean2 ||
+  if (!L.qkv || !L.ctx || !L.lse || !L.s1 || !L.mean1 || !L.rstd1 || !L.x1 || !L.h || !L.s2 || !L.mean2 ||
       !L.rstd2 || !L.x_out || !L.tmp)
     return set_error("layer: null activation pointer");
   return 0;
@@ -119,7 +119,8 @@ int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
   n1.x = L.tmp; n1.res = xin; n1.gamma = L.ln1_g; n1.beta = L.ln1_b; n1.y = L.x1; n1.sum_out = L.s1;
   n1.mean = L.mean1; n1.rstd = L.rstd1; n1.rows = Rt; n1.C = E; n1.p_drop = L.p_drop; n1.seed = L.seed_drop1;
   TRY(ln_fwd(n1, s));
-  TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, Rt, F, E, EPI_BIAS_GELU_SAVEG, s));   // hpre <- gelu'(pre)
+  // hpre <- gelu'(pre) for the backward; an inference call passes hpre = NULL and skips that store (half the epilogue's bytes)
+  TRY(lin_fwd(L.x1, L.w1, L.b1, L.h, L.hpre, Rt, F, E, L.hpre ? EPI_BIAS_GELU_SAVEG : EPI_BIAS_GELU, s));
   TRY(lin_fwd(L.h, L.w2, L.b2, L.tmp, nullptr, Rt, E, F, EPI_BIAS, s));
   LnFwdDesc n2{};
   n2.x = L.tmp; n2.res = L.post_ln ? L.x1 : L.s1; n2.gamma = L.ln2_g; n2.beta = L.ln2_b; n2.y = L.x_out; n2.sum_out = L.s2;
@@ -130,6 +131,7 @@ int layer_fwd(const w2vs_layer_desc& L, hipStream_t s) {
 
 int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   TRY(layer_check(L));
+  if (!L.hpre) return set_error("layer_bwd: the forward ran without hpre (inference form): nothing to differentiate");
   TRY(sel_check(L));
   const bool pre_t = L.wqkv_t && L.wo_t && L.w1_t && L.w2_t;
   if (!L.post_ln && !L.d_stream_in) return set_error("layer_bwd: the pre-LN form needs d_stream_in");

@@ -98,9 +98,14 @@ def _pname(i, tail):
 
 def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: bool, mask: bool,
             features_only: bool, padding_mask: Optional[torch.Tensor], draws: Draws, rng_base: int,
-            tau: float, packed: Optional[Dict[str, torch.Tensor]] = None) -> State:
+            tau: float, packed: Optional[Dict[str, torch.Tensor]] = None, upload_cache: Optional[dict] = None,
+            need_backward: bool = True) -> State:
     """W: name -> bf16 contiguous device tensor (reference state_dict names).  source [B, L] bf16.
-    packed: conv weights already tap-major [Cout, k*Cin] (flat parameter storage), else packed here."""
+    packed: conv weights already tap-major [Cout, k*Cin] (flat parameter storage), else packed here.
+    upload_cache: a dict the caller keeps (the streaming twin): without a mask and without padding every index array of the
+    step is a function of the shape alone, so its device copy is made once per (B, L, m, r) and reused - a call then contains
+    no host-to-device copy at all (which is also what lets it be captured into a HIP graph).
+    need_backward = False (no input of the call requires a gradient): the layers skip what only a backward would read."""
     st = State()
     packed = packed or {}
     st.packed = {}
@@ -191,7 +196,17 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         if up["neg"] is None:
             del up["neg"]
             st.neg = neg
-    st.up = _upload(up, dev)
+    ckey = None
+    if upload_cache is not None and mask_np is None and pad_frames is None and features_only:
+        ckey = (B, L, m_ctx, r_ctx, mult, str(dev))
+    if ckey is not None and ckey in upload_cache:
+        st.up = upload_cache[ckey]
+    else:
+        st.up = _upload(up, dev)
+        if ckey is not None:
+            if len(upload_cache) >= 256:
+                upload_cache.pop(next(iter(upload_cache)))
+            upload_cache[ckey] = st.up
     if "neg" in st.up:
         st.neg = st.up["neg"]
     mask_dev = st.up.get("mask")
@@ -321,6 +336,8 @@ def forward(cfg, W: Dict[str, torch.Tensor], source: torch.Tensor, *, training: 
         for f_, cols in (("qkv", 3 * E), ("ctx", E), ("s1", E), ("x1", E), ("hpre", F), ("h", F), ("s2", E), ("x_out", E)):
             setattr(d, f_, base16 + 2 * o)
             o += R * cols
+        if not need_backward:
+            d.hpre = None                  # inference: fc1's epilogue does not store gelu'(pre)
         base32 = slab32.data_ptr() + 4 * j * per32
         d.lse = base32
         d.mean1, d.rstd1 = base32 + 4 * (B * H * N), base32 + 4 * (B * H * N + R)

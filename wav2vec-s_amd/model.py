@@ -214,7 +214,8 @@ class _HotPath(torch.autograd.Function):
         st = engine.forward(cfg, W, src, training=model.training, mask=mask, features_only=features_only,
                             padding_mask=padding_mask, draws=draws, rng_base=base,
                             tau=float(model.quantizer.curr_temp) if model.quantizer is not None else 1.0,
-                            packed=packed)
+                            packed=packed, upload_cache=getattr(model, "_upload_cache", None),
+                            need_backward=any(ctx.needs_input_grad))
         ctx.st = st
         ctx.model = model
         if model._after_forward is not None and not features_only:
