@@ -215,7 +215,7 @@ class _HotPath(torch.autograd.Function):
                             padding_mask=padding_mask, draws=draws, rng_base=base,
                             tau=float(model.quantizer.curr_temp) if model.quantizer is not None else 1.0,
                             packed=packed, upload_cache=getattr(model, "_upload_cache", None),
-                            need_backward=any(ctx.needs_input_grad))
+                            need_backward=bool(getattr(model, "_grad_mode", True)) and any(ctx.needs_input_grad))
         ctx.st = st
         ctx.model = model
         if model._after_forward is not None and not features_only:
@@ -534,6 +534,7 @@ class Wav2Vec2Model(nn.Module):
         draws = self._draws if self._draws is not None else engine.Draws()
         self._draws = None
         params = self._named_params_cached()[1]
+        self._grad_mode = torch.is_grad_enabled()      # (inside Function.forward grad mode is always off; needs_input_grad ignores it)
         out = _HotPath.apply(self, source, padding_mask, mask, features_only, draws, *params)
         st = self._last_state
         pm = padding_mask
