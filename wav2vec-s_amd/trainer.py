@@ -359,6 +359,15 @@ class TrainStep:
         self.model._on_grad_ready = self.exchange.on_ready if (self.exchange is not None and last) else None
         with ROCTX.range("forward"):
             loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
+        ss_work = None
+        if self.exchange is not None and last:
+            # the global sample_size (mask lengths can differ across ranks) is known as soon as the closing micro-batch's
+            # forward is: its scalar all-reduce travels under the backward instead of between the last bucket and Adam.
+            # torch.full is a fill kernel with the value as a launch argument; torch.tensor([...], device=) would be a
+            # synchronous pageable H2D copy on this stream, i.e. the host would wait for the GPU every step
+            ss = torch.full((1,), float(self.ss_acc + sample_size), device=f.p16.device, dtype=torch.float32)
+            ss_work = self.dist.all_reduce(ss, group=self.group, async_op=True)
+            self.ss_dev = ss
         if self._one is None or self._one.device != loss.device:
             self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
         with ROCTX.range("backward"):
@@ -371,12 +380,8 @@ class TrainStep:
         if self.exchange is not None:
             with ROCTX.range("reduce-grads"):
                 self.exchange.finish()
-            # the global sample_size: mask lengths can differ across ranks (own batches, own masks)
-            # torch.full is a fill kernel with the value as a launch argument; torch.tensor([...], device=) would be a
-            # synchronous pageable H2D copy on this stream, i.e. the host would wait for the whole backward every step
-            ss = torch.full((1,), float(self.ss_acc), device=f.p16.device, dtype=torch.float32)
-            self.dist.all_reduce(ss, group=self.group)
-            self.ss_dev = ss
+                if ss_work is not None:
+                    ss_work.wait()
             total = None
         if self.use_optimizer:
             if self._before_optimizer is not None:
