@@ -71,6 +71,10 @@ typedef struct w2vs_gemm_desc {
    * The (3,2)-conv input gradient is such a product: pair p = [dY[p-1] | dY[p]] . [[W2, 0], [W0, W1]] - a quarter of its
    * multiply-adds are with that zero block.  Results are identical with and without the promise when it is true. */
   int32_t zk_col, zk_k;
+  /* TN only: 1 = Cf = alpha * A^T B instead of Cf += ... (colsum stays an accumulation).  The grouped single-writer launches
+   * then skip the read of their output tile, and a trainer need not zero those gradient ranges at the start of a step; the
+   * general kernels (atomics / partial-tile sums) clear the target first.  Needs ldc == N, no batch. */
+  int32_t overwrite;
 } w2vs_gemm_desc;
 int w2vs_gemm_nt(const w2vs_gemm_desc* d, void* stream);
 /* Tests / tuning: force a kernel variant process-wide (not thread safe).  nt_mode: -1 auto, 0/1/2 the 128x128 forms
@@ -245,6 +249,9 @@ typedef struct w2vs_layer_desc {
    * ws_e0 (d fc2-out), ws_qkv (d qkv), ws_e3 (d out_proj-out) until the caller passes this descriptor to w2vs_layer_wgrads -
    * the next layer's backward must therefore run on OTHER ws_f / ws_e0 / ws_qkv / ws_e3 buffers */
   int32_t defer_wgrads;
+  /* 1: the deferred weight gradients of this layer OVERWRITE g_wqkv / g_wo / g_w1 / g_w2 (w2vs_gemm_desc.overwrite; the bias
+   * gradients still accumulate): the first micro-batch of an update, whose caller then does not zero those ranges */
+  int32_t wgrad_overwrite;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

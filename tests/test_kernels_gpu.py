@@ -831,6 +831,18 @@ def test_gemm_tn_group_pair_split_needs_co_residency():
             return lib.w2vs_gemm_last_group_form(), ws, bs
         finally:
             lib.w2vs_gemm_tn8_max_split(2)
+    def run_overwrite(num_cu, max_split):
+        """The same launch with w2vs_gemm_desc.overwrite = 1 into NaN-filled targets: C = A^T B, the bias sums still accumulate."""
+        lib.w2vs_gemm_tn8_max_split(max_split)
+        try:
+            ws = [torch.full((dy.shape[1], x.shape[1]), float("nan"), device="cuda") for dy, x in zip(dys, xs)]
+            bs = [torch.zeros(dy.shape[1], device="cuda") for dy in dys]
+            ops.gemm_tn_group([dict(a=dy, b=x, out_f32=w, M=dy.shape[1], N=x.shape[1], K=R, lda=dy.shape[1], ldb=x.shape[1],
+                                    ldc=x.shape[1], colsum_out=b, overwrite=1) for dy, x, w, b in zip(dys, xs, ws, bs)], num_cu=num_cu)
+            torch.cuda.synchronize()
+            return lib.w2vs_gemm_last_group_form(), ws, bs
+        finally:
+            lib.w2vs_gemm_tn8_max_split(2)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     form, w0, b0 = run(cus, 2)
     assert form == 14 if cus >= 216 else form != 14            # 108 tiles of 256^2 x 2: needs 216 co-resident workgroups
@@ -839,6 +851,10 @@ def test_gemm_tn_group_pair_split_needs_co_residency():
         assert f_ in forms, (num_cu, max_split, f_)
         for a, b in zip(w0 + b0, w_ + b_):
             assert rel(b, a) < 2e-5, (num_cu, max_split, rel(b, a))
+        fo, wo, bo = run_overwrite(num_cu, max_split)      # every form: the overwriting launch equals the accumulation into zeros
+        assert fo == f_
+        for a, b in zip(w0 + b0, wo + bo):
+            assert not bool(torch.isnan(b).any()) and rel(b, a) < 2e-5, (num_cu, max_split, "overwrite")
 
 
 def test_group_attention_beyond_one_record_table(ops):

@@ -16,7 +16,7 @@ class GemmDesc(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("batch", i32),
                 ("lda", i64), ("ldb", i64), ("ldc", i64), ("a_off", i64),
                 ("sA", i64), ("sB", i64), ("sC", i64), ("a_bytes", i64), ("b_bytes", i64), ("c_elems", i64),
-                ("epi", i32), ("alpha", f32), ("colsum", vp), ("ws", vp), ("ws_bytes", i64), ("zk_col", i32), ("zk_k", i32)]
+                ("epi", i32), ("alpha", f32), ("colsum", vp), ("ws", vp), ("ws_bytes", i64), ("zk_col", i32), ("zk_k", i32), ("overwrite", i32)]
 
 
 class LnFwdDesc(C.Structure):
@@ -79,7 +79,7 @@ class LayerDesc(C.Structure):
                     "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64), ("sel_idx", vp), ("n_sel", i32),
                                                                             ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp), ("ws_e3", vp),
                                                                             ("stream_in", vp), ("d_stream_out", vp), ("d_stream_in", vp), ("drop_bits", vp),
-                                                                            ("defer_wgrads", i32)])
+                                                                            ("defer_wgrads", i32), ("wgrad_overwrite", i32)])
 
 
 class CollateDesc(C.Structure):

@@ -57,6 +57,7 @@ struct GemmP {
   float* colsum;              // TN only: optional out[m] += sum_k A[k, m]  (bias gradient)
   float* slab;                // TN loader/consumer: partial tiles [grid.z][M][N] instead of atomics into Cf
   float alpha;
+  int overwrite;              // TN single-writer kernels: Cf = alpha * acc instead of Cf += (the first writer of a zero-free arena)
   int zk_col, zk_kt;          // NT persistent kernels: tiles with n0 >= zk_col start at K tile zk_kt (B is zero before it); 0 = off
 };
 
@@ -1361,7 +1362,8 @@ __device__ __forceinline__ void tn_lc_body(const GemmP& p, const int tm_, const 
             f32x4{acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
       } else if (MODE == 2) {
         f32x4* dst = (f32x4*)(p.Cf + (long)row * p.ldc + col);
-        f32x4 o = *dst;
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!p.overwrite) o = *dst;            // workgroup-uniform
         o[0] += acc[i][j][0] * p.alpha; o[1] += acc[i][j][1] * p.alpha; o[2] += acc[i][j][2] * p.alpha; o[3] += acc[i][j][3] * p.alpha;
         *dst = o;
       } else {
@@ -1693,7 +1695,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
           const int row = m0 + wr * 128 + mh * 64 + ((i + wc) & 3) * 16 + fr, col = n0 + wc * 64 + j * 16 + fq * 4;
           if (row >= p.M || col >= p.N) continue;      // N % 8 == 0: the four columns are in or out together
           f32x4* dst = (f32x4*)(p.Cf + (long)row * p.ldc + col);
-          f32x4 o = *dst;
+          f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!p.overwrite) o = *dst;          // workgroup-uniform: the first writer of a step skips the read (and nobody zeroed it)
           o[0] += acc[mh][i][j][0] * p.alpha; o[1] += acc[mh][i][j][1] * p.alpha;
           o[2] += acc[mh][i][j][2] * p.alpha; o[3] += acc[mh][i][j][3] * p.alpha;
           *dst = o;
@@ -1987,6 +1990,10 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   if (int e = check_common(d)) return e;
   if (!d.Cf) return set_error("gemm_tn: needs an fp32 accumulation target");
   if ((d.M % 8) || (d.N % 8)) return set_error("gemm_tn: M and N must be multiples of 8");
+  if (d.overwrite) {       // the general kernels accumulate (atomics / slab sums): an overwriting call clears its target first
+    if (d.ldc != d.N || d.sC != 0) return set_error("gemm_tn: overwrite needs a contiguous, unbatched target (ldc == N)");
+    if (hipMemsetAsync(d.Cf, 0, (size_t)d.M * d.N * sizeof(float), s) != hipSuccess) return set_error("gemm_tn: memset failed");
+  }
   GemmP p{};
   p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.Cf = d.Cf;
   p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.a_off = d.a_off; p.alpha = d.alpha;
@@ -2116,7 +2123,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
     GemmP& p = gp[i];
     p.A = (const bf16*)d.A; p.B = (const bf16*)d.B; p.Cf = d.Cf;
     p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.a_off = d.a_off; p.alpha = d.alpha;
-    p.colsum = d.colsum;
+    p.colsum = d.colsum; p.overwrite = d.overwrite;      // the single-writer group kernels honour it; the fallbacks memset (gemm_tn)
     const long a_ext = d.a_bytes ? d.a_bytes : ((long)d.a_off + (long)(d.K - 1) * d.lda + d.M) * 2;
     const long b_ext = d.b_bytes ? d.b_bytes : ((long)(d.K - 1) * d.ldb + d.N) * 2;
     if (a_ext <= 0 || a_ext >= 0x7FFFFFF0L || b_ext >= 0x7FFFFFF0L) return set_error("gemm_tn: operand extent must be < 2 GiB per batch");

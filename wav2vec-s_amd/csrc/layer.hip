@@ -65,6 +65,7 @@ static void layer_wgrad_descs(const w2vs_layer_desc& L, GemmDesc* g) {
   g[1] = wgrad_desc(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, L.tn_ws, L.tn_ws_bytes);             // fc2   [E,F]
   g[2] = wgrad_desc(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, L.tn_ws, L.tn_ws_bytes); // qkv   [3E,E]
   g[3] = wgrad_desc(L.ws_e3, L.ctx, L.g_wo, L.g_bo, R, E, E, L.tn_ws, L.tn_ws_bytes);           // out_proj [E,E]
+  for (int i = 0; i < 4; ++i) g[i].overwrite = L.wgrad_overwrite ? 1 : 0;
 }
 
 static int layer_check(const w2vs_layer_desc& L) {

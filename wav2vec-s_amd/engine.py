@@ -578,11 +578,34 @@ def _linear_bwd(dy, x, w_name, b_name, W, A, *, need_dx=True, dgelu_aux=None, ad
     return ops.linear_dgrad(dy, wt, dgelu_aux=dgelu_aux, add_aux=add_aux)
 
 
-def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None, d_out=None, on_ready=None):
+def wgrad_overwrite_ranges(st: State, A: Arena):
+    """Arena ranges (offset, numel) that ``backward(..., overwrite_wgrads=True)`` will WRITE rather than add to: the four weight
+    matrices of every encoder layer whose weight gradients are deferred into the grouped single-writer launches
+    (w2vs_layer_wgrads).  A trainer zeroes the rest of the arena only: the fill of these 85 M of the base model's 90 M
+    gradients (340 MB) and their read inside the weight-gradient kernels disappear from the step.  Empty when the step does
+    not defer (one kept layer, PAIR / GROUP switches off); the last layer in selected-rows mode is never deferred."""
+    if not (PAIR_WGRADS and GROUP_WGRADS and len(st.layers) > 1):
+        return []
+    E, F = st.cfg.encoder_embed_dim, st.cfg.encoder_ffn_embed_dim
+    out = []
+    for rec in st.layers:
+        if rec["desc"].sel_idx:
+            continue
+        pre = f"encoder.layers.{rec['li']}."
+        out.append((A.offsets[pre + "self_attn.q_proj.weight"][0], 3 * E * E))       # q | k | v weights are adjacent
+        for n in ("self_attn.out_proj.weight", "fc1.weight", "fc2.weight"):
+            off, numel, _ = A.offsets[pre + n]
+            out.append((off, numel))
+    return out
+
+
+def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None, d_out=None, on_ready=None,
+             overwrite_wgrads: bool = False):
     """Accumulates parameter gradients into the arena.  d_logits fp32 [B*M, K+1] (rows (b, m));
     d_pen = dLoss/d features_pen, d_prob_ppl = dLoss/d prob_perplexity as fp32 DEVICE scalars (read by
     the kernels, never by the host: no sync); d_out bf16 [B, T, E] for features_only.
-    on_ready(offset): called at milestones - every arena element at index >= offset is final."""
+    on_ready(offset): called at milestones - every arena element at index >= offset is final.
+    overwrite_wgrads: the ranges of ``wgrad_overwrite_ranges`` are written, not accumulated (the caller did not zero them)."""
     ready = on_ready if on_ready is not None else (lambda off: None)
     cfg, W = st.cfg, st.W
     B, T, C0, N, Tp = st.B, st.T, st.C0, st.N, st.Tp
@@ -693,6 +716,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
             d.ws_e3 = e3.data_ptr() if e3 is not None else None
             deferred = bool(pair and not d.sel_idx)
             d.defer_wgrads = 1 if deferred else 0
+            d.wgrad_overwrite = 1 if (deferred and overwrite_wgrads) else 0
             if deferred and (jj & 1):                      # consecutive layers alternate between the two operand sets
                 for f_ in ("ws_e0", "ws_f", "ws_qkv", "ws_e3"):
                     setattr(d, f_, set2[f_])

@@ -268,6 +268,9 @@ class _HotPath(torch.autograd.Function):
                 model._arena_layout = (key, (A.offsets, A.numel), {n: tuple(st.W[n].shape) for n in st.W})
             else:
                 A = engine.Arena(None, st.feats.device, layout=lay[1])
+        # trainer.TrainStep, first micro-batch of an update: it zeroed the arena EXCEPT engine.wgrad_overwrite_ranges
+        ow = bool(flat_mode and getattr(model, "_wgrad_overwrite", False))
+        model._wgrad_overwrite = False
         if st.features_only:
             engine.backward(st, A, d_out=grads[0].to(BF16).contiguous())
         elif ctx.fused is not None:
@@ -276,13 +279,14 @@ class _HotPath(torch.autograd.Function):
             if g is None or dl is None:
                 raise W2vsError("fused criterion: no gradient arrived for the loss (or the forward ran without grad)")
             dsc = ops.infonce_loss_bwd(g.detach().float().reshape(1).contiguous(), dl, c_pen, c_ppl)
-            engine.backward(st, A, d_logits=dl, d_pen=dsc[0:1], d_prob_ppl=dsc[1:2], on_ready=model._on_grad_ready)
+            engine.backward(st, A, d_logits=dl, d_pen=dsc[0:1], d_prob_ppl=dsc[1:2], on_ready=model._on_grad_ready,
+                            overwrite_wgrads=ow)
         else:
             d_logits, d_pen, d_ppl = grads[0], grads[1], grads[2]
             d_logits = torch.zeros_like(st.logits) if d_logits is None else d_logits.float().contiguous()
             fix = lambda t: None if t is None else t.detach().float().reshape(1).contiguous()  # noqa: E731
             engine.backward(st, A, d_logits=d_logits, d_pen=fix(d_pen), d_prob_ppl=fix(d_ppl),
-                            on_ready=model._on_grad_ready)
+                            on_ready=model._on_grad_ready, overwrite_wgrads=ow)
         if flat_mode:
             ctx.st = None
             return (None,) * (6 + len(names))   # gradients stay in the arena (see trainer.FlatParams)

@@ -236,6 +236,7 @@ def gemm_tn_group(problems, num_cu=256):
         d.lda, d.ldb, d.ldc = pr["lda"], pr["ldb"], pr["ldc"]
         d.alpha = pr.get("alpha", 1.0)
         d.colsum = _p(pr.get("colsum_out"))
+        d.overwrite = int(pr.get("overwrite", 0))
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4       # only used if the group falls back to single launches
         flops += 2.0 * d.M * d.N * d.K
     ev = GEMM_TIMER.begin()

@@ -56,6 +56,8 @@ class _Roctx:
 
 
 ROCTX = _Roctx()
+# W2VS_OVERWRITE_WGRADS=0: zero the whole arena at the start of an update and let every weight gradient accumulate (A/B)
+OVERWRITE_WGRADS = os.environ.get("W2VS_OVERWRITE_WGRADS", "1") != "0"
 
 
 class FlatParams:
@@ -93,8 +95,28 @@ class FlatParams:
         if hasattr(model, "register_load_state_dict_post_hook"):
             model.register_load_state_dict_post_hook(lambda _m, _inc: self.sync_master_from_model())
 
-    def zero_grad(self):
-        self.arena.flat.zero_()
+    def zero_grad(self, except_ranges=None):
+        """Zero the gradient arena; ``except_ranges`` [(offset, numel), ...] are left alone (engine.wgrad_overwrite_ranges:
+        the backward WRITES them).  The complement is cleared through one multi-tensor fill; its views are cached per set of
+        ranges (LayerDrop makes a dozen different ones)."""
+        if not except_ranges:
+            self.arena.flat.zero_()
+            return
+        key = tuple(except_ranges)
+        cache = self.__dict__.setdefault("_gap_views", {})
+        views = cache.get(key)
+        if views is None:
+            views, pos = [], 0
+            for off, numel in sorted(except_ranges):
+                if off > pos:
+                    views.append(self.arena.flat[pos:off])
+                pos = max(pos, off + numel)
+            if pos < self.arena.numel:
+                views.append(self.arena.flat[pos:self.arena.numel])
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = views
+        torch._foreach_zero_(views)
 
     def sync_master_from_model(self):
         """fp32 master <- the bf16 parameters the model currently holds (call after writing ``p.data`` by hand;
@@ -351,14 +373,24 @@ class TrainStep:
         f = self.flat
         first, last = self.micro == 0, self.micro == self.update_freq - 1
         if first:
-            f.zero_grad()
             self.ss_acc = 0
             if self.exchange is not None:
                 self.exchange.begin_step()
+            if not OVERWRITE_WGRADS:
+                f.zero_grad()
         # only the closing micro-batch reports gradient milestones: earlier ones would all-reduce partial sums
         self.model._on_grad_ready = self.exchange.on_ready if (self.exchange is not None and last) else None
         with ROCTX.range("forward"):
             loss, sample_size, log = self.criterion(self.model, sample, sync_logging=False)
+        if first and OVERWRITE_WGRADS:
+            # The arena is cleared AFTER the forward's host phase (which drew LayerDrop) and before the backward: the encoder
+            # weight gradients that the grouped single-writer launches produce are WRITTEN by the first micro-batch of an
+            # update, so neither their 340 MB fill nor their read inside those kernels happens; everything else - biases,
+            # norms, extractor, heads, dropped layers, the pruned last layer - is zeroed as before
+            st = getattr(self.model, "_last_state", None)
+            ranges = engine.wgrad_overwrite_ranges(st, f.arena) if st is not None else []
+            f.zero_grad(ranges)
+            self.model._wgrad_overwrite = bool(ranges)
         ss_work = None
         if self.exchange is not None and last:
             # the global sample_size (mask lengths can differ across ranks) is known as soon as the closing micro-batch's
