@@ -16,7 +16,7 @@ import os
 
 import torch
 
-from . import engine, ops
+from . import _lib, engine, ops
 
 BF16 = torch.bfloat16
 
@@ -290,11 +290,6 @@ class TrainStep:
                 tail = engine.milestone_offset(self.flat.arena, "encoder.")
             self.exchange = GradExchange(self.flat.arena.flat, dist, group=group,
                                          flush_at=tail if tail < self.flat.arena.numel else -1, wire_dtype=wire_dtype)
-            # The pairwise K split of the grouped weight-gradient launch has workgroups WAIT on their partner: sound only while
-            # the whole grid is co-resident, which nobody can promise once RCCL's kernels share the chip with the backward.
-            # An odd (LayerDrop-ped) layer then takes the 256 x 128 single-writer group instead (~10 us per step).
-            from . import _lib
-            _lib.call("w2vs_gemm_tn8_max_split", 1)
         dev = self.flat.p16.device
         # The reference computes the gradient norm on EVERY update (clip_grad_norm_ with max_norm 0 still returns the norm,
         # fs/trainer.py:781) and raises FloatingPointError before optimizer.step when it is not finite (:791-793).  Here the
@@ -372,6 +367,11 @@ class TrainStep:
     def _step(self, sample):
         f = self.flat
         first, last = self.micro == 0, self.micro == self.update_freq - 1
+        # The pairwise K split of the grouped weight-gradient launch has workgroups WAIT on their partner: sound only while the
+        # whole grid is co-resident, which nobody can promise once RCCL's kernels share the chip with the backward.  An odd
+        # (LayerDrop-ped) layer then takes the 256 x 128 single-writer group instead (~10 us per step).  Set per step (the switch
+        # is process-wide; another TrainStep without an exchange sets it back).
+        _lib.call("w2vs_gemm_tn8_max_split", 1 if self.exchange is not None else 2)
         if first:
             self.ss_acc = 0
             if self.exchange is not None:
