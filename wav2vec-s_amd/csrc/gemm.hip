@@ -15,6 +15,8 @@
 //    LDS rows are 128 B; 16-B chunk c of row r lives at chunk (c ^ ((r>>1)&7)) which makes
 //    the ds_read_b128 fragment reads and the ds_write_b128 staging writes conflict free.
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 #include <type_traits>
 #include <vector>
 #include "common.h"
@@ -1917,6 +1919,24 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   }
   if (mode_env >= 0) mode = mode_env;
   if (g_force_nt_mode >= 0) mode = g_force_nt_mode;
+  {
+    // W2VS_NT_FORCE="N:K:epi=mode:height,..." (tuning): the kernel form / tile height for every launch of that output width,
+    // depth and epilogue - how tile choices are A/B-ed IN THE STEP, where operands are cold and probe rankings do not hold
+    struct Force { int N, K, epi, mode, h; };
+    static const std::vector<Force> forces = [] {
+      std::vector<Force> v;
+      const char* e = getenv("W2VS_NT_FORCE");
+      while (e && *e) {
+        Force f{};
+        if (sscanf(e, "%d:%d:%d=%d:%d", &f.N, &f.K, &f.epi, &f.mode, &f.h) == 5) v.push_back(f);
+        e = strchr(e, ',');
+        if (e) ++e;
+      }
+      return v;
+    }();
+    for (const Force& f : forces)
+      if (f.N == d.N && f.K == d.K && f.epi == d.epi && d.M >= 2048) { mode = f.mode; lc_h = f.h; wide_auto = false; }
+  }
   if ((mode == 5 || mode == 6) && !p_ok) return set_error("gemm_nt: the persistent kernel needs N % 8 == 0, ldc % 8 == 0, 16-byte aligned outputs");
   static const int lc_env = [] { const char* e = getenv("W2VS_LC_H"); return e ? atoi(e) : 0; }();
   if (lc_env > 0) lc_h = lc_env;
