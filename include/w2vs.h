@@ -252,6 +252,10 @@ typedef struct w2vs_layer_desc {
   /* 1: the deferred weight gradients of this layer OVERWRITE g_wqkv / g_wo / g_w1 / g_w2 (w2vs_gemm_desc.overwrite; the bias
    * gradients still accumulate): the first micro-batch of an update, whose caller then does not zero those ranges */
   int32_t wgrad_overwrite;
+  /* optional, selected-rows mode only: two more [R,E] backward scratch buffers.  With them (and ws_e3, defer_wgrads = 1) the
+   * scatter back to token rows no longer reuses ws_e0 / ws_f, the four weight-gradient operands of the LAST layer stay alive
+   * too, and w2vs_layer_wgrads takes the layer (three of its four GEMMs contract over the n_sel selected rows) */
+  void *ws_s0, *ws_s1;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

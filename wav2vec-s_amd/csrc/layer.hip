@@ -58,13 +58,17 @@ static GemmDesc wgrad_desc(const void* dy, const void* x, float* dw, float* db, 
 
 #define TRY(x) do { if (int e_ = (x)) return e_; } while (0)
 
-// the four weight gradients of a layer whose backward kept their operands alive (ws_e3 given, full rows)
+// the four weight gradients of a layer whose backward kept their operands alive (ws_e3 given).  Selected-rows mode (round 4):
+// everything behind the attention ran on the n_sel selected rows, so three of the four contract over n_sel rows (the attention
+// context operand is ctx_sel) and only the fused QKV projection over all R token rows - the grouped kernels take a K per problem
 static void layer_wgrad_descs(const w2vs_layer_desc& L, GemmDesc* g) {
   const int R = L.B * L.N, E = L.E, F = L.F;
-  g[0] = wgrad_desc(L.ws_f, L.x1, L.g_w1, L.g_b1, R, F, E, L.tn_ws, L.tn_ws_bytes);             // fc1   [F,E]
-  g[1] = wgrad_desc(L.ws_e0, L.h, L.g_w2, L.g_b2, R, E, F, L.tn_ws, L.tn_ws_bytes);             // fc2   [E,F]
+  const bool sel = L.sel_idx != nullptr;
+  const int Rt = sel ? L.n_sel : R;
+  g[0] = wgrad_desc(L.ws_f, L.x1, L.g_w1, L.g_b1, Rt, F, E, L.tn_ws, L.tn_ws_bytes);            // fc1   [F,E]
+  g[1] = wgrad_desc(L.ws_e0, L.h, L.g_w2, L.g_b2, Rt, E, F, L.tn_ws, L.tn_ws_bytes);            // fc2   [E,F]
   g[2] = wgrad_desc(L.ws_qkv, L.x_in, L.g_wqkv, L.g_bqkv, R, 3 * E, E, L.tn_ws, L.tn_ws_bytes); // qkv   [3E,E]
-  g[3] = wgrad_desc(L.ws_e3, L.ctx, L.g_wo, L.g_bo, R, E, E, L.tn_ws, L.tn_ws_bytes);           // out_proj [E,E]
+  g[3] = wgrad_desc(L.ws_e3, sel ? L.ctx_sel : L.ctx, L.g_wo, L.g_bo, Rt, E, E, L.tn_ws, L.tn_ws_bytes);   // out_proj [E,E]
   for (int i = 0; i < 4; ++i) g[i].overwrite = L.wgrad_overwrite ? 1 : 0;
 }
 
@@ -156,8 +160,10 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   // With a fourth [R,E] scratch (ws_e3) every operand of the four weight gradients stays alive to the end of the layer
   // (d_f in ws_e0, d_hpre in ws_f, d_a in ws_e3, d_qkv in ws_qkv) and they run as ONE grouped launch without a K split
   // (gemm_tn_group: 216 tiles of full-length K loops, no partial-tile slab, no summing launches).  Not in selected-rows
-  // mode, whose scatter step reuses ws_e0 / ws_f.
-  const bool defer = L.ws_e3 != nullptr && !sel;
+  // mode, whose scatter step reuses ws_e0 / ws_f - unless the caller hands it two more [R,E] buffers (ws_s0 / ws_s1, round 4)
+  // and asks for deferral: the last layer's weight gradients then join the grouped launch of its neighbour.
+  const bool sel_defer = sel && L.ws_e3 != nullptr && L.defer_wgrads && L.ws_s0 && L.ws_s1;
+  const bool defer = L.ws_e3 != nullptr && (!sel || sel_defer);
   void* d_a = defer ? L.ws_e3 : L.ws_e0;
   // fc2: wgrad, bias, dgrad chained through GELU -> d_hpre (ws_f)
   if (!defer) TRY(lin_wgrad(L.ws_e0, L.h, L.g_w2, L.g_b2, Rt, E, F, cu, s, L.tn_ws, L.tn_ws_bytes));
@@ -190,12 +196,14 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   if (sel) {
     // back to token rows: d_ctx and the residual-branch gradient are zero outside the selected rows
     const size_t bytes = (size_t)R * E * 2;
-    if (hipMemsetAsync(L.ws_e0, 0, bytes, s) != hipSuccess || hipMemsetAsync(L.ws_f, 0, bytes, s) != hipSuccess)
+    void* s0 = sel_defer ? L.ws_s0 : L.ws_e0;                       // ws_e0 (d_a) is dead after the out_proj pair ...
+    void* s1 = sel_defer ? L.ws_s1 : L.ws_f;                        // ... ws_f (d_hpre, LN slab) too - unless the wgrads are deferred
+    if (hipMemsetAsync(s0, 0, bytes, s) != hipSuccess || hipMemsetAsync(s1, 0, bytes, s) != hipSuccess)
       return set_error("layer_bwd: memset failed");
-    TRY(gather_rows(L.ws_e2, L.sel_idx, L.ws_e0, Rt, E, 1, s));     // ws_e0 (d_a) is dead after the out_proj pair
-    TRY(gather_rows(L.ws_e1, L.sel_idx, L.ws_f, Rt, E, 1, s));      // ws_f  (d_hpre, LN slab) is dead too
-    d_ctx = L.ws_e0; d_res = L.ws_f;
-    if (!L.post_ln && hipMemcpyAsync(L.d_stream_in, L.ws_f, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    TRY(gather_rows(L.ws_e2, L.sel_idx, s0, Rt, E, 1, s));
+    TRY(gather_rows(L.ws_e1, L.sel_idx, s1, Rt, E, 1, s));
+    d_ctx = s0; d_res = s1;
+    if (!L.post_ln && hipMemcpyAsync(L.d_stream_in, s1, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return set_error("layer_bwd: copy failed");
     // dq rows past n_q are not written by the attention backward: the QKV GEMMs read them
     if (hipMemsetAsync(L.ws_qkv, 0, (size_t)R * 3 * E * 2, s) != hipSuccess) return set_error("layer_bwd: memset failed");
@@ -214,7 +222,7 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   // post-LN: x_in is also the residual -> + d_res; pre-LN: x_in = LN(s_in) feeds the projection only, d_res went to d_stream_in
   TRY(lin_dgrad(L.ws_qkv, pre_t ? L.wqkv_t : L.wt_scratch, L.d_in, L.post_ln ? d_res : nullptr, R, 3 * E, E,
                 L.post_ln ? EPI_ADD : EPI_NONE, s));
-  if (L.defer_wgrads && !defer) return set_error("layer_bwd: defer_wgrads needs ws_e3 and no sel_idx");
+  if (L.defer_wgrads && !defer) return set_error("layer_bwd: defer_wgrads needs ws_e3 (and, with sel_idx, ws_s0 / ws_s1)");
   if (defer && !L.defer_wgrads) {
     GemmDesc g[4];
     layer_wgrad_descs(L, g);
@@ -229,9 +237,9 @@ int layer_wgrads(const w2vs_layer_desc* Ls, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     const w2vs_layer_desc& L = Ls[i];
     TRY(layer_check(L));
-    if (!L.ws_e3 || L.sel_idx || !L.ws_f || !L.ws_e0 || !L.ws_qkv || !L.g_wqkv || !L.g_bqkv || !L.g_wo || !L.g_bo || !L.g_w1 ||
-        !L.g_b1 || !L.g_w2 || !L.g_b2)
-      return set_error("layer_wgrads: the layer was not run with defer_wgrads (ws_e3, no sel_idx) or lacks gradient pointers");
+    if (!L.ws_e3 || (L.sel_idx && (!L.ws_s0 || !L.ws_s1 || !L.ctx_sel)) || !L.ws_f || !L.ws_e0 || !L.ws_qkv || !L.g_wqkv || !L.g_bqkv ||
+        !L.g_wo || !L.g_bo || !L.g_w1 || !L.g_b1 || !L.g_w2 || !L.g_b2)
+      return set_error("layer_wgrads: the layer was not run with defer_wgrads (ws_e3; ws_s0 / ws_s1 with sel_idx) or lacks gradient pointers");
     layer_wgrad_descs(L, g + 4 * i);
   }
   return gemm_tn_group(g, 4 * n, Ls[0].num_cu > 0 ? Ls[0].num_cu : 256, s);

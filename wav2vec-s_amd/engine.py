@@ -490,6 +490,8 @@ KEEP_MASK_STORE = os.environ.get("W2VS_ATTN_KEEP_BITS", "0") == "1"
 # the four weight gradients of a post-LN layer as one grouped launch (w2vs_gemm_tn_group); W2VS_GROUP_WGRADS=0 disables
 PAIR_WGRADS = os.environ.get("W2VS_PAIR_WGRADS", "1") != "0"     # A/B: 0 = every layer launches its own weight gradients
 GROUP_WGRADS = os.environ.get("W2VS_GROUP_WGRADS", "1") != "0"
+# the selected-rows (last) layer's weight gradients join the grouped launch of its neighbour; W2VS_SEL_DEFER=0: four launches of their own (A/B)
+SEL_DEFER = os.environ.get("W2VS_SEL_DEFER", "1") != "0"
 
 _POS_TABLES = {}
 
@@ -583,13 +585,13 @@ def wgrad_overwrite_ranges(st: State, A: Arena):
     matrices of every encoder layer whose weight gradients are deferred into the grouped single-writer launches
     (w2vs_layer_wgrads).  A trainer zeroes the rest of the arena only: the fill of these 85 M of the base model's 90 M
     gradients (340 MB) and their read inside the weight-gradient kernels disappear from the step.  Empty when the step does
-    not defer (one kept layer, PAIR / GROUP switches off); the last layer in selected-rows mode is never deferred."""
+    not defer (one kept layer, PAIR / GROUP switches off).  The last layer in selected-rows mode is deferred too (ws_s0 / ws_s1)."""
     if not (PAIR_WGRADS and GROUP_WGRADS and len(st.layers) > 1):
         return []
     E, F = st.cfg.encoder_embed_dim, st.cfg.encoder_ffn_embed_dim
     out = []
     for rec in st.layers:
-        if rec["desc"].sel_idx:
+        if rec["desc"].sel_idx and not SEL_DEFER:
             continue
         pre = f"encoder.layers.{rec['li']}."
         out.append((A.offsets[pre + "self_attn.q_proj.weight"][0], 3 * E * E))       # q | k | v weights are adjacent
@@ -677,6 +679,8 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         pending = None                                     # (layer descriptor, jj) whose weight gradients are still to be launched
         alt = ops.empty((R, E), BF16, dev)
         d_in_bufs[1] = alt.data_ptr()
+        # the selected-rows (last) layer joins the grouped weight-gradient launches when it gets its own scatter targets
+        sel_scatter = ops.empty((2, R, E), BF16, dev) if (pair and SEL_DEFER and st.layers[-1]["desc"].sel_idx) else None
         ds_bufs = [ops.empty((R, E), BF16, dev), ops.empty((R, E), BF16, dev)] if not post_ln else None
         cur = dx
         # every layer's four weights are transposed for the dgrad GEMMs in ONE launch (was 4 launches per layer)
@@ -714,7 +718,9 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                 setattr(d, f_, offs[f_])
             d.delta = delta.data_ptr()
             d.ws_e3 = e3.data_ptr() if e3 is not None else None
-            deferred = bool(pair and not d.sel_idx)
+            deferred = bool(pair and (SEL_DEFER or not d.sel_idx))
+            if d.sel_idx and deferred:
+                d.ws_s0, d.ws_s1 = sel_scatter[0].data_ptr(), sel_scatter[1].data_ptr()
             d.defer_wgrads = 1 if deferred else 0
             d.wgrad_overwrite = 1 if (deferred and overwrite_wgrads) else 0
             if deferred and (jj & 1):                      # consecutive layers alternate between the two operand sets
@@ -757,7 +763,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
             _lib.call("w2vs_layer_wgrads", arr, 1, stream)
             pending = None
         dx = cur
-        st._bwd_ws = (ws, alt, delta, e3, ds_bufs, ws2 if pair else None)
+        st._bwd_ws = (ws, alt, delta, e3, ds_bufs, ws2 if pair else None, sel_scatter)
     if post_ln:
         d_x0 = dx
     elif st.layers:
