@@ -256,6 +256,11 @@ typedef struct w2vs_layer_desc {
    * scatter back to token rows no longer reuses ws_e0 / ws_f, the four weight-gradient operands of the LAST layer stay alive
    * too, and w2vs_layer_wgrads takes the layer (three of its four GEMMs contract over the n_sel selected rows) */
   void *ws_s0, *ws_s1;
+  /* optional, with defer_wgrads = 1: a slab of ln_part_bytes (two halves of up to 768 x 2E fp32 each, i.e. 2 x 4.7 MB at E = 768)
+   * that this layer OWNS until its w2vs_layer_wgrads call: the two LayerNorm backward kernels leave their per-block
+   * dgamma / dbeta partial rows there and w2vs_layer_wgrads sums the partials of all its layers' norms in one launch
+   * (g_ln1_* / g_ln2_* are final only after that call, like the weight gradients).  NULL: each norm reduces at once. */
+  void* ln_part; int64_t ln_part_bytes;
 } w2vs_layer_desc;
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* stream);
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);

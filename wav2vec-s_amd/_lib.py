@@ -79,7 +79,7 @@ class LayerDesc(C.Structure):
                     "wqkv_t", "wo_t", "w1_t", "w2_t", "tn_ws")] + [("tn_ws_bytes", i64), ("sel_idx", vp), ("n_sel", i32),
                                                                             ("n_q", i32), ("ctx_sel", vp), ("xin_sel", vp), ("ws_e3", vp),
                                                                             ("stream_in", vp), ("d_stream_out", vp), ("d_stream_in", vp), ("drop_bits", vp),
-                                                                            ("defer_wgrads", i32), ("wgrad_overwrite", i32), ("ws_s0", vp), ("ws_s1", vp)])
+                                                                            ("defer_wgrads", i32), ("wgrad_overwrite", i32), ("ws_s0", vp), ("ws_s1", vp), ("ln_part", vp), ("ln_part_bytes", i64)])
 
 
 class CollateDesc(C.Structure):

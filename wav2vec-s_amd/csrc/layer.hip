@@ -72,6 +72,12 @@ static void layer_wgrad_descs(const w2vs_layer_desc& L, GemmDesc* g) {
   for (int i = 0; i < 4; ++i) g[i].overwrite = L.wgrad_overwrite ? 1 : 0;
 }
 
+// the dgamma / dbeta partial slabs of a deferred layer: LN2's in the first half of ln_part, LN1's in the second
+static bool ln_deferred(const w2vs_layer_desc& L) {
+  return L.defer_wgrads && L.ln_part && (L.ln_part_bytes / 2 & ~(int64_t)255) >= ln_min_slab_bytes(L.E);
+}
+static int64_t ln_half_bytes(const w2vs_layer_desc& L) { return L.ln_part_bytes / 2 & ~(int64_t)255; }
+
 static int layer_check(const w2vs_layer_desc& L) {
   if (L.B <= 0 || L.N <= 0 || L.E <= 0 || L.F <= 0 || L.H <= 0) return set_error("layer: bad dims");
   if (L.E % 8 || L.F % 8 || L.E / L.H != 64) return set_error("layer: need E%8==0, F%8==0, head_dim 64");
@@ -155,8 +161,10 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   if (!L.post_ln) b2.dsum = L.d_stream_out;            // pre-LN: the stream's own gradient joins here (NULL: last layer)
   b2.dx = L.ws_e0; b2.dres = L.ws_e1; b2.dgamma = L.g_ln2_g; b2.dbeta = L.g_ln2_b; b2.rows = Rt; b2.C = E;
   b2.p_drop = L.p_drop; b2.seed = L.seed_drop2; b2.out_scale = 1.f;
+  const bool ln_defer = ln_deferred(L) && L.ws_e3 && (!L.sel_idx || (L.ws_s0 && L.ws_s1));   // the partial rows wait for w2vs_layer_wgrads in the layer's own slab
   b2.ws = L.ws_f; b2.ws_bytes = (int64_t)R * F * 2;   // ws_f is not live yet: dgamma/dbeta partial slab
-  TRY(ln_bwd(b2, s));
+  if (ln_defer) { b2.ws = L.ln_part; b2.ws_bytes = ln_half_bytes(L); }
+  TRY(ln_bwd(b2, s, ln_defer));
   // With a fourth [R,E] scratch (ws_e3) every operand of the four weight gradients stays alive to the end of the layer
   // (d_f in ws_e0, d_hpre in ws_f, d_a in ws_e3, d_qkv in ws_qkv) and they run as ONE grouped launch without a K split
   // (gemm_tn_group: 216 tiles of full-length K loops, no partial-tile slab, no summing launches).  Not in selected-rows
@@ -186,7 +194,8 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   } else {
     b1.ws = L.ws_f; b1.ws_bytes = (int64_t)R * F * 2;   // fc1's wgrad/dgrad (enqueued above) were its last readers
   }
-  TRY(ln_bwd(b1, s));
+  if (ln_defer) { b1.ws = (char*)L.ln_part + ln_half_bytes(L); b1.ws_bytes = ln_half_bytes(L); }
+  TRY(ln_bwd(b1, s, ln_defer));
   // out_proj
   if (!defer) TRY(lin_wgrad(L.ws_e0, ctx, L.g_wo, L.g_bo, Rt, E, E, cu, s, L.tn_ws, L.tn_ws_bytes));
   if (!pre_t) TRY(transpose2d(L.wo, L.wt_scratch, E, E, 1, s));
@@ -242,6 +251,18 @@ int layer_wgrads(const w2vs_layer_desc* Ls, int n, hipStream_t s) {
       return set_error("layer_wgrads: the layer was not run with defer_wgrads (ws_e3; ws_s0 / ws_s1 with sel_idx) or lacks gradient pointers");
     layer_wgrad_descs(L, g + 4 * i);
   }
+  LnPartial lp[4];
+  int nl = 0;
+  for (int i = 0; i < n; ++i) {
+    const w2vs_layer_desc& L = Ls[i];
+    if (!ln_deferred(L)) continue;
+    if (L.E != Ls[0].E) return set_error("layer_wgrads: layers of different width");
+    if (!L.g_ln1_g || !L.g_ln1_b || !L.g_ln2_g || !L.g_ln2_b) return set_error("layer_wgrads: null LayerNorm gradient pointer");
+    const int G = ln_bwd_grid(L.sel_idx ? L.n_sel : L.B * L.N, L.E, ln_half_bytes(L));
+    lp[nl++] = LnPartial{(const float*)L.ln_part, L.g_ln2_g, L.g_ln2_b, G};
+    lp[nl++] = LnPartial{(const float*)((const char*)L.ln_part + ln_half_bytes(L)), L.g_ln1_g, L.g_ln1_b, G};
+  }
+  if (nl) TRY(ln_reduce_many(lp, nl, Ls[0].E, s));
   return gemm_tn_group(g, 4 * n, Ls[0].num_cu > 0 ? Ls[0].num_cu : 256, s);
 }
 

@@ -727,6 +727,57 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* part, i
   }
 }
 
+// the same sums for up to four LayerNorms in one launch (blockIdx.z picks the norm): the encoder layers leave their partial slabs
+// in place and the grouped weight-gradient call of a layer pair reduces all of them together (round 4: 4 launches -> 1)
+struct LnRedMany { LnPartial r[4]; int n, C; };
+__global__ __launch_bounds__(256) void ln_bwd_reduce_many_kernel(LnRedMany m) {
+  const LnPartial r = m.r[blockIdx.z];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx, C = m.C, C2 = 2 * C, G = r.G;
+  const float* part = r.part;
+  float s = 0.f;
+  if (col < C2) {
+    const int step = 4 * gridDim.y;
+    int gi = blockIdx.y * 4 + ty;
+    for (; gi + 3 * step < G; gi += 4 * step) {
+      float a0 = part[(long)gi * C2 + col], a1 = part[(long)(gi + step) * C2 + col];
+      float a2 = part[(long)(gi + 2 * step) * C2 + col], a3 = part[(long)(gi + 3 * step) * C2 + col];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; gi < G; gi += step) s += part[(long)gi * C2 + col];
+  }
+  __shared__ float red[4][64];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < C2) {
+    s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (col < C) atomicAdd(&r.dg[col], s);
+    else atomicAdd(&r.db[col - C], s);
+  }
+}
+
+int ln_reduce_many(const LnPartial* r, int n, int C, hipStream_t st) {
+  if (n < 1 || n > 4) return set_error("ln_reduce_many: 1..4 norms");
+  LnRedMany m{};
+  int gmax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!r[i].part || !r[i].dg || !r[i].db || r[i].G < 1) return set_error("ln_reduce_many: null pointer");
+    m.r[i] = r[i];
+    gmax = std::max(gmax, r[i].G);
+  }
+  m.n = n; m.C = C;
+  const int ry = std::max(1, std::min(16, gmax / 16));
+  hipLaunchKernelGGL(ln_bwd_reduce_many_kernel, dim3((2 * C + 63) / 64, ry, n), dim3(256), 0, st, m);
+  return hip_check(hipGetLastError(), "ln_reduce_many");
+}
+
+// the grid ln_bwd chooses for `rows` rows when it is given a partial slab of ws_bytes (shared with the deferred reduction)
+int ln_bwd_grid(long rows, int C, int64_t ws_bytes) {
+  constexpr int NW = 4;
+  int grid = (int)std::min<long>((rows + NW - 1) / NW, rows > 65536 ? 2048 : 768);
+  return (int)std::min<long>(grid, ws_bytes / ((long)sizeof(float) * 2 * C));
+}
+
 static int ln_check(const LnP& p, const char* who) {
   if (p.C % 8 || p.C > 1024 || p.C < 8) return set_error("layernorm: need C % 8 == 0 and C <= 1024");
   if (p.rows <= 0) return set_error("layernorm: rows must be positive");
@@ -753,7 +804,7 @@ int ln_fwd(const LnFwdDesc& d, hipStream_t st) {
   return hip_check(hipGetLastError(), "ln_fwd");
 }
 
-int ln_bwd(const LnBwdDesc& d, hipStream_t st) {
+int ln_bwd(const LnBwdDesc& d, hipStream_t st, bool leave_partials) {
   LnP p{};
   p.x = (const bf16*)d.x; p.g = (const bf16*)d.gamma; p.b = (const bf16*)d.beta; p.mean = const_cast<float*>(d.mean);
   p.rstd = const_cast<float*>(d.rstd); p.dy = (const bf16*)d.dy; p.dsum = (const bf16*)d.dsum; p.aux = (const bf16*)d.aux;
@@ -766,17 +817,18 @@ int ln_bwd(const LnBwdDesc& d, hipStream_t st) {
   int grid = (int)std::min<long>((p.rows + NW - 1) / NW, p.rows > 65536 ? 2048 : 768);
   // partial slab [grid][2C] fp32 in the caller's workspace; shrink the grid to what the workspace holds
   float* part = nullptr;
-  if (d.ws && d.ws_bytes >= (int64_t)sizeof(float) * 2 * p.C * 64) {
-    grid = (int)std::min<long>(grid, d.ws_bytes / ((long)sizeof(float) * 2 * p.C));
+  if (d.ws && d.ws_bytes >= ln_min_slab_bytes(p.C)) {
+    grid = ln_bwd_grid(p.rows, p.C, d.ws_bytes);
     part = (float*)d.ws;
   } else {
     grid = std::min(grid, 256);   // no workspace: per-block atomics, keep their number down
   }
+  if (leave_partials && !part) return set_error("ln_bwd: a deferred reduction needs a partial slab");
   static const int atomic_env = [] { const char* e = getenv("W2VS_LN_BWD_ATOMIC"); return e ? atoi(e) : 0; }();   // A/B: N > 0 = atomics from N blocks
-  if (atomic_env > 0) { part = nullptr; grid = std::min<long>((p.rows + NW - 1) / NW, atomic_env); }
+  if (atomic_env > 0 && !leave_partials) { part = nullptr; grid = std::min<long>((p.rows + NW - 1) / NW, atomic_env); }
   if (full) hipLaunchKernelGGL((ln_bwd_kernel<true, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);
   else hipLaunchKernelGGL((ln_bwd_kernel<false, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);
-  if (part) {
+  if (part && !leave_partials) {
     const int ry = std::max(1, std::min(16, grid / 16));
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * p.C + 63) / 64, ry), dim3(256), 0, st, part, grid, p.C, p.dg, p.db);
   }

@@ -49,7 +49,12 @@ int conv0_gn_bwd(const void* wave, const void* w, const void* cbias, const void*
                  const void* dy, float* bstat, float* dw, float* dcbias, float* dg, float* db, int B, int L, int C, int k,
                  int s, hipStream_t st);
 int ln_fwd(const LnFwdDesc& d, hipStream_t st);
-int ln_bwd(const LnBwdDesc& d, hipStream_t st);
+// leave_partials: the dgamma / dbeta partial rows stay in d.ws ([ln_bwd_grid(...)][2C] fp32) and ln_reduce_many sums them later
+int ln_bwd(const LnBwdDesc& d, hipStream_t st, bool leave_partials = false);
+struct LnPartial { const float* part; float* dg; float* db; int G; };
+inline int64_t ln_min_slab_bytes(int C) { return (int64_t)sizeof(float) * 2 * C * 64; }
+int ln_bwd_grid(long rows, int C, int64_t ws_bytes);
+int ln_reduce_many(const LnPartial* r, int n, int C, hipStream_t st);
 int enc_prologue_fwd(const EncPrologueDesc& d, hipStream_t st);
 int enc_prologue_bwd(const EncPrologueDesc& d, hipStream_t st);
 int attn_fwd(const AttnDesc& d, hipStream_t st);

@@ -492,6 +492,7 @@ PAIR_WGRADS = os.environ.get("W2VS_PAIR_WGRADS", "1") != "0"     # A/B: 0 = ever
 GROUP_WGRADS = os.environ.get("W2VS_GROUP_WGRADS", "1") != "0"
 # the selected-rows (last) layer's weight gradients join the grouped launch of its neighbour; W2VS_SEL_DEFER=0: four launches of their own (A/B)
 SEL_DEFER = os.environ.get("W2VS_SEL_DEFER", "1") != "0"
+LN_DEFER = os.environ.get("W2VS_LN_DEFER", "1") != "0"      # the layers' dgamma / dbeta partial sums wait for the grouped weight-gradient call
 
 _POS_TABLES = {}
 
@@ -682,6 +683,8 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         # the selected-rows (last) layer joins the grouped weight-gradient launches when it gets its own scatter targets
         sel_scatter = ops.empty((2, R, E), BF16, dev) if (pair and SEL_DEFER and st.layers[-1]["desc"].sel_idx) else None
         ds_bufs = [ops.empty((R, E), BF16, dev), ops.empty((R, E), BF16, dev)] if not post_ln else None
+        # one slab of LayerNorm partial sums per operand set: [2 norms][<= 768 blocks][2E] fp32 (w2vs_layer_desc.ln_part)
+        ln_parts = ops.empty((2, 2 * 768 * 2 * E), torch.float32, dev) if (pair and LN_DEFER) else None
         cur = dx
         # every layer's four weights are transposed for the dgrad GEMMs in ONE launch (was 4 launches per layer)
         per_t = 3 * E * E + E * E + 2 * E * F
@@ -722,6 +725,10 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
             if d.sel_idx and deferred:
                 d.ws_s0, d.ws_s1 = sel_scatter[0].data_ptr(), sel_scatter[1].data_ptr()
             d.defer_wgrads = 1 if deferred else 0
+            if deferred and ln_parts is not None:
+                d.ln_part, d.ln_part_bytes = ln_parts[jj & 1].data_ptr(), ln_parts[jj & 1].numel() * 4
+            else:
+                d.ln_part, d.ln_part_bytes = None, 0
             d.wgrad_overwrite = 1 if (deferred and overwrite_wgrads) else 0
             if deferred and (jj & 1):                      # consecutive layers alternate between the two operand sets
                 for f_ in ("ws_e0", "ws_f", "ws_qkv", "ws_e3"):
@@ -763,7 +770,7 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
             _lib.call("w2vs_layer_wgrads", arr, 1, stream)
             pending = None
         dx = cur
-        st._bwd_ws = (ws, alt, delta, e3, ds_bufs, ws2 if pair else None, sel_scatter)
+        st._bwd_ws = (ws, alt, delta, e3, ds_bufs, ws2 if pair else None, sel_scatter, ln_parts)
     if post_ln:
         d_x0 = dx
     elif st.layers:
