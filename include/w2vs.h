@@ -95,7 +95,8 @@ int w2vs_prof_read_raw(int id, double* total_ms, double* total_flops, int* launc
 int64_t w2vs_prof_launches(int id);
 double w2vs_prof_flops(int id);
 int w2vs_gemm_tn(const w2vs_gemm_desc* d, int num_cu_hint, void* stream);
-/* n <= 4 weight-gradient GEMMs (e.g. the four of one encoder layer: fused QKV, out_proj, fc1, fc2) as ONE launch without
+/* n <= 12 weight-gradient GEMMs (e.g. the four of one encoder layer: fused QKV, out_proj, fc1, fc2; more than four only as the
+ * 8-phase form: 256 x 256 tiles, all of them in one round of the chip - otherwise groups of four) as ONE launch without
  * a K split: together their 256x128 tiles fill the chip, every tile has a single writer (C += A^T B with plain stores:
  * no partial-tile workspace, no summing launch, no atomics except the optional column sums).  Same result as n calls of
  * w2vs_gemm_tn; falls back to exactly that when the group does not qualify. */
@@ -269,6 +270,14 @@ int w2vs_layer_bwd(const w2vs_layer_desc* d, void* stream);
  * workgroups - a single layer's 108 tiles need the split to fill the chip.  Falls back to one launch per layer when the pair
  * does not fit one workgroup per CU. */
 int w2vs_layer_wgrads(const w2vs_layer_desc* layers, int32_t n, void* stream);
+/* The same for a caller that packs its launches itself (round 4): parts[i] selects which of layers[i]'s gradients go into THIS
+ * launch - bit 0 fc1, bit 1 fc2, bit 2 fused QKV, bit 3 out_proj (weight + bias each), bit 4 the layer's LayerNorm partial sums
+ * (ln_part) - n <= 6 layers, <= 12 GEMMs and <= 8 norms per call.  One base-model layer is 36 + 36 + 27 + 9 output tiles of
+ * 256 x 256 and a launch is ONE round of the chip whatever its tile count (<= the CU count), so seven 36-tile GEMMs (or
+ * 6 x 36 + 27 + 9) = 252 tiles use 252 of 256 CUs where a layer pair uses 216.  Every selected gradient must come from a layer
+ * whose layer_bwd ran with defer_wgrads = 1 and whose operand buffers (ws_f, ws_e0, ws_qkv, ws_e3, ln_part) are still intact.
+ * Groups that do not fill 5/8 of the chip run as the smaller forms (K split through a slab), as in w2vs_gemm_tn_group. */
+int w2vs_layer_wgrads_parts(const w2vs_layer_desc* layers, const int32_t* parts, int32_t n, void* stream);
 
 /* ---- Gumbel vector quantizer ---------------------------------------------------------------------
  * fs/modules/gumbel_vector_quantizer.py:141-202 after the weight_proj GEMM: hard argmax +

@@ -473,6 +473,39 @@ def test_last_layer_selected_rows_equals_full_path():
             assert float((g0[n] - g1[n]).norm()) / den < 2e-3, n       # wgrad / reduction order differs, nothing else
 
 
+def test_packed_weight_gradient_launches_equal_layer_pairs():
+    """engine.PACK_WGRADS: "1" packs whole weight-gradient GEMMs of up to four layers into launches of <= 256 tiles
+    (w2vs_layer_wgrads_parts, four rotating operand sets, LayerNorm partial sums reduced with the first launch a layer appears
+    in), "0" launches whole layer pairs.  Same kernels per tile, so every gradient must agree to summation-order noise - on a
+    base-width model of five layers (108 tiles each: launches span three layers, the last one is a remainder that takes the
+    split-K forms) with dropouts on and the last layer pruned to the masked frames."""
+    from wav2vec_s_amd import engine
+    cfg_kw = dict(BASE, encoder_layers=5, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12,
+                  dropout=0.1, attention_dropout=0.1, encoder_layerdrop=0.0)
+    out = {}
+    keep = engine.PACK_WGRADS
+    for mode in ("0", "1"):
+        w, model, P, ocfg, source, draws, mask, neg, noise = _setup(cfg_kw, B=4, L=48000, seed=5, m_ctx=16, r_ctx=8)
+        model = model.cuda().train()
+        crit = w.Wav2vecCriterion(infonce=True, loss_weights=[0.1, 10.0])
+        engine.PACK_WGRADS = mode
+        try:
+            model.inject_draws(draws)
+            torch.manual_seed(7); torch.cuda.manual_seed(7)
+            loss, _, _ = crit(model, {"net_input": {"source": source.cuda()}})
+            loss.backward()
+            out[mode] = (float(loss), {n: p.grad.float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            engine.PACK_WGRADS = keep
+    (l0, g0), (l1, g1) = out["0"], out["1"]
+    assert l0 == l1
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        den = float(g0[n].norm())
+        if den > 1e-6:
+            assert float((g0[n] - g1[n]).norm()) / den < 1e-4, n       # atomics (bias / LayerNorm sums) and split-K order only
+
+
 @pytest.mark.parametrize("width", ["small", "base"])
 def test_update_freq_accumulates_every_gradient(width):
     """TrainStep(update_freq=2) fed the same micro-batch twice must leave exactly twice the gradient of one micro-batch in

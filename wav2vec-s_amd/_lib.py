@@ -120,6 +120,7 @@ _SIGS = {
     "w2vs_layer_fwd": [C.POINTER(LayerDesc), vp],
     "w2vs_layer_bwd": [C.POINTER(LayerDesc), vp],
     "w2vs_layer_wgrads": [vp, i32, vp],
+    "w2vs_layer_wgrads_parts": [vp, vp, i32, vp],
     "w2vs_quant_fwd": [C.POINTER(QuantDesc), vp],
     "w2vs_quant_bwd": [C.POINTER(QuantDesc), vp],
     "w2vs_nce_fwd": [C.POINTER(NceDesc), vp],

@@ -69,7 +69,8 @@ int w2vs_attn_fwd(const w2vs_attn_desc* d, void* s) { NONNULL(d); return attn_fw
 int w2vs_attn_bwd(const w2vs_attn_desc* d, void* s) { NONNULL(d); return attn_bwd(*d, ST(s)); }
 int w2vs_layer_fwd(const w2vs_layer_desc* d, void* s) { NONNULL(d); return layer_fwd(*d, ST(s)); }
 int w2vs_layer_bwd(const w2vs_layer_desc* d, void* s) { NONNULL(d); return layer_bwd(*d, ST(s)); }
-int w2vs_layer_wgrads(const w2vs_layer_desc* d, int32_t n, void* s) { NONNULL(d); return layer_wgrads(d, n, ST(s)); }
+int w2vs_layer_wgrads(const w2vs_layer_desc* d, int32_t n, void* s) { NONNULL(d); if (n > 2) return set_error("layer_wgrads: 1 or 2 layers (w2vs_layer_wgrads_parts takes more)"); return layer_wgrads(d, nullptr, n, ST(s)); }
+int w2vs_layer_wgrads_parts(const w2vs_layer_desc* d, const int32_t* parts, int32_t n, void* s) { NONNULL(d); NONNULL(parts); return layer_wgrads(d, parts, n, ST(s)); }
 int w2vs_quant_fwd(const w2vs_quant_desc* d, void* s) { NONNULL(d); return quant_fwd(*d, ST(s)); }
 int w2vs_quant_bwd(const w2vs_quant_desc* d, void* s) { NONNULL(d); return quant_bwd(*d, ST(s)); }
 int w2vs_nce_fwd(const w2vs_nce_desc* d, void* s) { NONNULL(d); return nce_fwd(*d, ST(s)); }

@@ -1441,7 +1441,8 @@ __global__ __launch_bounds__(768) void gemm_tn_group_kernel(TnGroupP g) {
 // issue-bound, not operand-bound like the 256 x 128 kernel; a one-sided hand-off (256 KB slab, plain stores + release
 // fence, last arriver combines) cost ~30 us per launch and erased the gain, hence the symmetric write-through form.
 // ---------------------------------------------------------------------------------------------
-struct Tn8GroupP { GemmP p[8]; int first[9]; int S; float* slab; long slab_bytes; unsigned* cnt; int dbg; };   // up to 8 GEMMs: two layers' weight gradients   // dbg: timing-only ablations
+constexpr int TN8_MAXP = 12;   // problems per grouped launch: the caller packs whole GEMMs of up to four layers into one round of the chip
+struct Tn8GroupP { GemmP p[TN8_MAXP]; int first[TN8_MAXP + 1]; int S; float* slab; long slab_bytes; unsigned* cnt; int dbg; };   // dbg: timing-only ablations
 // the tr read as inline asm: behind the builtin hipcc puts an s_waitcnt vmcnt(0) in front of the first read of every loop
 // iteration (an LDS read without a memory operand "may alias" every LDS-DMA in flight), which drains the staging pipeline.
 // The wave waits for these reads itself: s_waitcnt lgkmcnt(0) + sched_barrier behind the phase's first barrier.
@@ -1472,7 +1473,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
   }
   int pi = 0;
 #pragma unroll
-  for (int i = 1; i < 8; ++i)
+  for (int i = 1; i < TN8_MAXP; ++i)
     if (tile >= g.first[i]) pi = i;
   pi = __builtin_amdgcn_readfirstlane(pi);
   const GemmP& p = g.p[pi];
@@ -2107,7 +2108,7 @@ int gemm_last_group_form() { return g_last_group_form; }
 // n <= 4 weight-gradient GEMMs in one launch (see gemm_tn_group_kernel).  Falls back to one gemm_tn per problem when the
 // group does not qualify (alignment, batching, more tiles than CUs, tiny K).
 int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
-  if (!ds || n < 1 || n > 8) return set_error("gemm_tn_group: 1..8 problems");
+  if (!ds || n < 1 || n > TN8_MAXP) return set_error("gemm_tn_group: 1..12 problems");
   DevFacts* df = dev_facts();
   if (!df) return set_error("gemm_tn_group: cannot query the device");
   // the caller's hint can only LOWER the count (tests, a partitioned device); the real CU count caps it
@@ -2126,12 +2127,13 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
             ((uintptr_t)d.Cf % 16) == 0 && d.K >= 8 * TK;
     }
     if (!ok8 || t8 > ncu || t8 * 8 < ncu * 5) {
-      if (int e = gemm_tn_group(ds, 4, num_cu_hint, s)) return e;
-      return gemm_tn_group(ds + 4, n - 4, num_cu_hint, s);
+      for (int o = 0; o < n; o += 4)
+        if (int e = gemm_tn_group(ds + o, std::min(4, n - o), num_cu_hint, s)) return e;
+      return 0;
     }
   }
   TnGroupP g{};
-  GemmP gp[8] = {};
+  GemmP gp[TN8_MAXP] = {};
   int tiles = 0;
   double flops = 0;
   bool ok = true;
@@ -2161,7 +2163,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
     Tn8GroupP g8{};
     int t8 = 0;
     for (int i = 0; i < n; ++i) { g8.p[i] = gp[i]; g8.first[i] = t8; t8 += ((ds[i].N + 255) / 256) * ((ds[i].M + 255) / 256); }
-    for (int i = n; i <= 8; ++i) g8.first[i] = t8;
+    for (int i = n; i <= TN8_MAXP; ++i) g8.first[i] = t8;
     int minK = ds[0].K;
     for (int i = 1; i < n; ++i) minK = std::min(minK, ds[i].K);
     int S = std::max(1, std::min(g_tn8_max_split, ncu / std::max(1, t8)));
@@ -2195,9 +2197,10 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
       return hip_check(hipGetLastError(), "gemm_tn8_group launch");
     }
   }
-  if (n > 4) {                                     // (the pre-check above makes this unreachable; never run the 4-entry kernel on 8)
-    if (int e = gemm_tn_group(ds, 4, num_cu_hint, s)) return e;
-    return gemm_tn_group(ds + 4, n - 4, num_cu_hint, s);
+  if (n > 4) {                                     // (the pre-check above makes this unreachable; never run the 4-entry kernel on more)
+    for (int o = 0; o < n; o += 4)
+      if (int e = gemm_tn_group(ds + o, std::min(4, n - o), num_cu_hint, s)) return e;
+    return 0;
   }
   static const int grp_env = [] { const char* e = getenv("W2VS_TN_GROUP"); return e ? atoi(e) : 1; }();
   // grouped only when it fills >= 3/4 of the chip AND leaves some slack: with exactly one workgroup per CU a single CU that is

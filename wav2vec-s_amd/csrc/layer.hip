@@ -240,30 +240,40 @@ int layer_bwd(const w2vs_layer_desc& L, hipStream_t s) {
   return 0;
 }
 
-int layer_wgrads(const w2vs_layer_desc* Ls, int n, hipStream_t s) {
-  if (!Ls || n < 1 || n > 2) return set_error("layer_wgrads: 1 or 2 layers");
-  GemmDesc g[8];
+// parts[i]: bit 0 fc1, bit 1 fc2, bit 2 fused QKV, bit 3 out_proj weight (+ bias) gradient of Ls[i]; bit 4: sum that layer's
+// LayerNorm partial slabs.  NULL = everything of every layer.
+int layer_wgrads(const w2vs_layer_desc* Ls, const int32_t* parts, int n, hipStream_t s) {
+  if (!Ls || n < 1 || n > 6) return set_error("layer_wgrads: 1 to 6 layers");
+  GemmDesc g[12];
+  LnPartial lp[8];
+  int ng = 0, nl = 0;
   for (int i = 0; i < n; ++i) {
     const w2vs_layer_desc& L = Ls[i];
+    const int part = parts ? parts[i] : 31;
+    if (part & ~31) return set_error("layer_wgrads: parts has bits 0-4 only");
     TRY(layer_check(L));
     if (!L.ws_e3 || (L.sel_idx && (!L.ws_s0 || !L.ws_s1 || !L.ctx_sel)) || !L.ws_f || !L.ws_e0 || !L.ws_qkv || !L.g_wqkv || !L.g_bqkv ||
         !L.g_wo || !L.g_bo || !L.g_w1 || !L.g_b1 || !L.g_w2 || !L.g_b2)
       return set_error("layer_wgrads: the layer was not run with defer_wgrads (ws_e3; ws_s0 / ws_s1 with sel_idx) or lacks gradient pointers");
-    layer_wgrad_descs(L, g + 4 * i);
-  }
-  LnPartial lp[4];
-  int nl = 0;
-  for (int i = 0; i < n; ++i) {
-    const w2vs_layer_desc& L = Ls[i];
-    if (!ln_deferred(L)) continue;
-    if (L.E != Ls[0].E) return set_error("layer_wgrads: layers of different width");
-    if (!L.g_ln1_g || !L.g_ln1_b || !L.g_ln2_g || !L.g_ln2_b) return set_error("layer_wgrads: null LayerNorm gradient pointer");
-    const int G = ln_bwd_grid(L.sel_idx ? L.n_sel : L.B * L.N, L.E, ln_half_bytes(L));
-    lp[nl++] = LnPartial{(const float*)L.ln_part, L.g_ln2_g, L.g_ln2_b, G};
-    lp[nl++] = LnPartial{(const float*)((const char*)L.ln_part + ln_half_bytes(L)), L.g_ln1_g, L.g_ln1_b, G};
+    GemmDesc four[4];
+    layer_wgrad_descs(L, four);
+    for (int k = 0; k < 4; ++k)
+      if (part >> k & 1) {
+        if (ng == 12) return set_error("layer_wgrads: at most 12 GEMMs per call");
+        g[ng++] = four[k];
+      }
+    if ((part & 16) && ln_deferred(L)) {
+      if (nl + 2 > 8) return set_error("layer_wgrads: at most 8 LayerNorm reductions per call");
+      if (L.E != Ls[0].E) return set_error("layer_wgrads: layers of different width");
+      if (!L.g_ln1_g || !L.g_ln1_b || !L.g_ln2_g || !L.g_ln2_b) return set_error("layer_wgrads: null LayerNorm gradient pointer");
+      const int G = ln_bwd_grid(L.sel_idx ? L.n_sel : L.B * L.N, L.E, ln_half_bytes(L));
+      lp[nl++] = LnPartial{(const float*)L.ln_part, L.g_ln2_g, L.g_ln2_b, G};
+      lp[nl++] = LnPartial{(const float*)((const char*)L.ln_part + ln_half_bytes(L)), L.g_ln1_g, L.g_ln1_b, G};
+    }
   }
   if (nl) TRY(ln_reduce_many(lp, nl, Ls[0].E, s));
-  return gemm_tn_group(g, 4 * n, Ls[0].num_cu > 0 ? Ls[0].num_cu : 256, s);
+  if (!ng) return 0;
+  return gemm_tn_group(g, ng, Ls[0].num_cu > 0 ? Ls[0].num_cu : 256, s);
 }
 
 }  // namespace w2vs

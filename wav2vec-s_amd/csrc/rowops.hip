@@ -727,9 +727,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* part, i
   }
 }
 
-// the same sums for up to four LayerNorms in one launch (blockIdx.z picks the norm): the encoder layers leave their partial slabs
+// the same sums for up to eight LayerNorms in one launch (blockIdx.z picks the norm): the encoder layers leave their partial slabs
 // in place and the grouped weight-gradient call of a layer pair reduces all of them together (round 4: 4 launches -> 1)
-struct LnRedMany { LnPartial r[4]; int n, C; };
+struct LnRedMany { LnPartial r[8]; int n, C; };
 __global__ __launch_bounds__(256) void ln_bwd_reduce_many_kernel(LnRedMany m) {
   const LnPartial r = m.r[blockIdx.z];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_many_kernel(LnRedMany m) {
 }
 
 int ln_reduce_many(const LnPartial* r, int n, int C, hipStream_t st) {
-  if (n < 1 || n > 4) return set_error("ln_reduce_many: 1..4 norms");
+  if (n < 1 || n > 8) return set_error("ln_reduce_many: 1..8 norms");
   LnRedMany m{};
   int gmax = 0;
   for (int i = 0; i < n; ++i) {

@@ -61,7 +61,7 @@ int attn_fwd(const AttnDesc& d, hipStream_t st);
 int attn_bwd(const AttnDesc& d, hipStream_t st);
 int layer_fwd(const w2vs_layer_desc& L, hipStream_t st);
 int layer_bwd(const w2vs_layer_desc& L, hipStream_t st);
-int layer_wgrads(const w2vs_layer_desc* Ls, int n, hipStream_t st);
+int layer_wgrads(const w2vs_layer_desc* Ls, const int32_t* parts, int n, hipStream_t st);
 int quant_fwd(const QuantDesc& d, hipStream_t st);
 int quant_bwd(const QuantDesc& d, hipStream_t st);
 int nce_fwd(const NceDesc& d, hipStream_t st);

@@ -493,6 +493,85 @@ GROUP_WGRADS = os.environ.get("W2VS_GROUP_WGRADS", "1") != "0"
 # the selected-rows (last) layer's weight gradients join the grouped launch of its neighbour; W2VS_SEL_DEFER=0: four launches of their own (A/B)
 SEL_DEFER = os.environ.get("W2VS_SEL_DEFER", "1") != "0"
 LN_DEFER = os.environ.get("W2VS_LN_DEFER", "1") != "0"      # the layers' dgamma / dbeta partial sums wait for the grouped weight-gradient call
+# how deferred weight gradients are put into grouped launches: "1" = packed by tile count (_WgradPacker), "0" = whole layer pairs
+# (round 3), "auto" = packed only when a layer pair does not fit one round of the chip anyway (the large model: 192 tiles per
+# layer, 192 + 64 = 256; 18.84 -> 18.44 ms per step).  The base model's pairs (216 tiles) stay: packed to 252 its launches take
+# 175 us instead of 154 (the launch time follows the tile count there) and the 36-tile remainder costs what the saved launch gave
+PACK_WGRADS = os.environ.get("W2VS_PACK_WGRADS", "auto")
+
+
+class _WgradPacker:
+    """Decides which deferred weight gradients go into which grouped launch (w2vs_layer_wgrads_parts).  An item is one GEMM of
+    one layer (fc2, fc1, out_proj, fused QKV - the order they become available in) with its count of 256 x 256 output tiles;
+    a launch takes items oldest first while they fit `cap` tiles (the CU count), at most 12 GEMMs of at most 4 layers.
+    pack = False restores round 3's rule: two whole layers per launch."""
+    BITS = (("fc2", 2), ("fc1", 1), ("out", 8), ("qkv", 4))
+
+    @staticmethod
+    def tile_counts(E, F):
+        t = lambda n, k: ((n + 255) // 256) * ((k + 255) // 256)      # noqa: E731
+        return {"fc2": t(E, F), "fc1": t(F, E), "out": t(E, E), "qkv": t(3 * E, E)}
+
+    def __init__(self, stream, E, F, cap, pack):
+        self.tiles = self.tile_counts(E, F)
+        self.stream, self.cap, self.pack = stream, cap, pack
+        self.items = []            # [desc, jj, bit, tiles]
+        self.ln_due = {}           # jj -> True while the layer's LayerNorm partial sums are still to be reduced
+        self.layers = {}           # jj -> desc of every layer that has something pending
+
+    def add(self, d, jj):
+        for name, bit in self.BITS:
+            self.items.append([d, jj, bit, self.tiles[name]])
+        self.ln_due[jj] = True
+        self.layers[jj] = d
+
+    def holds(self, jj):
+        return jj in self.layers
+
+    def pending_tiles(self):
+        return sum(it[3] for it in self.items)
+
+    def due(self):
+        if not self.pack:
+            return len(self.layers) >= 2
+        return self.pending_tiles() >= self.cap
+
+    def complete_prefix(self, ran):
+        """how many of the `ran` layers run so far (backward order) have nothing pending, counted from the first"""
+        return min(self.layers) if self.layers else ran
+
+    def launch(self):
+        chosen, tiles, jjs = [], 0, []
+        for it in self.items:
+            new_layer = it[1] not in jjs
+            if len(chosen) == 12 or (new_layer and len(jjs) == 4):
+                break
+            if self.pack and chosen and tiles + it[3] > self.cap:
+                continue
+            chosen.append(it)
+            tiles += it[3]
+            if new_layer:
+                jjs.append(it[1])
+        if not chosen:
+            return
+        parts = {jj: 0 for jj in jjs}
+        for it in chosen:
+            parts[it[1]] |= it[2]
+        for jj in jjs:
+            if self.ln_due.pop(jj, False):
+                parts[jj] |= 16
+        ids = {id(it) for it in chosen}
+        self.items = [it for it in self.items if id(it) not in ids]
+        left = {it[1] for it in self.items}
+        descs = [self.layers[jj] for jj in jjs]
+        for jj in jjs:
+            if jj not in left:
+                del self.layers[jj]
+        arr = (type(descs[0]) * len(descs))(*descs)
+        pm = (C.c_int32 * len(descs))(*[parts[jj] for jj in jjs])
+        _lib.call("w2vs_layer_wgrads_parts", arr, pm, len(descs), self.stream)
+
+
 
 _POS_TABLES = {}
 
@@ -672,19 +751,28 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         # K loops and no exchange.  The first layer of a pair keeps its dY operands (ws_f, ws_e0, ws_qkv, ws_e3) while the second
         # one runs its backward on a second set of those four buffers.
         pair = PAIR_WGRADS and e3 is not None and len(st.layers) > 1
-        set2 = None
+        # Round 4: the launches are PACKED.  A grouped launch is one round of the chip whatever its tile count, and a base layer is
+        # 36 + 36 + 9 + 27 tiles: whole GEMMs of up to four layers are put together until they make ~252 of 256 tiles (a layer pair
+        # is 216); the large model's 64 + 64 + 16 + 48 make exactly 256.  Operand sets rotate over NSET layers accordingly.
+        tiles_per_layer = sum(_WgradPacker.tile_counts(E, F).values())
+        ncu_ = st.layers[0]["desc"].num_cu or 256
+        pack = pair and (PACK_WGRADS == "1" or (PACK_WGRADS == "auto" and 2 * tiles_per_layer > ncu_))
+        NSET = 4 if pack else 2
+        base_set = {"ws_e0": offs["ws_e0"], "ws_f": offs["ws_f"], "ws_qkv": offs["ws_qkv"], "ws_e3": e3.data_ptr() if e3 is not None else None}
+        op_sets, more_sets = [base_set], []
         if pair:
-            ws2 = ops.empty((R * (E + F + 3 * E + E),), BF16, dev)
-            p2 = ws2.data_ptr()
-            set2 = {"ws_e0": p2, "ws_f": p2 + 2 * R * E, "ws_qkv": p2 + 2 * R * (E + F), "ws_e3": p2 + 2 * R * (E + F + 3 * E)}
-        pending = None                                     # (layer descriptor, jj) whose weight gradients are still to be launched
+            for _ in range(NSET - 1):
+                ws2 = ops.empty((R * (E + F + 3 * E + E),), BF16, dev)
+                p2 = ws2.data_ptr()
+                more_sets.append(ws2)
+                op_sets.append({"ws_e0": p2, "ws_f": p2 + 2 * R * E, "ws_qkv": p2 + 2 * R * (E + F), "ws_e3": p2 + 2 * R * (E + F + 3 * E)})
         alt = ops.empty((R, E), BF16, dev)
         d_in_bufs[1] = alt.data_ptr()
         # the selected-rows (last) layer joins the grouped weight-gradient launches when it gets its own scatter targets
         sel_scatter = ops.empty((2, R, E), BF16, dev) if (pair and SEL_DEFER and st.layers[-1]["desc"].sel_idx) else None
         ds_bufs = [ops.empty((R, E), BF16, dev), ops.empty((R, E), BF16, dev)] if not post_ln else None
         # one slab of LayerNorm partial sums per operand set: [2 norms][<= 768 blocks][2E] fp32 (w2vs_layer_desc.ln_part)
-        ln_parts = ops.empty((2, 2 * 768 * 2 * E), torch.float32, dev) if (pair and LN_DEFER) else None
+        ln_parts = ops.empty((NSET, 2 * 768 * 2 * E), torch.float32, dev) if (pair and LN_DEFER) else None
         cur = dx
         # every layer's four weights are transposed for the dgrad GEMMs in ONE launch (was 4 launches per layer)
         per_t = 3 * E * E + E * E + 2 * E * F
@@ -707,6 +795,24 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         tn_ws = ops.tn_workspace(dev)
         for rec in st.layers:
             rec["desc"].tn_ws, rec["desc"].tn_ws_bytes = tn_ws.data_ptr(), tn_ws.numel() * 4
+        packer = _WgradPacker(stream, E, F, cap=ncu_, pack=pack)
+        nl_ = len(st.layers)
+        reported = 0                                       # layers (in backward order) whose milestone went out
+
+        def report():
+            # a milestone is reported only once every gradient at or above it is final, i.e. never while any of a layer's weight
+            # gradients (or LayerNorm partial sums) are pending.  pre-LN: a layer's call also finalises the NEXT norm's gradient
+            # (layer li+1's self_attn_layer_norm), so the arena is final from that layer's start only one layer later
+            nonlocal reported
+            done = packer.complete_prefix(ran)
+            while reported < done:
+                reported += 1
+                if post_ln:
+                    ready(milestone_offset(A, f"encoder.layers.{st.layers[nl_ - reported]['li']}."))
+                elif reported > 1:
+                    ready(milestone_offset(A, f"encoder.layers.{st.layers[nl_ - reported + 1]['li']}."))
+
+        ran = 0
         for jj, rec in enumerate(reversed(st.layers)):
             li = rec["li"]
             pre = f"encoder.layers.{li}."
@@ -725,14 +831,16 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
             if d.sel_idx and deferred:
                 d.ws_s0, d.ws_s1 = sel_scatter[0].data_ptr(), sel_scatter[1].data_ptr()
             d.defer_wgrads = 1 if deferred else 0
-            if deferred and ln_parts is not None:
-                d.ln_part, d.ln_part_bytes = ln_parts[jj & 1].data_ptr(), ln_parts[jj & 1].numel() * 4
-            else:
-                d.ln_part, d.ln_part_bytes = None, 0
             d.wgrad_overwrite = 1 if (deferred and overwrite_wgrads) else 0
-            if deferred and (jj & 1):                      # consecutive layers alternate between the two operand sets
-                for f_ in ("ws_e0", "ws_f", "ws_qkv", "ws_e3"):
-                    setattr(d, f_, set2[f_])
+            d.ln_part, d.ln_part_bytes = None, 0
+            if deferred:                                   # consecutive layers rotate over the operand sets
+                while packer.holds(jj - NSET):             # ... whose previous user must have launched everything
+                    packer.launch()
+                    report()
+                for f_, v_ in op_sets[jj % NSET].items():
+                    setattr(d, f_, v_)
+                if ln_parts is not None:
+                    d.ln_part, d.ln_part_bytes = ln_parts[jj % NSET].data_ptr(), ln_parts[jj % NSET].numel() * 4
             off_w = A.offsets[pre + "self_attn.q_proj.weight"][0]
             off_b = A.offsets[pre + "self_attn.q_proj.bias"][0]
             fp = A.flat.data_ptr()
@@ -743,34 +851,23 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
                            ("g_w2", pre + "fc2.weight"), ("g_b2", pre + "fc2.bias"), ("g_ln2_g", nb[0]), ("g_ln2_b", nb[1])):
                 setattr(d, f_, fp + 4 * A.offsets[n_][0])
             _lib.call("w2vs_layer_bwd", C.byref(d), stream)
-            launched = not deferred
+            ran = jj + 1
             if deferred:
-                if pending is None:
-                    pending = d
-                else:
-                    arr = (type(d) * 2)(pending, d)
-                    _lib.call("w2vs_layer_wgrads", arr, 2, stream)
-                    pending, launched = None, True
-            # a milestone is reported only once every gradient at or above it is final, i.e. never while a layer's weight
-            # gradients are pending.  pre-LN: this call also finalised the NEXT norm's gradient (layer li+1's
-            # self_attn_layer_norm), so the arena is final from that layer's start only once this one is done - one layer late
-            if launched:
-                if post_ln:
-                    ready(milestone_offset(A, pre))
-                elif jj > 0:
-                    ready(milestone_offset(A, f"encoder.layers.{st.layers[len(st.layers) - jj]['li']}."))
+                packer.add(d, jj)
+                while packer.due():
+                    packer.launch()
+            report()
             if jj & 1:
                 cur = alt
             else:
                 cur = ws[(3 * R * E + R * F + 3 * R * E):(3 * R * E + R * F + 3 * R * E) + R * E].view(R, E)
             if not post_ln:
                 d_stream = ds_bufs[jj & 1]
-        if pending is not None:                             # an odd layer count: the last one goes alone (K split as before)
-            arr = (type(pending) * 1)(pending)
-            _lib.call("w2vs_layer_wgrads", arr, 1, stream)
-            pending = None
+        while packer.items:                                 # what is left goes out in as few launches as it takes
+            packer.launch()
+        report()
         dx = cur
-        st._bwd_ws = (ws, alt, delta, e3, ds_bufs, ws2 if pair else None, sel_scatter, ln_parts)
+        st._bwd_ws = (ws, alt, delta, e3, ds_bufs, more_sets, sel_scatter, ln_parts)
     if post_ln:
         d_x0 = dx
     elif st.layers:

@@ -224,7 +224,7 @@ def gemm_tn(a, b, out_f32, *, M, N, K, lda, ldb, ldc, a_off=0, batch=1, sA=0, sB
 
 
 def gemm_tn_group(problems, num_cu=256):
-    """problems: up to 8 dicts with the keyword arguments of ``gemm_tn`` (a, b, out_f32, M, N, K, lda, ldb, ldc[, alpha,
+    """problems: up to 12 dicts with the keyword arguments of ``gemm_tn`` (a, b, out_f32, M, N, K, lda, ldb, ldc[, alpha,
     colsum_out]): weight-gradient GEMMs sharing the reduction dimension, enqueued as ONE launch (w2vs_gemm_tn_group)."""
     n = len(problems)
     arr = (GemmDesc * n)()
