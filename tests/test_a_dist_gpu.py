@@ -160,6 +160,98 @@ def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
         assert n1 > clip                                                   # the case does clip
 
 
+# LayerDrop per UPDATE, the same on both ranks: the host RNG streams are seeded identically on every rank (fairseq_cli/train.py:67-68),
+# and the bucket boundaries of the exchange follow the backward's milestones, which must therefore agree between ranks
+KEEP2 = ([True, True, False, True], [True, True, True, True])
+
+
+def batch_of(update, rank, B, L):
+    return torch.randn(B, L, generator=torch.Generator().manual_seed(100 + 10 * update + rank))
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_two_ranks_on_one_gpu_equal_accumulated_local_step(nccl_group, wire, tmp_path):
+    """Row (e) with TWO real ranks: two processes share this box's one GPU (gloo carries the all-reduce of the device arena
+    through host memory - RCCL wants one GPU per rank), each with its own utterances and its own mask / negative draws (LayerDrop
+    as the shared host RNG stream gives it: the same layer on both ranks, one dropped in the first update), two updates with clipping.  (1) both ranks must hold bit-identical masters, moments and bf16
+    images afterwards; (2) they must equal ONE process that accumulates the same two micro-batches per update
+    (update_freq = 2): sum of gradients / sum of sample sizes is what both compute
+    (fs/distributed/legacy_distributed_data_parallel.py:94-170, fs/trainer.py:769-774); (3) every arena element was
+    all-reduced exactly once per update, from the milestones of the real backward of each rank."""
+    import subprocess
+    import sys
+    from wav2vec_s_amd import trainer, ops
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist2_worker.py")
+    outs = [str(tmp_path / ("rank%d.pt" % r)) for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), outs[r], wire, "2"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    r0, r1 = (torch.load(o, weights_only=False) for o in outs)
+    for k in ("arena", "p32", "m", "v", "p16"):
+        if not torch.equal(r0[k], r1[k]):
+            bad = torch.nonzero(r0[k] != r1[k]).view(-1)
+            names = {}
+            for i in bad.tolist()[:20000]:
+                for n, (off, numel, _) in r0["offsets"].items():
+                    if off <= i < off + numel:
+                        names[n] = names.get(n, 0) + 1
+            raise AssertionError("%s differs between the ranks in %d of %d elements (max |d| %.3g); by tensor: %s" % (
+                k, bad.numel(), r0[k].numel(), float((r0[k].double() - r1[k].double()).abs().max()), names))
+    assert r0["gn"] == r1["gn"] and r0["step"] == r1["step"] == 2
+    for r in (r0, r1):
+        for launched in r["launched"]:
+            cov = np.zeros(r["numel"], dtype=np.int32)
+            for lo, hi in launched:
+                cov[lo:hi] += 1
+            assert (cov == 1).all() and len(launched) >= 3
+    # the same two updates in one process: update_freq = 2 over rank 0's and rank 1's micro-batch
+    B, L = 2, 16000
+    w, cfg, model, crit = _build(SMALL)
+    step = trainer.TrainStep(model, crit, world_size=1, lr=1e-3, clip_norm=0.05, update_freq=2, arena_gib=1.0)
+    for u in range(2):
+        for rank in range(2):
+            model.inject_draws(_draws(cfg, B, L, KEEP2[u], seed=7 + 10 * u + rank)())
+            step({"net_input": {"source": batch_of(u, rank, B, L).to(BF).cuda()}})
+        torch.cuda.synchronize()
+        if u == 0:
+            # after ONE update: the summed gradient, the moments and - within what Adam's own inputs explain - every parameter
+            f = {k: t.cuda() for k, t in r0["first"].items()}
+            g1 = step.flat.arena.flat
+            tol = 2e-4 if wire == "fp32" else 4e-3           # bf16 wire: each rank's contribution is rounded before the sum
+            assert float((g1.double() - f["arena"].double()).norm()) / float(g1.double().norm()) < tol
+            assert float((step.flat.m.double() - f["m"].double()).norm()) / float(f["m"].double().norm()) < tol
+            if wire == "fp32":
+                assert _same_update(step.flat.p32, f["p32"], 1e-3, step.flat.arena, adam=((step.flat.m, step.flat.v), (f["m"], f["v"]), 1))
+            else:
+                assert torch.equal(f["arena"], f["arena"].to(BF).float())      # what the ranks hold came back as a bf16 image
+    assert step.flat.step == 2
+    # after the second one the two runs have seen slightly different weights (Adam moves a near-zero-gradient element by up
+    # to lr whatever its size): the trajectories stay together, no longer element for element
+    gn = step.grad_norm()
+    tol2 = 2e-2 if wire == "fp32" else 0.2
+    assert abs(gn - r0["gn"]) / gn < tol2
+    m1, p1 = step.flat.m, step.flat.p32
+    m2, p2 = r0["m"].cuda(), r0["p32"].cuda()
+    assert float((m1.double() - m2.double()).norm()) / float(m1.double().norm()) < tol2
+    diff = (p1.double() - p2.double()).abs()
+    assert float((diff > 1e-4).double().mean()) < tol2 and float(diff.max()) <= 2 * 2.1 * 1e-3
+    ops.ARENA.deactivate()
+
+
 def test_rccl_bf16_wire_rounds_only_the_exchanged_gradient(nccl_group):
     """GradExchange(wire_dtype="bf16") on RCCL: every range is packed into a bf16 image (w2vs_f32_to_bf16), all-reduced there
     (half the bytes: the reference reduces in the model dtype, legacy_distributed_data_parallel.py:100-115) and unpacked into

@@ -136,3 +136,41 @@ def test_grad_exchange_flushes_before_the_tail():
         assert (covered == 1).all()
         if flush_at >= 0:
             assert before_finish[-1] == (1500, 4000)          # launched at the milestone, not at finish()
+
+
+def test_grad_exchange_ranges_do_not_depend_on_the_milestones_a_rank_saw():
+    """Two ranks whose LayerDrop decisions differ report different milestones above flush_at (the one that dropped the
+    first layer never reports flush_at itself: its next milestone is already the extractor side's).  The all-reduce ranges must still pair up: the same list, in the same
+    order, on both - only WHEN a range goes out may differ."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import wav2vec_s_amd  # noqa: F401
+    from wav2vec_s_amd.trainer import GradExchange
+
+    class _Work:
+        def wait(self):
+            pass
+
+    class _Dist:
+        class ReduceOp:
+            SUM = 0
+
+        def all_reduce(self, t, op=None, group=None, async_op=False):
+            return _Work()
+
+    flat = torch.zeros(10_000)
+    tail = (1_200, 700, 0)                     # the extractor's milestones: the same on every rank
+    seen = []
+    for encoder_offsets in ((9_500, 8_000, 6_100, 4_000, 2_500, 1_500), (9_000, 6_100, 2_500), (8_000, 1_600), (1_500,), ()):
+        ex = GradExchange(flat, _Dist(), bucket_elems=3_000, flush_at=1_500)
+        ex.begin_step()
+        for off in encoder_offsets + tail:
+            ex.on_ready(off)
+        ex.finish()
+        covered = np.zeros(10_000, dtype=np.int32)
+        for lo, hi in ex.launched:
+            covered[lo:hi] += 1
+        assert (covered == 1).all()
+        seen.append(list(ex.launched))
+    assert all(s == seen[0] for s in seen), seen
+    assert seen[0][:3] == [(7000, 10000), (4000, 7000), (1500, 4000)]

@@ -585,6 +585,21 @@ def test_fused_adam_matches_fairseq_formula(ops):
     out = torch.zeros(1, device="cuda")
     ops.sumsq(grad.cuda(), out)
     assert abs(float(out) - float((grad ** 2).sum())) / float((grad ** 2).sum()) < 1e-5
+    # the norm is reproducible to the bit (partials summed in index order by the last block, no float atomics): data-parallel
+    # replicas that hold the same summed gradient must derive the same clip coefficient.  Also: accumulation into out, odd n
+    big = torch.randn(5_000_003, generator=torch.Generator().manual_seed(3)).cuda()
+    vals = []
+    for _ in range(6):
+        o = torch.zeros(1, device="cuda")
+        ops.sumsq(big[:5_000_000], o)
+        vals.append(float(o))
+    assert len(set(vals)) == 1, vals
+    assert abs(vals[0] - float((big[:5_000_000].double() ** 2).sum())) / vals[0] < 1e-5
+    o = torch.full((1,), 2.5, device="cuda")
+    ops.sumsq(big[:1_000_003], o)
+    ops.sumsq(big[:1_000_003], o)
+    want = 2.5 + 2 * float((big[:1_000_003].double() ** 2).sum())
+    assert abs(float(o) - want) / want < 1e-5
 
 
 @pytest.mark.parametrize("clip", [25.0, 0.0])

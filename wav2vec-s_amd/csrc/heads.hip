@@ -4,6 +4,7 @@
 //   gumbel_quantize   a14  fs/modules/gumbel_vector_quantizer.py:141-202
 //   infonce_logits    a16 gather + a17 compute_preds   fs/models/wav2vec/wav2vec2.py:521-542
 //   ce_rows           a19  fs/criterions/wav2vec_criterion.py:64-68, 133-155
+#include <mutex>
 #include <stdlib.h>
 #include "common.h"
 #include "w2vs_internal.h"
@@ -941,8 +942,13 @@ int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n,
   return hip_check(hipGetLastError(), "adam_step");
 }
 
-// out[0] += sum x^2 (fp32): gradient norm for clip_grad_norm_ (fs/utils.py:341-386)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
+// out[0] += sum x^2 (fp32): gradient norm for clip_grad_norm_ (fs/utils.py:341-386).
+// DETERMINISTIC (round 4): every block leaves its partial sum in a scratch row; the block that finishes last adds the
+// partials in index order.  With float atomics from 1 024 blocks the norm differed in its last bit from run to run - and so
+// did the clip coefficient, and with it the whole Adam update, between two data-parallel ranks holding the SAME summed
+// gradient (tests/test_a_dist_gpu.py::test_two_ranks_on_one_gpu...): the reference's replicas stay bit-identical.
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out, float* part, unsigned* cnt) {
   float s = 0.f;
   const long n4 = n >> 2, stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -952,13 +958,54 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, floa
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[(n4 << 2) + threadIdx.x]; s += t * t; }
   s = wave_sum(s);
   __shared__ float red[4];
+  __shared__ int last;
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));   // one same-address atomic per block
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&part[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(cnt, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float a = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = wave_sum(a);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] += (red[0] + red[1]) + (red[2] + red[3]);
+    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this region
+  }
+}
+// scratch of the kernel above: 16 regions per device (launches in flight on different streams do not share one), zeroed
+// synchronously when made
+struct SumsqScratch { float* part = nullptr; unsigned* cnt = nullptr; unsigned next = 0; };
+static SumsqScratch* sumsq_scratch() {
+  static std::mutex mu;
+  static SumsqScratch per_dev[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  SumsqScratch& sc = per_dev[dev];
+  if (!sc.part) {
+    void* p = nullptr;
+    const size_t bytes = 16 * (SUMSQ_BLOCKS + 64) * sizeof(float);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    sc.part = (float*)p;
+    sc.cnt = (unsigned*)p + 16 * SUMSQ_BLOCKS;
+  }
+  return &sc;
 }
 int sumsq(const float* x, long n, float* out, hipStream_t st) {
   if (!x || !out || n <= 0 || ((uintptr_t)x & 15)) return set_error("sumsq: bad arguments (x must be 16-byte aligned)");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, st, x, n, out);
+  SumsqScratch* sc = sumsq_scratch();
+  if (!sc) return set_error("sumsq: scratch allocation failed");
+  const unsigned r = sc->next++ & 15;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, out, sc->part + r * SUMSQ_BLOCKS, sc->cnt + r * 4);
   return hip_check(hipGetLastError(), "sumsq");
 }
 

@@ -184,15 +184,26 @@ class GradExchange:
 
     def on_ready(self, offset: int):
         """Elements [offset, numel) are final.  Launch whole buckets; keep a remainder < bucket for later
-        unless offset == 0 (flush everything)."""
+        unless offset == 0 (flush everything).
+
+        The launched ranges must be the SAME on every rank whatever milestones it saw (ranks whose host RNG streams differ
+        LayerDrop different layers and report different offsets; a rank-dependent boundary would pair collectives of
+        different sizes).  So: above ``flush_at`` whole buckets count down from the top of the arena and never reach below
+        ``flush_at``; the remainder of that zone goes out as [flush_at, hi) as soon as a milestone reaches flush_at; below it
+        only the extractor's milestones remain, which do not depend on LayerDrop, and each flushes what is final."""
         offset = max(0, min(int(offset), self.hi))
-        while self.hi - offset >= self.bucket or (offset == 0 and self.hi > 0):
-            lo = max(offset, self.hi - self.bucket) if self.hi - offset >= self.bucket else 0
-            if offset == 0 and self.hi - lo < self.bucket:
-                lo = 0
+        while self.hi > 0:
+            floor = self.flush_at if 0 <= self.flush_at < self.hi else 0
+            tgt = max(offset, floor)
+            if self.hi - tgt >= self.bucket:
+                lo = self.hi - self.bucket
+            elif offset <= floor and (floor > 0 or offset == 0):
+                lo = floor                                 # the zone is complete: its remainder (< bucket) goes out
+            else:
+                break
             self._launch(lo, self.hi)
             self.hi = lo
-        if 0 <= offset <= self.flush_at and self.hi > offset:
+        if 0 <= offset <= self.flush_at and offset < self.hi <= self.flush_at:
             self._launch(offset, self.hi)
             self.hi = offset
 
