@@ -176,8 +176,17 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # W2VS_REHEARSE_ONE_GPU=1: the driver's multi-rank launch line on a ONE-GPU box - every rank on cuda:0, gloo instead of
+        # RCCL (which wants a GPU per rank).  Checks the rendezvous, the exchange from real backward milestones, the barriers
+        # and the one JSON line; its timing means nothing (two ranks share the card, the arena travels through host memory)
+        rehearse = os.environ.get("W2VS_REHEARSE_ONE_GPU") == "1"
+        if rehearse:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
