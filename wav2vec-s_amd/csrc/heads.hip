@@ -943,12 +943,12 @@ int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n,
 }
 
 // out[0] += sum x^2 (fp32): gradient norm for clip_grad_norm_ (fs/utils.py:341-386).
-// DETERMINISTIC (round 4): every block leaves its partial sum in a scratch row; the block that finishes last adds the
-// partials in index order.  With float atomics from 1 024 blocks the norm differed in its last bit from run to run - and so
+// DETERMINISTIC (round 4): every block leaves its partial sum in a scratch row; a one-block launch adds the partials in
+// index order.  With float atomics from 1 024 blocks the norm differed in its last bit from run to run - and so
 // did the clip coefficient, and with it the whole Adam update, between two data-parallel ranks holding the SAME summed
 // gradient (tests/test_a_dist_gpu.py::test_two_ranks_on_one_gpu...): the reference's replicas stay bit-identical.
 constexpr int SUMSQ_BLOCKS = 1024;
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out, float* part, unsigned* cnt) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* part) {
   float s = 0.f;
   const long n4 = n >> 2, stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -958,29 +958,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, floa
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[(n4 << 2) + threadIdx.x]; s += t * t; }
   s = wave_sum(s);
   __shared__ float red[4];
-  __shared__ int last;
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&part[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    last = atomicAdd(cnt, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// second launch (a "last block done" tail inside the first kernel needs a device-scope release per block: 96 us against 68):
+// one block adds the partials in index order
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* part, int nparts, float* out) {
   float a = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
   a = wave_sum(a);
-  __syncthreads();
+  __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    out[0] += (red[0] + red[1]) + (red[2] + red[3]);
-    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this region
-  }
+  if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
-// scratch of the kernel above: 16 regions per device (launches in flight on different streams do not share one), zeroed
+// scratch of the kernels above: 16 regions per device (launches in flight on different streams do not share one), zeroed
 // synchronously when made
 struct SumsqScratch { float* part = nullptr; unsigned* cnt = nullptr; unsigned next = 0; };
 static SumsqScratch* sumsq_scratch() {
@@ -1005,7 +998,9 @@ int sumsq(const float* x, long n, float* out, hipStream_t st) {
   SumsqScratch* sc = sumsq_scratch();
   if (!sc) return set_error("sumsq: scratch allocation failed");
   const unsigned r = sc->next++ & 15;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, out, sc->part + r * SUMSQ_BLOCKS, sc->cnt + r * 4);
+  float* part = sc->part + r * SUMSQ_BLOCKS;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, x, n, part);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, part, SUMSQ_BLOCKS, out);
   return hip_check(hipGetLastError(), "sumsq");
 }
 
