@@ -907,6 +907,7 @@ int relu_gate(const void* x, const void* gate, void* out, long n, hipStream_t st
 // Fused Adam over flat arrays (fs/optim/adam.py:205-229: decoupled weight decay, bias-corrected
 // step size) with the fp32 master / bf16 working copy split of fs/optim/fp16_optimizer.py:205-218.
 // g is the fp32 gradient arena; grad_scale folds the 1/sample_size (and clip) factor in.
+template <int NT_>
 __global__ void adam_kernel(float* p32, bf16* p16, float* m, float* v, const float* g, long n, float lr_wd, float step_size,
                             float b1, float b2, float eps, const float* scale_dev, float scale_host) {
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -916,7 +917,13 @@ __global__ void adam_kernel(float* p32, bf16* p16, float* m, float* v, const flo
   // moments and the bf16 image keep their values, no weight decay (NaN * 0 would poison all four).  The reference raises
   // FloatingPointError before optimizer.step in that case (fs/trainer.py:791-793); the host raises it from the flag later.
   if (gs == 0.f) return;
-  f32x4 pv = *(f32x4*)(p32 + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i), gv = *(const f32x4*)(g + i);
+  f32x4 pv, mv, vv, gv;
+  if (NT_) {   // every stream is touched once per update: no reuse to keep in L2
+    pv = __builtin_nontemporal_load((f32x4*)(p32 + i)); mv = __builtin_nontemporal_load((f32x4*)(m + i));
+    vv = __builtin_nontemporal_load((f32x4*)(v + i)); gv = __builtin_nontemporal_load((const f32x4*)(g + i));
+  } else {
+    pv = *(f32x4*)(p32 + i); mv = *(f32x4*)(m + i); vv = *(f32x4*)(v + i); gv = *(const f32x4*)(g + i);
+  }
   bf16x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -928,8 +935,13 @@ __global__ void adam_kernel(float* p32, bf16* p16, float* m, float* v, const flo
     pv[e] = pe;
     o[e] = f2bf(pe);
   }
-  *(f32x4*)(p32 + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
-  *(bf16x4*)(p16 + i) = o;
+  if (NT_) {
+    __builtin_nontemporal_store(pv, (f32x4*)(p32 + i)); __builtin_nontemporal_store(mv, (f32x4*)(m + i));
+    __builtin_nontemporal_store(vv, (f32x4*)(v + i));
+  } else {
+    *(f32x4*)(p32 + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+  }
+  *(bf16x4*)(p16 + i) = o;          // the working copy IS read again (next forward): normal policy
 }
 int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n, float lr, float b1, float b2, float eps,
               float wd, int step, const float* scale_dev, float scale_host, hipStream_t st) {
@@ -937,8 +949,17 @@ int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n,
   if (step < 1) return set_error("adam_step: step counts from 1");
   double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
   float step_size = (float)(lr * sqrt(bc2) / bc1);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, p32, (bf16*)p16, m, v, g, n,
-                     wd * lr, step_size, b1, b2, eps, scale_dev, scale_host);
+  // nontemporal loads / stores of the four fp32 streams (each touched once per update: 2.7 GB that would otherwise displace
+  // what the next forward wants from L2 / the Infinity Cache): kernel 474 -> 425 us (6.0 -> 6.7 TB/s), step 8.60 -> 8.46 ms -
+  // more than the kernel's own gain.  The same hint on the saved gelu' / LayerNorm inputs / gradient-norm read measured
+  // nothing (EXPERIMENTS.md).  W2VS_ADAM_NT=0 is the A/B.
+  static const int nt_env = [] { const char* e = getenv("W2VS_ADAM_NT"); return e ? atoi(e) : 1; }();
+  if (nt_env)
+    hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, p32, (bf16*)p16, m, v, g, n,
+                       wd * lr, step_size, b1, b2, eps, scale_dev, scale_host);
+  else
+    hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, p32, (bf16*)p16, m, v, g, n,
+                       wd * lr, step_size, b1, b2, eps, scale_dev, scale_host);
   return hip_check(hipGetLastError(), "adam_step");
 }
 
