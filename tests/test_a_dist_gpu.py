@@ -113,16 +113,18 @@ def _same_update(p1, p2, lr, arena, adam=None):
     return True
 
 
-@pytest.mark.parametrize("clip,update_freq,keep", [
-    (0.0, 1, None), (0.05, 1, None), (0.05, 2, [True, False, True, True]), (0.0, 2, [True, True, False, True]),
-    (0.05, 8, [True, True, False, True])])      # update_freq 8 = BASELINE configs[2] (one exchange + one Adam per 8 micro-batches)
-def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep):
+@pytest.mark.parametrize("clip,update_freq,keep,pack", [
+    (0.0, 1, None, "auto"), (0.05, 1, None, "auto"), (0.05, 2, [True, False, True, True], "auto"), (0.0, 2, [True, True, False, True], "auto"),
+    (0.05, 8, [True, True, False, True], "auto"),      # update_freq 8 = BASELINE configs[2] (one exchange + one Adam per 8 micro-batches)
+    (0.05, 1, None, "1"), (0.0, 2, [True, False, True, True], "1")])   # weight-gradient launches packed across layers: milestones follow the oldest pending layer
+def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep, pack, monkeypatch):
     """TrainStep with the gradient exchange ACTIVE (world_size-2 code path on a 1-rank RCCL group: every all-reduce is an
     identity) must leave the same arena, the same Adam state and the same parameters as the plain single-GPU step on the
     same draws - with clipping, gradient accumulation and a LayerDrop-ped layer - and every arena element must be
     all-reduced exactly once, from the milestones the real backward reports
     (fs/distributed/legacy_distributed_data_parallel.py:81-170, fs/trainer.py:769-774)."""
-    from wav2vec_s_amd import trainer, ops
+    from wav2vec_s_amd import trainer, ops, engine
+    monkeypatch.setattr(engine, "PACK_WGRADS", pack)
     B, L = 2, 16000
     src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
     res = []
