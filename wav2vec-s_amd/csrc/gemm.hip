@@ -1688,7 +1688,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
           }
     }
   }
-  if (keep) {
+  if (keep && !(g.dbg & 4)) {                              // dbg bit 2: the output tile is not stored
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_group_kernel(Tn8GroupP g) {
           *dst = o;
         }
   }
-  if (do_cs && fq == 0) {   // every accumulator row of cs holds the same sums: lane fr owns output row (i-tile wc = slot 0) * 16 + fr
+  if (do_cs && fq == 0 && !(g.dbg & 8)) {   // (dbg bit 3: no bias column sums)  every accumulator row of cs holds the same sums: lane fr owns output row (i-tile wc = slot 0) * 16 + fr
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
       const int row = m0 + wr * 128 + mh * 64 + wc * 16 + fr;
