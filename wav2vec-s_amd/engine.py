@@ -682,12 +682,15 @@ def wgrad_overwrite_ranges(st: State, A: Arena):
 
 
 def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None, d_out=None, on_ready=None,
-             overwrite_wgrads: bool = False):
+             overwrite_wgrads: bool = False, wt_cache=None):
     """Accumulates parameter gradients into the arena.  d_logits fp32 [B*M, K+1] (rows (b, m));
     d_pen = dLoss/d features_pen, d_prob_ppl = dLoss/d prob_perplexity as fp32 DEVICE scalars (read by
     the kernels, never by the host: no sync); d_out bf16 [B, T, E] for features_only.
     on_ready(offset): called at milestones - every arena element at index >= offset is final.
-    overwrite_wgrads: the ranges of ``wgrad_overwrite_ranges`` are written, not accumulated (the caller did not zero them)."""
+    overwrite_wgrads: the ranges of ``wgrad_overwrite_ranges`` are written, not accumulated (the caller did not zero them).
+    wt_cache: {"have": set, "store": dict} kept by the caller while the weights do not change (the micro-batches of one update,
+    trainer.TrainStep with update_freq > 1): the transposed weights of the input-gradient GEMMs are made once per update, not
+    once per backward.  None: made here, every time."""
     ready = on_ready if on_ready is not None else (lambda off: None)
     cfg, W = st.cfg, st.W
     B, T, C0, N, Tp = st.B, st.T, st.C0, st.N, st.Tp
@@ -776,21 +779,36 @@ def backward(st: State, A: Arena, *, d_logits=None, d_pen=None, d_prob_ppl=None,
         cur = dx
         # every layer's four weights are transposed for the dgrad GEMMs in ONE launch (was 4 launches per layer)
         per_t = 3 * E * E + E * E + 2 * E * F
-        wt_all = ops.empty((len(st.layers) * per_t,), BF16, dev)
+        have = wt_cache["have"] if wt_cache is not None else None
+        wt_all = ops.empty((len(st.layers) * per_t,), BF16, dev) if wt_cache is None else None
         items = []
         for j_, rec in enumerate(st.layers):
             d = rec["desc"]
-            base = wt_all.data_ptr() + 2 * j_ * per_t
+            if wt_cache is None:
+                base, fresh = wt_all.data_ptr() + 2 * j_ * per_t, True
+            else:                                          # a persistent buffer per layer (not the step arena), filled once per update
+                buf_ = wt_cache["store"].get(rec["li"])
+                if buf_ is None or buf_.numel() != per_t or buf_.device != torch.device(dev):
+                    buf_ = wt_cache["store"][rec["li"]] = torch.empty((per_t,), dtype=BF16, device=dev)
+                    have.discard(rec["li"])
+                base, fresh = buf_.data_ptr(), rec["li"] not in have
+                have.add(rec["li"])
             d.wqkv_t, d.wo_t = base, base + 2 * 3 * E * E
             d.w1_t, d.w2_t = base + 2 * 4 * E * E, base + 2 * (4 * E * E + E * F)
-            items += [(d.wqkv, d.wqkv_t, 3 * E, E), (d.wo, d.wo_t, E, E), (d.w1, d.w1_t, F, E), (d.w2, d.w2_t, E, F)]
+            if fresh:
+                items += [(d.wqkv, d.wqkv_t, 3 * E, E), (d.wo, d.wo_t, E, E), (d.w1, d.w1_t, F, E), (d.w2, d.w2_t, E, F)]
         st._dgrad_w = {}
+        conv_fresh = have is None or "conv" not in have
         for ci_ in range(1, len(cfg.conv_layers)):        # conv dgrad operands ride in the same launch
             _, ck, cs = cfg.conv_layers[ci_]
             buf, its = ops.conv_dgrad_weight_items((id(A), ci_), st.packed[ci_], ck, cs)
             st._dgrad_w[ci_] = buf
-            items += its
-        ops.transpose_multi(items)
+            if conv_fresh:
+                items += its
+        if have is not None:
+            have.add("conv")
+        if items:
+            ops.transpose_multi(items)
         st._wt_all = wt_all
         tn_ws = ops.tn_workspace(dev)
         for rec in st.layers:

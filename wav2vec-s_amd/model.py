@@ -271,6 +271,8 @@ class _HotPath(torch.autograd.Function):
         # trainer.TrainStep, first micro-batch of an update: it zeroed the arena EXCEPT engine.wgrad_overwrite_ranges
         ow = bool(flat_mode and getattr(model, "_wgrad_overwrite", False))
         model._wgrad_overwrite = False
+        # trainer.TrainStep with update_freq > 1: the transposed weights live as long as the update (FlatParams.wt_cache)
+        wtc = getattr(model, "_wt_cache", None) if flat_mode else None
         if st.features_only:
             engine.backward(st, A, d_out=grads[0].to(BF16).contiguous())
         elif ctx.fused is not None:
@@ -280,13 +282,13 @@ class _HotPath(torch.autograd.Function):
                 raise W2vsError("fused criterion: no gradient arrived for the loss (or the forward ran without grad)")
             dsc = ops.infonce_loss_bwd(g.detach().float().reshape(1).contiguous(), dl, c_pen, c_ppl)
             engine.backward(st, A, d_logits=dl, d_pen=dsc[0:1], d_prob_ppl=dsc[1:2], on_ready=model._on_grad_ready,
-                            overwrite_wgrads=ow)
+                            overwrite_wgrads=ow, wt_cache=wtc)
         else:
             d_logits, d_pen, d_ppl = grads[0], grads[1], grads[2]
             d_logits = torch.zeros_like(st.logits) if d_logits is None else d_logits.float().contiguous()
             fix = lambda t: None if t is None else t.detach().float().reshape(1).contiguous()  # noqa: E731
             engine.backward(st, A, d_logits=d_logits, d_pen=fix(d_pen), d_prob_ppl=fix(d_ppl),
-                            on_ready=model._on_grad_ready, overwrite_wgrads=ow)
+                            on_ready=model._on_grad_ready, overwrite_wgrads=ow, wt_cache=wtc)
         if flat_mode:
             ctx.st = None
             return (None,) * (6 + len(names))   # gradients stay in the arena (see trainer.FlatParams)

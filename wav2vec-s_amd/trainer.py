@@ -58,6 +58,7 @@ class _Roctx:
 ROCTX = _Roctx()
 # W2VS_OVERWRITE_WGRADS=0: zero the whole arena at the start of an update and let every weight gradient accumulate (A/B)
 OVERWRITE_WGRADS = os.environ.get("W2VS_OVERWRITE_WGRADS", "1") != "0"
+WT_CACHE = os.environ.get("W2VS_WT_CACHE", "1") != "0"     # A/B: 0 = transposed weights rebuilt by every backward
 
 
 class FlatParams:
@@ -89,6 +90,9 @@ class FlatParams:
         self.m = torch.zeros_like(self.p32)
         self.v = torch.zeros_like(self.p32)
         self.step = 0
+        # transposed weights of the input-gradient GEMMs, valid while the weights do not change (engine.backward, wt_cache):
+        # "have" is cleared by whoever changes a weight - the optimizer step, a load, a hand-written p.data
+        self.wt_cache = {"have": set(), "store": {}}
         model._flat = self
         # parameters are VIEWS of p16: load_state_dict / load_pretrained_model / manual init write the bf16 image only, and
         # the next adam_step would rewrite it from a stale fp32 master.  Re-derive the master after every load.
@@ -123,6 +127,7 @@ class FlatParams:
         ``load_state_dict`` does it through a hook).  Mirrors FP16Optimizer rebuilding ``fp32_params`` from the model
         (fs/optim/fp16_optimizer.py:53-77)."""
         self.p32.copy_(self.p16)
+        self.wt_cache["have"].clear()
 
     # ---- optimizer state (fs/optim/fp16_optimizer.py:151-177 + torch Adam state: step, exp_avg, exp_avg_sq) ----
     def state_dict(self):
@@ -139,6 +144,7 @@ class FlatParams:
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
         self.p16.copy_(self.p32)          # the working copy is the rounded master, as after every update
+        self.wt_cache["have"].clear()
 
 
 class GradExchange:
@@ -384,6 +390,10 @@ class TrainStep:
         # is process-wide; another TrainStep without an exchange sets it back).
         _lib.call("w2vs_gemm_tn8_max_split", 1 if self.exchange is not None else 2)
         if first:
+            # update_freq > 1: the weights stay as they are until the closing micro-batch's Adam, so their transposes (the B
+            # operands of the input-gradient GEMMs: 340 MB of traffic, ~80 us per backward) are made once per update
+            f.wt_cache["have"].clear()
+            self.model._wt_cache = f.wt_cache if (self.update_freq > 1 and WT_CACHE) else None
             self.ss_acc = 0
             if self.exchange is not None:
                 self.exchange.begin_step()
@@ -455,4 +465,6 @@ class TrainStep:
                 ops.adam_step(f.p32, f.p16, f.m, f.v, f.arena.flat, lr=lr, beta1=self.betas[0], beta2=self.betas[1],
                               eps=self.eps, weight_decay=self.wd, step=f.step, scale_host=scale, scale_dev=scale_dev)
             self.last_lr = lr
+            f.wt_cache["have"].clear()            # the weights have changed
+            self.model._wt_cache = None
         return loss.detach()
