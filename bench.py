@@ -130,6 +130,42 @@ def side_workload(name, no_cpu):
     return bench_rnnt.main([], cpu_baseline=None if no_cpu else _cpu_baseline_rnnt)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks the way the driver's own line does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`) as a
+    CHILD process - this process has not touched the GPU (no HIP call so far; counting devices does not initialise it) and
+    never will - relay its output and leave with its exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("W2VS_REHEARSE_ONE_GPU") != "1":
+        print("bench.py: --gpus %d but %d GPUs are visible; refusing to time fewer ranks than asked for" % (n, have), file=sys.stderr)
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if ln not in js:
+            print(ln, file=sys.stderr)              # launcher chatter stays off stdout: ONE JSON line
+    if proc.returncode != 0 or len(js) != 1:
+        print("bench.py: the %d-rank launch failed (exit code %d, %d result lines)" % (n, proc.returncode, len(js)), file=sys.stderr)
+        sys.exit(proc.returncode or 3)
+    rec = json.loads(js[0])
+    if rec.get("n_gpus") != n or rec.get("ranks_seen") != n:
+        print("bench.py: asked for %d ranks, the run reports n_gpus=%r ranks_seen=%r" % (n, rec.get("n_gpus"), rec.get("ranks_seen")),
+              file=sys.stderr)
+        sys.exit(3)
+    print(js[0])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,11 +200,17 @@ def main():
         if args.samples == L_SAMPLES:
             args.samples = 320000
 
+    force_dist = os.environ.get("W2VS_FORCE_DIST") == "1"   # exercise the RCCL path with a 1-rank group
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not force_dist:
+        return self_launch(args.gpus)             # `python bench.py --gpus N`: start the N ranks here, before any GPU call
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not force_dist:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    force_dist = os.environ.get("W2VS_FORCE_DIST") == "1"   # exercise the RCCL path with a 1-rank group
+    backend = None
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -182,12 +224,26 @@ def main():
         rehearse = os.environ.get("W2VS_REHEARSE_ONE_GPU") == "1"
         if rehearse:
             local_rank = 0
+        elif world > torch.cuda.device_count():
+            print("bench.py: %d ranks but only %d GPUs are visible (one process per GPU)" % (world, torch.cuda.device_count()),
+                  file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
+        backend = "gloo" if rehearse else "nccl"
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # the ranks the collective library itself sees: one all-reduce of ones over the group that carries the gradients
+        seen = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
+        if ranks_seen != (1 if force_dist and world == 1 else args.gpus) or dist.get_world_size() != ranks_seen:
+            print("bench.py: --gpus %d but %s saw %d ranks (world size %d)" % (args.gpus, backend, ranks_seen, dist.get_world_size()),
+                  file=sys.stderr)
+            sys.exit(2)
     else:
+        ranks_seen = 1
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
@@ -249,6 +305,7 @@ def main():
             step_fn(next_sample())
         barrier()
         fl = 0.0
+        fl_exec[0] = 0.0
         audio_done[0] = 0.0
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]   # per-step GPU time without a host sync
         marks[0].record()
@@ -258,12 +315,14 @@ def main():
             loss = step_fn(next_sample())
             marks[i + 1].record()
             fl += flops_mod.step_flops_from_state(model._last_state)     # host arithmetic on the step's own draws
+            fl_exec[0] += flops_mod.executed_step_flops_from_state(model._last_state)
         barrier()
         el = time.perf_counter() - t0
         per_step_ms[:] = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)]
         return el, fl, loss
 
     per_step_ms = []
+    fl_exec = [0.0]
 
     for i in range(args.warmup):
         model.set_num_updates(i)
@@ -271,6 +330,7 @@ def main():
     barrier()
     ops.GEMM_TIMER.enable()
     elapsed, step_flops, loss_t = timed(0, args.steps, args.warmup)
+    exec_flops = fl_exec[0]
     ops.GEMM_TIMER.disable()
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -283,8 +343,14 @@ def main():
     roof = ops.GEMM_TIMER.report(PEAK_BF16_TFLOPS)
     # step level: algorithmic FLOPs of the steps actually run / their time / the bf16 MFMA peak
     ach = step_flops / elapsed / 1e12
+    # frac: the reference's arithmetic (SURVEY 8d calculator) over the step time; frac_executed: the same net of the rows of
+    # the last kept layer this build never computes (flops.pruned_forward_flops) - the MFMA work actually issued
+    ach_x = exec_flops / elapsed / 1e12
     roof["step"] = {"flops_per_step": round(step_flops / args.steps / 1e12, 4), "unit": "TFLOP", "achieved_tflops": round(ach, 1),
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "note": "this run's own draws (sampled contexts%s)" % ("" if large else ", LayerDrop 0.05")}
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "flops_executed_per_step": round(exec_flops / args.steps / 1e12, 4), "executed_tflops": round(ach_x, 1),
+                    "frac_executed": round(ach_x / PEAK_BF16_TFLOPS, 4),
+                    "note": "this run's own draws (sampled contexts%s)" % ("" if large else ", LayerDrop 0.05")}
     st_main = model._last_state
     # HBM-side bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     # of this same command (counters cannot be read in-process).  The newest committed summary is quoted only if it was
@@ -322,6 +388,8 @@ def main():
             torch.cuda.synchronize()
             roof["measured_gemm_peak_tflops"] = round(5 * 2.0 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
             roof["measured_gemm_peak_note"] = "w2vs_gemm_nt, 8192^3 bf16, random operands, same process, after the timed region"
+            roof["step"]["frac_of_measured_peak"] = round(ach / roof["measured_gemm_peak_tflops"], 4)
+            roof["step"]["frac_executed_of_measured_peak"] = round(ach_x / roof["measured_gemm_peak_tflops"], 4)
             del gx, gw
         except Exception as e:          # noqa: BLE001
             roof["measured_gemm_peak_note"] = "not measured: %r" % (e,)
@@ -340,7 +408,7 @@ def main():
     st = st_main
     out = {
         "metric": "audio-seconds/s/GPU, wav2vec-S %s pretrain step, 1/2/4/8 MI355X" % ("large" if large else "base"),
-        "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": None if ms_median is None else round(ms_median, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
@@ -351,7 +419,7 @@ def main():
                                 "wav2vec-S base (12L d768, 90.3M params) pretrain step: fwd + InfoNCE/diversity/penalty loss + "
                                 "bwd%s%s; %d x %d samples (%.1f audio-s) per GPU; yaml dropouts, LayerDrop 0.05, sampled "
                                 "block contexts; random-init weights; unread rows of the last encoder layer pruned (exact)") % (
-                                   (" + RCCL grad all-reduce (%s on the wire)" % args.wire) if world > 1 else "",
+                                   (" + %s grad all-reduce (%s on the wire)" % ("RCCL" if backend == "nccl" else "gloo (one-GPU rehearsal, not RCCL)", args.wire)) if world > 1 else "",
                                    ("" if args.no_optimizer else " + fused Adam") + (
                                        "" if args.update_freq == 1 else " (update_freq %d: exchange + Adam every %d-th step)" % (
                                            args.update_freq, args.update_freq)), B, L, audio_s),

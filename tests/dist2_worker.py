@@ -15,7 +15,9 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     rank, port, out, wire, updates = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=2)
+    import datetime
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=2,
+                            timeout=datetime.timedelta(seconds=300))   # a dead peer fails the collective, not the test's clock
     from test_a_dist_gpu import SMALL, BF, KEEP2, _build, _draws, batch_of
     from wav2vec_s_amd import trainer
     w, cfg, model, crit = _build(SMALL)                    # the same seed on both ranks: identical initial weights

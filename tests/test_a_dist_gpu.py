@@ -162,6 +162,96 @@ def test_rccl_exchange_equals_local_step(nccl_group, clip, update_freq, keep, pa
         assert n1 > clip                                                   # the case does clip
 
 
+KEEP_MICRO = ([True, False, True, True], [True, True, False, True], [True, True, True, True], [False, True, True, True])
+
+
+def test_update_freq_with_a_different_layerdrop_draw_per_micro_batch(nccl_group, monkeypatch):
+    """fs/models/wav2vec/wav2vec_S.py:414-423 draws LayerDrop in EVERY forward, so the micro-batches of one update
+    (fs/trainer.py:644-660, update_freq = 4) drop different layers: the first one drops a layer later ones keep, and keeps one a
+    later one drops.  The write-instead-of-accumulate path (the first micro-batch WRITES the weight gradients of ITS kept
+    layers, the complement is zeroed: engine.wgrad_overwrite_ranges) under the 1-rank RCCL exchange must leave the arena,
+    the moments and the update that plain local accumulation into a fully zeroed arena (W2VS_OVERWRITE_WGRADS=0) leaves."""
+    from wav2vec_s_amd import trainer, ops
+    B, L, uf = 2, 16000, 4
+    srcs = [torch.randn(B, L, generator=torch.Generator().manual_seed(40 + i)).to(BF).cuda() for i in range(uf)]
+    res = []
+    for world, overwrite in ((1, False), (2, True)):
+        monkeypatch.setattr(trainer, "OVERWRITE_WGRADS", overwrite)
+        w, cfg, model, crit = _build(SMALL)
+        step = trainer.TrainStep(model, crit, world_size=world, lr=1e-3, clip_norm=0.05, update_freq=uf, arena_gib=1.0)
+        if world == 2:
+            step.exchange.bucket = 50_000
+        for i in range(uf):
+            model.inject_draws(_draws(cfg, B, L, KEEP_MICRO[i], seed=7 + i)())
+            step({"net_input": {"source": srcs[i]}})
+            if overwrite and i == 0:
+                assert len(model._last_state.kept) == 3
+        torch.cuda.synchronize()
+        assert step.flat.step == 1 and step.micro == 0
+        if world == 2:
+            cov = np.zeros(step.flat.arena.numel, dtype=np.int32)
+            for lo, hi in step.exchange.launched:
+                cov[lo:hi] += 1
+            assert (cov == 1).all()
+        res.append((step.flat.arena.flat.clone(), step.flat.p32.clone(), step.flat.m.clone(), step.flat.v.clone(), step.grad_norm()))
+        arena = step.flat.arena
+        ops.ARENA.deactivate()
+    (g1, p1, m1, v1, n1), (g2, p2, m2, v2, n2) = res
+    # per layer too: a range the first micro-batch did not write (its dropped layer) and one a later one skipped
+    for li in range(4):
+        off, numel, _ = arena.offsets["encoder.layers.%d.fc1.weight" % li]
+        a, b = g1[off:off + numel].double(), g2[off:off + numel].double()
+        assert float(a.norm()) > 0 and float((a - b).norm() / a.norm()) < 2e-4, li
+    assert float((g1.double() - g2.double()).norm() / g1.double().norm()) < 2e-4
+    assert float((m1.double() - m2.double()).norm() / m1.double().norm()) < 2e-4
+    assert _same_update(p1, p2, 1e-3, arena, adam=((m1, v1), (m2, v2), 1))
+    assert abs(n1 - n2) / n1 < 1e-4
+
+
+class _FeaturesOnlyCriterion:
+    """What a CTC / fine-tune criterion does with the model: ``features_only=True`` and a loss of its own on the encoder output
+    (fs/models/wav2vec/wav2vec2.py:602-603, 695-699).  A fixed linear functional here."""
+
+    def __init__(self):
+        self.w = None
+
+    def __call__(self, model, sample, sync_logging=False):
+        x = model(sample["net_input"]["source"], None, mask=False, features_only=True)["x"]
+        if self.w is None:
+            self.w = torch.randn(x.shape, generator=torch.Generator().manual_seed(11)).to(x.device)
+        return (x.float() * self.w).sum(), int(x.shape[0] * x.shape[1]), {}
+
+
+@pytest.mark.parametrize("update_freq", [1, 2])
+def test_features_only_criterion_under_the_overwriting_step(update_freq, monkeypatch):
+    """Round-4 advisor finding: TrainStep leaves the encoder weight-gradient ranges un-zeroed for the first micro-batch of an
+    update to WRITE (engine.wgrad_overwrite_ranges); the features_only branch of the backward must honour that flag as the
+    pre-training branches do, or a second update accumulates onto the first one's gradients.  Two updates with a
+    features_only criterion: the arena after the SECOND one must equal the run that zeroes everything and accumulates."""
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    res = []
+    for overwrite in (False, True):
+        monkeypatch.setattr(trainer, "OVERWRITE_WGRADS", overwrite)
+        w, cfg, model, _ = _build(SMALL)
+        step = trainer.TrainStep(model, _FeaturesOnlyCriterion(), lr=0.0, weight_decay=0.0, update_freq=update_freq, arena_gib=1.0)
+        for _ in range(2 * update_freq):                  # lr = 0: both updates see the same weights, the same gradient
+            model.inject_draws(_draws(cfg, B, L, [True, True, False, True])())
+            step({"net_input": {"source": src}})
+        torch.cuda.synchronize()
+        assert step.flat.step == 2
+        res.append(step.flat.arena.flat.clone())
+        arena = step.flat.arena
+        ops.ARENA.deactivate()
+    g0, g1 = res
+    off, numel, _ = arena.offsets["encoder.layers.0.fc1.weight"]
+    assert float(g0[off:off + numel].abs().max()) > 0
+    assert float((g0.double() - g1.double()).norm() / g0.double().norm()) < 2e-4      # 1.0 before the fix (twice the gradient)
+    off, numel, _ = arena.offsets["encoder.layers.2.fc1.weight"]
+    assert float(g1[off:off + numel].abs().max()) == 0                               # the dropped layer stays zero
+
+
 # LayerDrop per UPDATE, the same on both ranks: the host RNG streams are seeded identically on every rank (fairseq_cli/train.py:67-68),
 # and the bucket boundaries of the exchange follow the backward's milestones, which must therefore agree between ranks
 KEEP2 = ([True, True, False, True], [True, True, True, True])
@@ -190,17 +280,27 @@ def test_two_ranks_on_one_gpu_equal_accumulated_local_step(nccl_group, wire, tmp
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist2_worker.py")
     outs = [str(tmp_path / ("rank%d.pt" % r)) for r in range(2)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # each rank writes its output to a file of its own: draining two PIPEs one after the other lets the second rank block on
+    # a full pipe buffer (RCCL / gloo warnings) while the first waits for it inside a collective
+    log_paths = [str(tmp_path / ("rank%d.log" % r)) for r in range(2)]
+    log_files = [open(lp, "wb") for lp in log_paths]
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(port), outs[r], wire, "2"], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=420)
-        except subprocess.TimeoutExpired:
-            for q in procs:
+                              stdout=log_files[r], stderr=subprocess.STDOUT) for r in range(2)]
+    import time
+    deadline = time.time() + 420
+    try:
+        while any(p.poll() is None for p in procs):
+            if time.time() > deadline or any(p.poll() not in (None, 0) for p in procs):
+                break                                                  # timeout, or one rank died: do not wait for its peer
+            time.sleep(0.2)
+    finally:
+        for q in procs:
+            if q.poll() is None:
                 q.kill()
-            raise
-        logs.append(o.decode(errors="replace")[-3000:])
+                q.wait()
+        for f in log_files:
+            f.close()
+    logs = [open(lp, "rb").read().decode(errors="replace")[-3000:] for lp in log_paths]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     r0, r1 = (torch.load(o, weights_only=False) for o in outs)
     for k in ("arena", "p32", "m", "v", "p16"):

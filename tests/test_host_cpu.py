@@ -260,3 +260,23 @@ def test_attention_dropout_hash_statistics_within_and_across_seeds():
     a_lo, _ = fields((5 << 32) | s0, off=delta)
     b_lo, _ = fields((5 << 32) | s0b)
     assert np.array_equal(a_lo, b_lo)
+
+
+def _run_bench(args, env_extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "W2VS_FORCE_DIST", "W2VS_REHEARSE_ONE_GPU")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="needs a host with fewer than 2 GPUs")
+def test_bench_gpus_n_never_times_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself or fail: it must not time ONE GPU and
+    print n_gpus 1 (round-4 review).  On a host with fewer than N GPUs it exits non-zero before touching a device; a launcher
+    that started a different number of ranks than --gpus is refused as well."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0 and "GPUs are visible" in r.stderr and '"metric"' not in r.stdout, (r.returncode, r.stderr[-500:])
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and '"metric"' not in r.stdout, (r.returncode, r.stderr[-500:])

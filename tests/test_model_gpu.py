@@ -325,6 +325,60 @@ def test_large_full_length_step_matches_oracle():
     _assert_parity(rep, grads, loss=1e-3, loss_free=1e-3, act=2e-2, bar_scale=1.7, median=4e-2)
 
 
+def test_large_full_depth_and_length_forward_matches_oracle_and_every_gradient_is_live():
+    """BASELINE configs[3] at its OWN size in one run: 24 layers x d 1024 x 16 heads x ffn 4096, final_dim 768, pre-LN, conv
+    bias, 7 extractor LayerNorms, loss_weights [0.1, 0], 3 x 320 000 samples (T = 999, N = 1 496, R = 4 488 token rows;
+    wav2vec-S_large_librivox.yaml:16-22, 52-70).  The oracle runs FORWARD only (one CPU pass over 3.2 TFLOP; its backward at
+    this size is what the width-only and length-only tests above bound): loss with and without the code selection pinned
+    within 1e-3, conv output / features / encoder output within 2e-2; the HIP backward of the same step must leave a finite,
+    non-zero gradient in every parameter (k_proj.bias, analytically zero, excepted)."""
+    kw = dict(BASE, encoder_layers=24, encoder_embed_dim=1024, encoder_ffn_embed_dim=4096, encoder_attention_heads=16,
+              layer_norm_first=True, conv_bias=True, feature_grad_mult=1.0, final_dim=768)
+    m_ctx, r_ctx, lw = 16, 8, (0.1, 0.0)
+    w, model, P, ocfg, source, draws, mask, neg, noise = _setup(kw, 3, 320000, 15, m_ctx, r_ctx)
+    ocfg.loss_weights = lw
+    model = model.cuda().train()
+    model.inject_draws(draws)
+    crit = w.Wav2vecCriterion(infonce=True, loss_weights=list(lw), log_keys=["prob_perplexity", "code_perplexity", "temp"])
+    loss, sample_size, log = crit(model, {"net_input": {"source": source.cuda()}})
+    loss.backward()
+    st = model._last_state
+    assert (st.T, st.N, len(st.kept)) == (999, 1496, 24)
+    Pd = {k: v.detach() for k, v in P.items()}
+    col = {}
+    with torch.no_grad():
+        free = O.forward_loss(Pd, source.float(), ocfg, mask_indices=torch.from_numpy(mask), neg_idx=neg, main_context=m_ctx,
+                              right_context=r_ctx, tau=2.0, gumbel_noise=noise, layer_keep=draws.layer_keep)
+        ref = O.forward_loss(Pd, source.float(), ocfg, mask_indices=torch.from_numpy(mask), neg_idx=neg, main_context=m_ctx,
+                             right_context=r_ctx, tau=2.0, gumbel_noise=noise, layer_keep=draws.layer_keep, collect=col,
+                             force_code_idx=st.qst.idx.cpu())
+    rep = {"tag": "large_full_depth_length", "loss_hip": float(loss), "loss_ref": float(ref["loss"]), "loss_ref_unpinned": float(free["loss"])}
+    rep["loss_rel"] = abs(rep["loss_hip"] - rep["loss_ref"]) / abs(rep["loss_ref"])
+    rep["loss_rel_unpinned"] = abs(rep["loss_hip"] - rep["loss_ref_unpinned"]) / abs(rep["loss_ref_unpinned"])
+    rep["conv_out"] = rel(st.y_last, col[f"conv{len(ocfg.conv_layers) - 1}"].transpose(1, 2))
+    rep["features"] = rel(st.feats, col["features"])
+    if getattr(st, "enc_is_sel", False):
+        rep["enc_out"] = rel(st.enc, col["enc_out"][torch.from_numpy(mask)])
+    else:
+        rep["enc_out"] = rel(st.enc.view(st.B, st.N, -1)[:, :st.T], col["enc_out"])
+    rep["code_idx_equal"] = float((st.qst.idx.cpu().long() == col["q_idx"]).float().mean())
+    dead, bad = [], []
+    for n, p_ in model.named_parameters():
+        g_ = p_.grad
+        if g_ is None or not bool(torch.isfinite(g_.float()).all()):
+            bad.append(n)
+        elif float(g_.float().abs().max()) == 0 and "k_proj.bias" not in n:
+            dead.append(n)
+    rep["grad_missing_or_nonfinite"], rep["grad_all_zero"] = bad, dead
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_large_full_depth_length.json"), "w") as f:
+        json.dump(rep, f, indent=1, default=str)
+    assert rep["loss_rel"] < 1e-3 and rep["loss_rel_unpinned"] < 1e-3, rep
+    assert rep["conv_out"] < 2e-2 and rep["features"] < 2e-2 and rep["enc_out"] < 2e-2, rep
+    assert rep["code_idx_equal"] >= 0.975, rep
+    assert not bad and not dead, rep
+
+
 def test_large_style_model_step_matches_oracle():
     """pre-LN encoder, conv bias, LayerNorm in every conv layer (layer_norm_num=7), odd T, no grad mult."""
     kw = dict(BASE, encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256, encoder_attention_heads=2,

@@ -277,6 +277,7 @@ def test_streaming_calls_replay_a_graph_per_shape():
               pos_type="sin", load_pretrained_model_from=None)
     torch.manual_seed(5)
     model = streaming.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(**kw)).to(BF).cuda().eval()
+    model.graph_after = 0                                              # capture at first sight (the default waits for repeats)
     g = torch.Generator().manual_seed(1)
     srcs = {L: [torch.randn(1, L, generator=g).to(BF).cuda() for _ in range(3)] for L in (16000, 24320)}
 
@@ -310,3 +311,50 @@ def test_streaming_calls_replay_a_graph_per_shape():
     with torch.no_grad():
         out = model(srcs[16000][2], pm, None, False, True)
     assert len([k for k in model._graphs if isinstance(k, tuple)]) == n_before
+
+
+def test_growing_prefix_session_captures_only_repeated_shapes():
+    """A streaming session re-encodes a growing prefix, so every call of an utterance has a new shape: a shape is captured only
+    after ``graph_after`` eager calls (the first utterances of a fixed chunk schedule run eagerly, later ones replay), the
+    cache is least-recently-used with a bound on the number of graphs, and every call - eager, captured or replayed - gives
+    the eager result (round-4 advisor finding on streaming.py)."""
+    from wav2vec_s_amd import streaming
+    kw = dict(extractor_mode="layer_norm", encoder_layers=2, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+              encoder_attention_heads=2, final_dim=128, quantize_targets=True, feature_grad_mult=0.1, dropout=0.0,
+              attention_dropout=0.0, dropout_input=0.0, dropout_features=0.0, encoder_layerdrop=0.0, latent_vars=40,
+              conv_feature_layers="[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64,2,2)] * 2", main_context=8, right_context=4,
+              pos_type="sin", load_pretrained_model_from=None)
+    torch.manual_seed(6)
+    model = streaming.BlockWiseWav2Vec2Model.build_model(argparse.Namespace(**kw)).to(BF).cuda().eval()
+    assert model.graph_after == 2
+    model.max_graphs = 3
+    g = torch.Generator().manual_seed(2)
+    chunk, n_chunks = 2560, 5
+    utts = [torch.randn(1, chunk * n_chunks, generator=g).to(BF).cuda() for _ in range(4)]
+
+    def call(src, graphs):
+        model.graph_calls = graphs
+        try:
+            with torch.no_grad():
+                return model(src, None, None, False, True)["encoder_out"][0].clone()
+        finally:
+            model.graph_calls = True
+    for ui, u in enumerate(utts):
+        for c in range(3, n_chunks + 1):                               # prefixes of 3, 4, 5 chunks: three shapes per utterance
+            pre = u[:, :c * chunk].contiguous()
+            assert torch.equal(call(pre, True), call(pre, False)), (ui, c)
+        st = model.graph_stats()
+        if ui < 2:
+            assert st["captures"] == 0 and st["hits"] == 0             # the first two utterances never pay for a capture
+        elif ui == 2:
+            assert st["captures"] == 3 and st["graphs"] == 3
+        else:
+            assert st["captures"] == 3 and st["hits"] == 3             # the fourth utterance replays all three
+    # a fourth shape, seen often enough, evicts the least recently used graph (the 3-chunk prefix), not the newest
+    pre6 = torch.randn(1, chunk * 6, generator=g).to(BF).cuda()
+    for _ in range(3):
+        assert torch.equal(call(pre6, True), call(pre6, False))
+    st = model.graph_stats()
+    assert st["graphs"] == 3 and st["captures"] == 4 and st["bytes"] > 0
+    keys = [k[0][1] for k in model._graphs if isinstance(k, tuple)]
+    assert chunk * 3 not in keys and chunk * 6 in keys

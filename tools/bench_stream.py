@@ -85,6 +85,28 @@ def main(argv=None):
             model.graph_calls = True
         rep["streaming_call"].append({"prefix_s": sec, "ms_per_call": round(ms, 3), "ms_per_call_eager": round(ms_e, 3),
                                       "block_ms": 16 * 20, "real_time_factor": round(ms / (16 * 20), 4)})
+    # a growing-prefix session (what a streaming client does): 320 ms chunks up to 10 s, four utterances of the same chunk
+    # schedule.  With graph_after = 2 the first two run eagerly, the third captures (the miss cost), the fourth replays.
+    chunk = 5120
+    n_chunks = 31
+    fresh = streaming.BlockWiseWav2Vec2Model(cfg).to(torch.bfloat16).cuda().eval()
+    fresh.load_state_dict(model.state_dict())
+    per_utt = []
+    with torch.no_grad():
+        for ui in range(4):
+            u = torch.randn(1, chunk * n_chunks, generator=g).to(torch.bfloat16).cuda()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for c in range(2, n_chunks + 1):
+                fresh(u[:, :c * chunk].contiguous(), None, None, False, True)
+            torch.cuda.synchronize()
+            per_utt.append(round((time.perf_counter() - t0) * 1e3 / (n_chunks - 1), 3))
+    gs = fresh.graph_stats()
+    rep["growing_prefix_session"] = {"chunk_ms": 320, "utterance_s": 9.92, "calls_per_utterance": n_chunks - 1,
+                                     "ms_per_call_by_utterance": per_utt, "graph_after": fresh.graph_after,
+                                     "hits": gs["hits"], "misses": gs["misses"], "captures": gs["captures"],
+                                     "graphs_held": gs["graphs"], "bytes_held": gs["bytes"],
+                                     "note": "utterances 1-2 eager, 3 = capture (miss cost), 4 = replay"}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(rep, f, indent=1)

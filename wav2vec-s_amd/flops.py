@@ -56,3 +56,34 @@ def step_flops_from_state(st) -> float:
     """3 x forward FLOPs of the step whose engine.State is ``st`` (its own sampled context and LayerDrop outcome)."""
     f = forward_flops(st.cfg, st.B, st.source.shape[1], m=st.m, r=st.r, layers_kept=len(st.kept), M=st.M)
     return 3.0 * f["total"]
+
+
+def _main_query_pairs(Tp: int, m: int, r: int) -> int:
+    """``attention_pairs`` without the right-context copies as QUERIES (their outputs are dropped, wav2vec_S.py:425-427)."""
+    nblk_rc = Tp // m if r > 0 else 0
+    pairs, b, t = 0, 0, 0
+    while t < Tp:
+        mb = min(m, Tp - t)
+        pairs += mb * (min((b + 1) * m, Tp) + (r if b < nblk_rc else 0))
+        t += mb
+        b += 1
+    return pairs
+
+
+def pruned_forward_flops(st) -> float:
+    """Forward FLOPs of the reference's arithmetic that this build does NOT execute in the step of ``st``: of the last kept
+    encoder layer only the masked frames are read downstream (fs/models/wav2vec/wav2vec2.py:590, 641), so its attention runs
+    for the main-frame queries only and out_proj / fc1 / fc2 on the B*M selected rows (engine.forward, selected-rows mode)."""
+    if not getattr(st, "enc_is_sel", False) or not st.kept:
+        return 0.0
+    cfg = st.cfg
+    E, Fd = cfg.encoder_embed_dim, cfg.encoder_ffn_embed_dim
+    rows_all, rows_sel = st.B * st.N, st.B * st.M
+    lin = (rows_all - rows_sel) * (2 * E * E + 2 * 2 * E * Fd)
+    att = st.B * 4 * (attention_pairs(st.Tp, st.m, st.r) - _main_query_pairs(st.Tp, st.m, st.r)) * E
+    return float(lin + att)
+
+
+def executed_step_flops_from_state(st) -> float:
+    """``step_flops_from_state`` net of the pruned rows (3 x: forward, data gradient, weight gradient are all skipped)."""
+    return step_flops_from_state(st) - 3.0 * pruned_forward_flops(st)

@@ -274,7 +274,10 @@ class _HotPath(torch.autograd.Function):
         # trainer.TrainStep with update_freq > 1: the transposed weights live as long as the update (FlatParams.wt_cache)
         wtc = getattr(model, "_wt_cache", None) if flat_mode else None
         if st.features_only:
-            engine.backward(st, A, d_out=grads[0].to(BF16).contiguous())
+            # the same flags as the pre-training branches: TrainStep zeroed the arena EXCEPT the overwrite ranges whatever the
+            # criterion asked the model for (a CTC / fine-tune criterion runs it with features_only=True)
+            engine.backward(st, A, d_out=grads[0].to(BF16).contiguous(), on_ready=model._on_grad_ready,
+                            overwrite_wgrads=ow, wt_cache=wtc)
         elif ctx.fused is not None:
             dl, c_pen, c_ppl = ctx.fused
             g = grads[0]

@@ -99,19 +99,36 @@ class BlockWiseWav2Vec2Model(Wav2Vec2Model):
     def build_model(cls, args, task=None):
         return cls(args)
 
-    # A streaming call is ~150 small kernels whose GPU time is their dispatch latency (1.3 / 1.6 / 2.0 ms at 2 / 10 / 30 s
+    # A streaming call is ~150 small kernels whose GPU time is their dispatch latency (0.9 / 1.4 / 1.8 ms at 2 / 10 / 30 s
     # prefixes, nearly flat in the prefix length).  For a fixed input shape the whole launch sequence - index upload, extractor,
-    # prologue, twelve composite layer calls, gather - is the same every call, so inference calls without a padding mask are
-    # captured ONCE per shape into a HIP graph and replayed (W2VS_STREAM_GRAPH=0, or ``graph_calls = False``, runs them eagerly).
+    # prologue, twelve composite layer calls, gather - is the same every call, so inference calls without a padding mask can be
+    # captured per shape into a HIP graph and replayed (W2VS_STREAM_GRAPH=0, or ``graph_calls = False``, runs them eagerly).
+    # A real streaming session re-encodes a GROWING prefix: every call of an utterance has a new shape, and a capture costs two
+    # warm-up forwards, a capture, an instantiate and the activations it holds.  So a shape is captured only once it has been
+    # seen ``graph_after`` times eagerly (fixed chunk schedules make later utterances repeat the shapes of the first; a shape
+    # met once never pays for a capture), graphs are evicted least-recently-used, and both their number and the bytes they
+    # hold are bounded.
     graph_calls = os.environ.get("W2VS_STREAM_GRAPH", "1") != "0"
-    max_graphs = 64        # captured shapes kept (a graph holds its activations: ~40 MB at a 10 s prefix); oldest dropped first
+    graph_after = 2                 # eager calls of a shape before it is captured
+    max_graphs = 128                # captured shapes kept (30 s at 320 ms chunks = 94 shapes)
+    max_graph_bytes = 6 << 30       # device bytes the kept graphs may hold (~40 MB each at a 10 s prefix)
 
     def _graph_key(self):
         return tuple((p.data_ptr(), p._version, p.dtype) for p in self._named_params_cached()[1])
 
+    def graph_stats(self):
+        """{"hits", "misses", "captures", "graphs", "bytes"} of the per-shape graph cache (tools/bench_stream.py reports them)."""
+        st = self.__dict__.setdefault("_gstats", {"hits": 0, "misses": 0, "captures": 0})
+        graphs = self.__dict__.get("_graphs") or {}
+        ents = [v for k, v in graphs.items() if isinstance(k, tuple)]
+        return dict(st, graphs=len(ents), bytes=sum(e[4] for e in ents))
+
     def _forward_graphed(self, source):
-        """-> (x [B, T, C], state): the features-only forward of this shape through its captured graph."""
-        graphs = self.__dict__.setdefault("_graphs", {})
+        """-> (x [B, T, C], state) through the captured graph of this shape, or None while the shape is not worth one yet."""
+        import collections
+        graphs = self.__dict__.setdefault("_graphs", collections.OrderedDict())
+        seen = self.__dict__.setdefault("_gseen", collections.OrderedDict())
+        stats = self.__dict__.setdefault("_gstats", {"hits": 0, "misses": 0, "captures": 0})
         wkey = self._graph_key()
         # a graph bakes in the weights' addresses AND the launch-side repacks of the call it was captured from: recapture
         # everything when a parameter changed (in place, reloaded, moved: its (data_ptr, _version, dtype)) or when the repack
@@ -121,24 +138,40 @@ class BlockWiseWav2Vec2Model(Wav2Vec2Model):
         key = (tuple(source.shape), source.dtype, source.device.index)
         ent = graphs.get(key)
         if ent is None:
+            stats["misses"] += 1
+            n = seen.pop(key, 0) + 1
+            seen[key] = n
+            while len(seen) > 4096:
+                seen.popitem(last=False)
+            if n <= self.graph_after:
+                return None                              # run this call eagerly
+            seen.pop(key, None)
             cur = torch.cuda.current_stream()
+            before = torch.cuda.memory_allocated()
             static_in = source.clone()
             side = torch.cuda.Stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):                # warm-up: lazy allocations inside the library, the launch-weight
-                for _ in range(2):                       # cache and the pinned index buffer all exist before the capture
-                    super().forward(static_in, None, mask=False, features_only=True)
+                super().forward(static_in, None, mask=False, features_only=True)   # cache and the pinned index buffer exist
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 res = super().forward(static_in, None, mask=False, features_only=True)
             # the state keeps the pinned index buffer the graph's copy node reads from, and every intermediate, alive
-            ent = (g, static_in, res["x"], self._last_state)
-            while len([k for k in graphs if isinstance(k, tuple)]) >= self.max_graphs:
-                graphs.pop(next(k for k in graphs if isinstance(k, tuple)))
+            held = max(0, torch.cuda.memory_allocated() - before)
+            ent = (g, static_in, res["x"], self._last_state, held)
             graphs[key] = ent
             graphs["_wkey"], graphs["_lc"] = wkey, self._launch_cache
-        g, static_in, x, st = ent
+            stats["captures"] += 1
+            shapes = [k for k in graphs if isinstance(k, tuple)]
+            total = sum(graphs[k][4] for k in shapes)
+            while len(shapes) > 1 and (len(shapes) > self.max_graphs or total > self.max_graph_bytes):
+                old = shapes.pop(0)                      # least recently used first
+                total -= graphs.pop(old)[4]
+        else:
+            stats["hits"] += 1
+            graphs.move_to_end(key)
+        g, static_in, x, st, _ = ent
         static_in.copy_(source)
         g.replay()
         self._last_state = st
@@ -151,8 +184,11 @@ class BlockWiseWav2Vec2Model(Wav2Vec2Model):
         context yet and are emitted by a later call on the longer prefix."""
         if (self.graph_calls and padding_mask is None and source.is_cuda and source.dtype == BF16 and not self.training
                 and not torch.is_grad_enabled() and self._draws is None and not ops.ARENA.active):
-            x, st = self._forward_graphed(source)
-            pad = None
+            got = self._forward_graphed(source)
+        else:
+            got = None
+        if got is not None:
+            (x, st), pad = got, None
         else:
             res = super().forward(source, padding_mask, mask=False, features_only=True)
             st = self._last_state

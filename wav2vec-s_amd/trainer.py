@@ -32,10 +32,14 @@ class _Roctx:
         if os.environ.get("W2VS_ROCTX", "1") != "0":
             for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
                 try:
-                    self.lib = ctypes.CDLL(name)
-                    self.lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    lib = ctypes.CDLL(name)
+                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    lib.roctxRangePushA.restype = ctypes.c_int
+                    lib.roctxRangePop.argtypes = []
+                    lib.roctxRangePop.restype = ctypes.c_int
+                    self.lib = lib
                     break
-                except OSError:
+                except (OSError, AttributeError):      # not installed, or a library of that name without the two symbols
                     self.lib = None
 
     def push(self, name: str):
@@ -318,6 +322,7 @@ class TrainStep:
         self.norm_buf = torch.zeros(1, device=dev, dtype=torch.float32)
         self.clip_out = torch.zeros(3, device=dev, dtype=torch.float32)   # [grad scale, gnorm, non-finite flag]
         self._bad_acc = torch.zeros(1, device=dev, dtype=torch.float32)   # sticky: number of skipped (non-finite) updates
+        self._bad_reported = 0            # how many of them the host has raised for (and taken out of the step count)
         self._flag_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self._flag_event = None
         self._one = None                  # cached d(loss)/d(loss)
@@ -342,11 +347,19 @@ class TrainStep:
         the sticky device state so that the error is reported ONCE, and raise what the reference raises.  Updates enqueued
         between the skipped one and this report ran with a step count (bias correction, scheduled rate) one too high - call
         ``check()`` after every update when that matters (it is a sync)."""
-        self.flat.step = max(0, self.flat.step - int(n_bad))
-        self._bad_acc.zero_()
+        # n_bad is the STICKY device count (never zeroed: a skip that happened after the copy the host is looking at would be
+        # lost with it); only what has not been reported yet comes out of the step count
+        new = int(n_bad) - self._bad_reported
+        self._bad_reported = int(n_bad)
+        self._flag_event = None
+        if new <= 0:
+            return
+        self.flat.step = max(0, self.flat.step - new)
         self.norm_buf.zero_()
         self.clip_out[2:3].zero_()
-        self._flag_event = None
+        # a caller that catches the error starts a fresh update: no half-accumulated micro-batches, no pending overwrite flag
+        self.micro, self.ss_acc = 0, 0
+        self.model._wgrad_overwrite = False
         raise FloatingPointError("gradients are Nan/Inf")            # fs/trainer.py:791-793
 
     def check(self):
@@ -354,7 +367,7 @@ class TrainStep:
         last report was skipped.  Call it before checkpointing and at the end of training (a non-finite LAST update is otherwise
         never looked at) - or after every update for the reference's exact abort-at-once behaviour."""
         n_bad = float(self._bad_acc[0]) if self.use_optimizer and (self.clip > 0 or self.check_finite) else 0.0
-        if n_bad != 0.0:
+        if n_bad > self._bad_reported:
             self._report_skipped(n_bad)
 
     finish = check
@@ -365,13 +378,13 @@ class TrainStep:
         if ev is not None and ev.query():
             self._flag_event = None
             n_bad = float(self._flag_host[0])
-            if n_bad != 0.0:
+            if n_bad > self._bad_reported:
                 self._report_skipped(n_bad)    # that update was skipped on the device
 
     def __call__(self, sample):
-        self._raise_if_nonfinite()
         ops.ARENA.activate(self.arena_bytes, self.flat.p16.device)
         try:
+            self._raise_if_nonfinite()
             return self._step(sample)
         except BaseException:
             # a step that died between w2vs_sumsq and w2vs_clip_scale_acc would leave its partial sum for the next update
