@@ -280,3 +280,17 @@ def test_bench_gpus_n_never_times_fewer_ranks_than_asked_for():
     assert r.returncode != 0 and "GPUs are visible" in r.stderr and '"metric"' not in r.stdout, (r.returncode, r.stderr[-500:])
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and '"metric"' not in r.stdout, (r.returncode, r.stderr[-500:])
+
+
+def test_product_library_reads_no_environment_variable():
+    """libw2vs.so runs every kernel selector on its measured default - the configuration the tests cover: no `getenv` is
+    compiled into the product (csrc/w2vs_internal.h: the W2VS_* switches exist only under -DW2VS_TUNING, `make tuning`)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "wav2vec-s_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")) and fn != "w2vs_internal.h":
+            assert "getenv" not in open(os.path.join(csrc, fn)).read(), fn
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert not re.search(r"\bgetenv\b", nm.stdout), "libw2vs.so imports getenv"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the tuning build (make -C wav2vec-s_amd/csrc tuning): libw2vs.so itself reads no environment variable
+export W2VS_LIB=${W2VS_LIB:-$PWD/wav2vec-s_amd/libw2vs_tuning.so}
 # The same in-step A/B for the LARGE configuration (24 L, d 1024, ffn 4096, pre-LN: input gradients without the residual add).
 run() { W2VS_NT_FORCE="$1" timeout -k 10 200 python bench.py --workload large --steps 12 --warmup 4 --no-cpu-baseline --no-variants --no-gemm-peak 2>/dev/null | tail -1 | python -c "
 import sys, json

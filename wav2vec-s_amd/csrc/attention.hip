@@ -638,7 +638,7 @@ static int attn_fill(const AttnDesc& d, AttnP& p) {
 static int g_attn_variant = -1;      // -1: environment / default, 1: attention.hip kernels, 2: attention2.hip kernels
 void attn_tune(int variant) { g_attn_variant = variant; }
 static bool use_v2(const AttnP& p) {
-  static const bool v1 = [] { const char* e = getenv("W2VS_ATTN_V1"); return e && atoi(e) != 0; }();
+  static const bool v1 = W2VS_ENV_INT("W2VS_ATTN_V1", 0) != 0;
   const bool want_v1 = g_attn_variant == 1 || (g_attn_variant < 0 && v1);
   return p.mq > 0 || (!want_v1 && attn2_ok(p));
 }

@@ -830,7 +830,7 @@ static inline int drop_mode(const AttnP& p) { return p.thr16 == 0 ? 0 : (p.drop_
 // about a third of its instructions: two waves instead of four halve that share - as long as the longest tile's sub-tile
 // list, now split two ways only, does not become the tail of the launch.  Measured (p = 0.1): N = 818 (longest list 26)
 // forward 33.4 -> 31.0 us, dQ pass -2 us; N = 1496 (longest 47) forward 35.3 -> 38.2 us.  W2VS_ATTN_NW=2|4 forces one.
-static const int g_attn_nw_env = [] { const char* e = getenv("W2VS_ATTN_NW"); return e ? atoi(e) : 0; }();
+static const int g_attn_nw_env = W2VS_ENV_INT("W2VS_ATTN_NW", 0);
 #define W2VS_LAUNCH_DM_NW(kern, tiles)                                                                              \
  {const int longest_ = (int)(pp.rec[0] >> 10) & 1023;     /* the table is sorted longest first */                   \
   const int nw_ = g_attn_nw_env == 2 || g_attn_nw_env == 4 ? g_attn_nw_env : (longest_ <= 32 ? 2 : 4);               \
@@ -883,7 +883,7 @@ int attn2_bwd(const AttnP& p, hipStream_t st) {
   }
   key_tile_table(pp, p, nkt);
   {
-    static const int dkv_nw_env = [] { const char* e = getenv("W2VS_ATTN_DKV_NW"); return e ? atoi(e) : 0; }();
+    static const int dkv_nw_env = W2VS_ENV_INT("W2VS_ATTN_DKV_NW", 0);
     const int longest_k = (int)(pp.rec[0] >> 10) & 1023;
     // two waves per workgroup: half the K / V staging, hand-over and merge instructions per key tile (measured: dQ + dK/dV
     // 96.6 -> 89.8 us at N = 818, 99.6 -> 92.2 us at N = 1496); four once a key tile's query list gets long enough to be the tail

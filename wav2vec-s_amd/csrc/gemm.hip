@@ -1836,7 +1836,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   // single-buffer / 3-blocks-per-CU form when the grid has enough tiles to fill it (measured +6..10 % on
   // the QKV / fc1 / conv shapes), double-buffer / 2-per-CU for short grids with a long K (fc2, out_proj)
   hipEvent_t pe = prof_begin(s);
-  static const int mode_env = [] { const char* e = getenv("W2VS_GEMM_MODE"); return e ? atoi(e) : -1; }();
+  static const int mode_env = W2VS_ENV_INT("W2VS_GEMM_MODE", -1);
   const long ntiles = (long)grid.x * grid.y * grid.z;
   // measured on MI355X: LDS-DMA staging wins on encoder-sized grids (+8..15 % on the N=768 and QKV shapes),
   // the register-staged 3-blocks-per-CU form on the very large conv grids (+5..8 %)
@@ -1851,9 +1851,9 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   int lc_h = 256;
   const bool p_ok = (d.N % 8) == 0 && (d.ldc % 8) == 0 && d.epi != EPI_F32 && ((uintptr_t)d.C % 16) == 0 &&
                     ((uintptr_t)d.C2 % 16) == 0 && ((uintptr_t)d.aux % 16) == 0 && (d.sC % 8) == 0;
-  static const int conv_p_env = [] { const char* e = getenv("W2VS_CONV_PERSIST"); return e ? atoi(e) : 1; }();
+  static const int conv_p_env = W2VS_ENV_INT("W2VS_CONV_PERSIST", 1);
   bool wide_auto = false;
-  static const int conv_model_env = [] { const char* e = getenv("W2VS_CONV_TILE_MODEL"); return e ? atoi(e) : 1; }();   // 0: 256 x 128 on the conv grids (A/B)
+  static const int conv_model_env = W2VS_ENV_INT("W2VS_CONV_TILE_MODEL", 1);   // 0: 256 x 128 on the conv grids (A/B)
   if (mode == 1 && p_ok && conv_p_env && (d.N < 256 || !conv_model_env)) {
     mode = 5;
   } else if ((mode == 1 || mode == 2) && p_ok && conv_p_env && ntiles >= 256 && d.N >= 256) {
@@ -1880,7 +1880,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     // dedicated loader waves, and its tile epilogue is longer: measured time ~ 1.35 x the rounds x (rows + columns) proxy
     // relative to the kernels above (tools/gemm_probe.py on QKV / fc1 / conv1 dgrad / conv2 / 4096^3: predicted 0.90 - 0.93,
     // measured 0.92 - 0.95; conv1 forward predicted 1.07, measured 1.04).
-    static const int nt8_env = [] { const char* e = getenv("W2VS_NT8"); return e ? atoi(e) : 1; }();
+    static const int nt8_env = W2VS_ENV_INT("W2VS_NT8", 1);
     if (nt8_env && (d.K % 64) == 0 && ((uintptr_t)d.bias % 16) == 0) {
       const int h8[2] = {256, 320};
       for (int c = 0; c < 2; ++c) {
@@ -1908,7 +1908,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     // Round 4: 64 x 128 tiles (2 consumer waves + 4 loaders, 72 KiB of LDS: two workgroups per CU) for SHORT outputs - the
     // streaming encoder's M = B x N' of a few hundred rows, where 160-row tiles leave three quarters of the chip idle behind a
     // 48-K-tile loop (fc2 at a 10 s prefix: 30 tiles, 32 us).  Taken only below one chip's worth of 64-row tiles x 2.
-    static const int lc64_env = [] { const char* e = getenv("W2VS_LC64"); return e ? atoi(e) : 1; }();
+    static const int lc64_env = W2VS_ENV_INT("W2VS_LC64", 1);
     {
       const long t64 = (long)((d.N + 127) / 128) * ((d.M + 63) / 64) * nbz;
       if (lc64_env && t64 <= 512) {
@@ -1926,7 +1926,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     struct Force { int N, K, epi, mode, h; };
     static const std::vector<Force> forces = [] {
       std::vector<Force> v;
-      const char* e = getenv("W2VS_NT_FORCE");
+      const char* e = W2VS_ENV_STR("W2VS_NT_FORCE");
       while (e && *e) {
         Force f{};
         if (sscanf(e, "%d:%d:%d=%d:%d", &f.N, &f.K, &f.epi, &f.mode, &f.h) == 5) v.push_back(f);
@@ -1939,7 +1939,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
       if (f.N == d.N && f.K == d.K && f.epi == d.epi && d.M >= 2048) { mode = f.mode; lc_h = f.h; wide_auto = false; }
   }
   if ((mode == 5 || mode == 6) && !p_ok) return set_error("gemm_nt: the persistent kernel needs N % 8 == 0, ldc % 8 == 0, 16-byte aligned outputs");
-  static const int lc_env = [] { const char* e = getenv("W2VS_LC_H"); return e ? atoi(e) : 0; }();
+  static const int lc_env = W2VS_ENV_INT("W2VS_LC_H", 0);
   if (lc_env > 0) lc_h = lc_env;
   if (g_force_lc_h > 0) lc_h = g_force_lc_h;
   // lc_h = 1160 selects the 160 x 256 loader/consumer tile (WN = 4)
@@ -1952,7 +1952,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     if (lc_h != 256 && lc_h != 320) return set_error("gemm_nt: 8-phase tile height must be 256 or 320");
   } else if (lc_h == 64 && mode != 3) { lc_h = 160;        // the 64-row tile exists for the one-tile-per-workgroup kernel only
   } else if (lc_h != 256 && lc_h != 192 && lc_h != 160 && lc_h != 64) return set_error("gemm_nt: tile height must be 256, 192, 160 or 64");
-  static const bool nt_log = getenv("W2VS_GEMM_LOG") != nullptr;      // shapes and the form chosen for them, one line per launch
+  static const bool nt_log = W2VS_ENV_SET("W2VS_GEMM_LOG");      // shapes and the form chosen for them, one line per launch
   if (nt_log) fprintf(stderr, "gemm_nt M %d N %d K %d batch %d epi %d lda %ld -> mode %d tile %dx%d\n", d.M, d.N, d.K, (int)d.batch, d.epi,
                       (long)d.lda, mode, mode >= 3 ? lc_h : 128, (wide || mode == 8) ? 256 : 128);
   const dim3 grid8((d.N + (wide ? 255 : 127)) / (wide ? 256 : 128), (d.M + lc_h - 1) / lc_h, d.batch > 0 ? d.batch : 1);
@@ -2027,14 +2027,14 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
   p.sA = d.sA; p.sB = d.sB; p.sC = d.sC;   // sC: batch stride of Cf (0 = every batch adds into the same matrix)
   // loader/consumer form (256x128 tiles, one workgroup per CU) when its grid can fill the chip with at most ~1
   // workgroup per CU and each keeps a long K loop; small outputs (out_proj) stay on the 128x128 kernel
-  static const int tn_lc_env = [] { const char* e = getenv("W2VS_TN_LC"); return e ? atoi(e) : -1; }();
+  static const int tn_lc_env = W2VS_ENV_INT("W2VS_TN_LC", -1);
   {
     const int tiles8 = ((d.N + 127) / 128) * ((d.M + 255) / 256) * nb;
     const int ncu = num_cu_hint > 0 ? num_cu_hint : 256;
     bool use_lc = tiles8 >= 16 && tiles8 <= ncu && d.sC == 0;
     if (tn_lc_env >= 0) use_lc = tn_lc_env != 0;
     if (g_force_tn_lc >= 0) use_lc = g_force_tn_lc != 0 && d.sC == 0;
-    static const bool tn_log = getenv("W2VS_GEMM_LOG") != nullptr;
+    static const bool tn_log = W2VS_ENV_SET("W2VS_GEMM_LOG");
     if (tn_log) fprintf(stderr, "gemm_tn M %d N %d K %d batch %d -> %s (%d tiles of 256x128)\n", d.M, d.N, d.K, nb, use_lc ? "loader/consumer" : "128^2 atomics", tiles8);
     if (use_lc) {
       int splits = std::max(1, ncu / tiles8);
@@ -2063,7 +2063,7 @@ int gemm_tn(const GemmDesc& d, int num_cu_hint, hipStream_t s) {
     }
   }
   int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * nb;
-  static const int tn_target = [] { const char* e = getenv("W2VS_TN_TARGET"); return e ? atoi(e) : 0; }();
+  static const int tn_target = W2VS_ENV_INT("W2VS_TN_TARGET", 0);
   int target = tn_target > 0 ? tn_target : (num_cu_hint > 0 ? num_cu_hint : 256) * 3 / 2;  // 1.5 blocks per CU: measured best trade between fill and atomic traffic
   int splits = (target + tiles - 1) / tiles;
   int max_splits = (d.K + TK - 1) / TK;
@@ -2117,7 +2117,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
   if (n > 4) {
     // more than four problems (two layers' weight gradients): only the 8-phase kernel takes them as ONE launch, and only when
     // their 256^2 tiles fit one workgroup per CU WITHOUT a K split; otherwise two groups, as before
-    static const int tn8_env2 = [] { const char* e = getenv("W2VS_TN8"); return e ? atoi(e) : 1; }();
+    static const int tn8_env2 = W2VS_ENV_INT("W2VS_TN8", 1);
     int t8 = 0;
     bool ok8 = tn8_env2 != 0;
     for (int i = 0; i < n; ++i) {
@@ -2158,7 +2158,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
   }
   for (int i = std::min(n, 4); i <= 4; ++i) g.first[i] = tiles;
   // Round 3: 256 x 256 tiles + split K over workgroup pairs (gemm_tn8_group_kernel) when that fills the chip better
-  static const int tn8_env = [] { const char* e = getenv("W2VS_TN8"); return e ? atoi(e) : 1; }();
+  static const int tn8_env = W2VS_ENV_INT("W2VS_TN8", 1);
   if (ok && tn8_env) {
     Tn8GroupP g8{};
     int t8 = 0;
@@ -2180,16 +2180,16 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
         if (hipMemset(df->flags, 0, 16 * 2048 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
           return set_error("gemm_tn_group: flag memset failed");
       }
-      static const int s_env = [] { const char* e = getenv("W2VS_TN8_S"); return e ? atoi(e) : 0; }();
+      static const int s_env = W2VS_ENV_INT("W2VS_TN8_S", 0);
       if (s_env > 0) S = std::min(S, s_env);
 #ifdef W2VS_ABLATION      // timing-only ablations (results are WRONG by design): never in the product build
-      static const int dbg_env = [] { const char* e = getenv("W2VS_TN8_DBG"); return e ? atoi(e) : 0; }();
+      static const int dbg_env = W2VS_ENV_INT("W2VS_TN8_DBG", 0);
       g8.dbg = dbg_env;
 #endif
       g8.S = S; g8.slab = (float*)ds[0].ws; g8.slab_bytes = std::min<int64_t>(ds[0].ws_bytes, 0x7FFFFFF0L);
       g8.cnt = df->flags + 2048 * (df->next++ & 15);
       g_last_group_form = S == 2 ? 14 : 13;
-      static const bool tn_log8 = getenv("W2VS_GEMM_LOG") != nullptr;
+      static const bool tn_log8 = W2VS_ENV_SET("W2VS_GEMM_LOG");
       if (tn_log8) fprintf(stderr, "gemm_tn_group -> 8-phase, %d tiles of 256x256, split K %d\n", t8, S);
       hipEvent_t pe = prof_begin(s, 5);
       hipLaunchKernelGGL(gemm_tn8_group_kernel, dim3(t8 * S), dim3(512), 0, s, g8);
@@ -2202,7 +2202,7 @@ int gemm_tn_group(const GemmDesc* ds, int n, int num_cu_hint, hipStream_t s) {
       if (int e = gemm_tn_group(ds + o, std::min(4, n - o), num_cu_hint, s)) return e;
     return 0;
   }
-  static const int grp_env = [] { const char* e = getenv("W2VS_TN_GROUP"); return e ? atoi(e) : 1; }();
+  static const int grp_env = W2VS_ENV_INT("W2VS_TN_GROUP", 1);
   // grouped only when it fills >= 3/4 of the chip AND leaves some slack: with exactly one workgroup per CU a single CU that is
   // not free at dispatch costs a whole extra round of full-length K loops (measured on the large model's 128 + 128 tiles)
   if (!ok || tiles > ncu - ncu / 16 || tiles * 4 < ncu * 3 || !grp_env) {

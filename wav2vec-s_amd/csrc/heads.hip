@@ -563,7 +563,7 @@ int nce_bwd(const NceDesc& d, hipStream_t st) {
   {
     const long Mp = (p.M + 63) / 64 * 64;
     const long need = 4L * p.B * Mp * (2L * p.C + 2) + 2L * 2 * p.B * Mp * Mp;
-    static const int dense_env = [] { const char* e = getenv("W2VS_NCE_DENSE"); return e ? atoi(e) : -1; }();
+    static const int dense_env = W2VS_ENV_INT("W2VS_NCE_DENSE", -1);
     bool dense = d.ws && d.ws_bytes >= need && ((uintptr_t)d.ws % 16) == 0 && Mp <= 1024 && (p.C % 8) == 0;
     if (dense_env == 0) dense = false;
     if (dense) return nce_bwd_dense(d, p, st);
@@ -953,7 +953,7 @@ int adam_step(float* p32, void* p16, float* m, float* v, const float* g, long n,
   // what the next forward wants from L2 / the Infinity Cache): kernel 474 -> 425 us (6.0 -> 6.7 TB/s), step 8.60 -> 8.46 ms -
   // more than the kernel's own gain.  The same hint on the saved gelu' / LayerNorm inputs / gradient-norm read measured
   // nothing (EXPERIMENTS.md).  W2VS_ADAM_NT=0 is the A/B.
-  static const int nt_env = [] { const char* e = getenv("W2VS_ADAM_NT"); return e ? atoi(e) : 1; }();
+  static const int nt_env = W2VS_ENV_INT("W2VS_ADAM_NT", 1);
   if (nt_env)
     hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, p32, (bf16*)p16, m, v, g, n,
                        wd * lr, step_size, b1, b2, eps, scale_dev, scale_host);

@@ -793,8 +793,8 @@ int ln_fwd(const LnFwdDesc& d, hipStream_t st) {
   if (!p.x || !p.g || !p.b) return set_error("ln_fwd: null pointer");
   if (p.y && !p.mean) return set_error("ln_fwd: mean/rstd buffers required");
   if (int e = ln_check(p, "ln_fwd")) return e;
-  static const int cap = getenv("W2VS_LN_FWD_GRID") ? atoi(getenv("W2VS_LN_FWD_GRID")) : 256 * 4;   // ~1.6 rows per wave at the encoder size: measured best of 512 / 768 / 1024 / 2048
-  static const int lean_env = [] { const char* e = getenv("W2VS_LN_LEAN"); return e ? atoi(e) : 1; }();
+  static const int cap = W2VS_ENV_INT("W2VS_LN_FWD_GRID", 256 * 4);   // ~1.6 rows per wave at the encoder size: measured best of 512 / 768 / 1024 / 2048
+  static const int lean_env = W2VS_ENV_INT("W2VS_LN_LEAN", 1);
   if (lean_env && p.y && !p.sumsq && !p.gelu && p.rows >= 1024 && p.rows < (1L << 30)) {
     hipLaunchKernelGGL(ln_fwd_lean_kernel, dim3((unsigned)((p.rows + 3) / 4)), dim3(256), 0, st, p);
     return hip_check(hipGetLastError(), "ln_fwd");
@@ -824,7 +824,7 @@ int ln_bwd(const LnBwdDesc& d, hipStream_t st, bool leave_partials) {
     grid = std::min(grid, 256);   // no workspace: per-block atomics, keep their number down
   }
   if (leave_partials && !part) return set_error("ln_bwd: a deferred reduction needs a partial slab");
-  static const int atomic_env = [] { const char* e = getenv("W2VS_LN_BWD_ATOMIC"); return e ? atoi(e) : 0; }();   // A/B: N > 0 = atomics from N blocks
+  static const int atomic_env = W2VS_ENV_INT("W2VS_LN_BWD_ATOMIC", 0);   // A/B: N > 0 = atomics from N blocks
   if (atomic_env > 0 && !leave_partials) { part = nullptr; grid = std::min<long>((p.rows + NW - 1) / NW, atomic_env); }
   if (full) hipLaunchKernelGGL((ln_bwd_kernel<true, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);
   else hipLaunchKernelGGL((ln_bwd_kernel<false, NW>), dim3(grid), dim3(NW * 64), 0, st, p, part);

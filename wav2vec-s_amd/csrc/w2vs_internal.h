@@ -5,6 +5,20 @@
 #include <algorithm>
 #include "../../include/w2vs.h"
 
+// Tuning switches.  libw2vs.so reads NO environment variable: every selector runs on its measured default, the configuration
+// the tests cover.  `make -C wav2vec-s_amd/csrc tuning` builds libw2vs_tuning.so with -DW2VS_TUNING, where the same
+// expressions read the environment once (tools/*probe*.py, tools/nt_force_sweep*.sh load it through W2VS_LIB).
+#ifdef W2VS_TUNING
+#include <stdlib.h>
+#define W2VS_ENV_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#define W2VS_ENV_SET(name) (getenv(name) != nullptr)
+#define W2VS_ENV_STR(name) (getenv(name))
+#else
+#define W2VS_ENV_INT(name, dflt) (dflt)
+#define W2VS_ENV_SET(name) (false)
+#define W2VS_ENV_STR(name) ((const char*)nullptr)
+#endif
+
 namespace w2vs {
 
 int set_error(const char* msg);                 // records msg, returns W2VS_ERR_INVALID
