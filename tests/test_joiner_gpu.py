@@ -119,6 +119,55 @@ def test_joiner_caat_width_matches_oracle_and_feeds_the_head():
     assert head.output_proj.weight.grad is not None
 
 
+@pytest.mark.parametrize("ds", [64, 32, 160, 320])
+def test_joiner_script_width_matches_oracle_at_every_random_step(ds):
+    """The joiner the reference's training script builds (wav2vec_s_scripts/train/train_wav2vec_s_caat_simulst_base.sh:17,
+    40-41: 6 layers, 768 wide, 12 heads, ffn 3072, --transducer-downsample 64 --step-mode random) at each of the four group
+    sizes its random step can draw ({2, 4, 10, 20} x 16 frames, rain/layers/attention_transducer.py:800-808), on a
+    MuST-C-shaped batch (B = 8, S = 312 frames = 6.25 s, U = 32) with ragged source lengths; dropout-free, so the comparison
+    with the oracle is exact in expectation.  Then the script's dropouts (0.3 / 0.1 / 0.1) on: finite, a new draw per call."""
+    import random
+    from wav2vec_s_amd import joiner
+    torch.manual_seed(4)
+    D, H, S, U, B = 768, 12, 312, 32, 8
+    net = joiner.MHAJointNet(_args(D, H, 64, 6, True, 3072))
+    net.step_mode = "random"
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "layer_norm" in n or n.endswith("bias"):
+                p.add_(torch.randn_like(p) * 0.1)
+    net = net.to(BF)
+    P = {k: v.float().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda().train()                                   # training mode: the step is drawn; every dropout is 0
+    seed = {64: 1, 32: 2, 160: 5, 320: 0}[ds]                  # python `random` seeds whose first draw is that step
+    enc = torch.randn(S, B, D).to(BF)
+    dec = torch.randn(B, U, D).to(BF)
+    lens = torch.tensor([312, 300, 250, 312, 97, 160, 201, 65])
+    pad = torch.arange(S).view(1, S) >= lens.view(B, 1)
+    e_r, d_r = enc.float().requires_grad_(True), dec.float().requires_grad_(True)
+    xr, glen_r = R.mha_joint_net(P, e_r, pad, d_r, layers=6, heads=H, downsample=ds)
+    w = torch.randn(xr.shape)
+    (xr * w).sum().backward()
+    e_g, d_g = enc.cuda().requires_grad_(True), dec.cuda().requires_grad_(True)
+    random.seed(seed)
+    x, glen = net({"encoder_out": [e_g], "encoder_padding_mask": [pad.cuda()]}, d_g)
+    assert net.downsample == ds and tuple(x.shape) == (B, -(-S // ds), U, D)
+    assert torch.equal(glen.cpu(), glen_r)
+    assert rel(x, xr) < 2e-2, rel(x, xr)
+    (x.float() * w.cuda()).sum().backward()
+    assert rel(e_g.grad, e_r.grad) < 4e-2 and rel(d_g.grad, d_r.grad) < 4e-2
+    errs = {n: rel(p.grad, P[n].grad) for n, p in net.named_parameters() if "k_proj.bias" not in n}
+    _check_families(errs, "caat", "script_width_ds%d" % ds)
+    if ds == 64:
+        net_t = joiner.MHAJointNet(_args(D, H, 64, 2, True, 3072, p=0.1)).to(BF).cuda().train()
+        for layer in net_t.layers:
+            layer.dropout = 0.3                                # --dropout 0.3 --activation-dropout 0.1 --attention-dropout 0.1
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        a1, _ = net_t({"encoder_out": [e_g.detach()], "encoder_padding_mask": [pad.cuda()]}, d_g.detach())
+        a2, _ = net_t({"encoder_out": [e_g.detach()], "encoder_padding_mask": [pad.cuda()]}, d_g.detach())
+        assert not torch.equal(a1, a2) and torch.isfinite(a1.float()).all() and torch.isfinite(a2.float()).all()
+
+
 def test_joiner_incremental_state_matches_reference_fixture():
     """The decoding path (rain/layers/attention_transducer.py:607-674, 826-852 with downsample = -1 as TransducerMHADecoder sets
     it, :901-902) against outputs recorded from the reference's own classes: a fresh call, a call with the SAME prefix length

@@ -61,7 +61,24 @@ struct GemmP {
   float alpha;
   int overwrite;              // TN single-writer kernels: Cf = alpha * acc instead of Cf += (the first writer of a zero-free arena)
   int zk_col, zk_kt;          // NT persistent kernels: tiles with n0 >= zk_col start at K tile zk_kt (B is zero before it); 0 = off
+#ifdef W2VS_ABLATION
+  // tuning build only: in-kernel time stamps of the 8-phase NT kernel (s_memrealtime, 100 MHz), 8 words per wave group and
+  // workgroup: entry, first tile landed, end of each tile's K loop / epilogue issue (first two tiles), all stores done
+  unsigned long long* stamps;
+  int epi_dbg;                // timing-only epilogue ablations: bit 0 no GELU arithmetic, bit 1 no second (gelu') store, bit 2 no store at all
+#endif
 };
+#ifdef W2VS_ABLATION
+static unsigned long long* g_nt_stamps = nullptr;
+static int g_epi_dbg = 0;
+extern "C" void w2vs_dbg_nt_stamps(void* buf, int epi_dbg) { g_nt_stamps = (unsigned long long*)buf; g_epi_dbg = epi_dbg; }
+#define W2VS_STAMP(p, slot)                                                                                       \
+  do {                                                                                                            \
+    if ((p).stamps && lane == 0 && wc == 0) (p).stamps[((long)blockIdx.x * 2 + wr) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define W2VS_STAMP(p, slot) do { } while (0)
+#endif
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_GELU_SAVE = 3, EPI_DGELU = 4, EPI_F32 = 5, EPI_ADD = 6,
        EPI_BIAS_GELU_SAVEG = 7,   // C = gelu(pre), C2 = gelu'(pre): the backward then needs one multiply, not an erf
@@ -169,10 +186,16 @@ __device__ __forceinline__ void epi_direct(const GemmP& p, int bz, int row0_, in
             const float v = val(u, b, e) + bv[e];
             pre.h[e] = f2bf(v);
             float gv, dv;
+#ifdef W2VS_ABLATION
+            if (p.epi_dbg & 1) { gv = v; dv = v + 1.f; } else
+#endif
             gelu_pair(epi_is_save(EPI) ? bf2f(pre.h[e]) : v, gv, dv);  // the activation of the value that is saved
             o8.h[e] = f2bf(gv);
             if (EPI == EPI_BIAS_GELU_SAVEG) pre.h[e] = f2bf(dv);
           }
+#ifdef W2VS_ABLATION
+          if (p.epi_dbg & 6) { if (p.epi_dbg & 4) asm volatile("" :: "v"(pre.w), "v"(o8.w)); else { asm volatile("" :: "v"(pre.w)); __builtin_amdgcn_raw_buffer_store_b128(o8.w, rc, offs(fr, col, b), 0, 0); } continue; }
+#endif
           if constexpr (epi_is_save(EPI)) __builtin_amdgcn_raw_buffer_store_b128(pre.w, rc2, offs(fr, col, b), 0, 0);
         } else {
 #pragma unroll
@@ -961,6 +984,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)dst, 16, o, 0, 0, 0);
     }
   };
+  W2VS_STAMP(p, 0);
   set_tile(0);
   if (!live_s) return;                                   // workgroup-uniform: more workgroups than tiles
   // ---- prologue: K tile 0 whole, K tile 1 without its A_h1 (phase 1 of step 0 brings it)
@@ -971,6 +995,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
   advance();
   wait_vm8<VMW>();
   __builtin_amdgcn_s_barrier();
+  W2VS_STAMP(p, 1);
   if (wr == 1) __builtin_amdgcn_s_barrier();             // the stagger: group 1 runs one barrier behind group 0
 
   f32x4 acc[2][MH][4];
@@ -1058,6 +1083,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
     // the EIGHT consecutive columns wc*64 + u*32 + fq*8 .. +7.  The stagger is suspended around it (group 0 waits one barrier
     // for group 1's last MFMA phase, group 1 re-opens the gap afterwards): staggered, the two groups' epilogues run one after
     // the other, each with one wave per SIMD - half the VALU / store issue rate of the CU.
+    if (r < 2) W2VS_STAMP(p, 2 + 2 * r);
     if (wr == 0) __builtin_amdgcn_s_barrier();
     const int m0 = tm * TBM, n0 = tn * 256;
     auto col_of = [&](int u) { return n0 + wc * 64 + u * 32 + fq * 8; };
@@ -1065,10 +1091,12 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmP p, int ntm, int ntn
     auto val = [&](int u, int b, int e) { return acc[b / MH][b % MH][2 * u + (e >> 2)][e & 3]; };
     if constexpr (EPI == EPI_F32) epi_direct_f32<2, 2 * MH>(p, bz, m0 + wr * WROWS, fr, col_of, row_blk, val);
     else epi_direct<EPI, 2, 2 * MH, true>(p, bz, m0 + wr * WROWS, fr, col_of, row_blk, val);
+    if (r < 2) W2VS_STAMP(p, 3 + 2 * r);
     if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 falls one barrier behind again
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's extra barrier in front of the tile loop
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (out-of-range) prefetches still target the LDS
+  W2VS_STAMP(p, 6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1963,6 +1991,9 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     const int tw = (wide || mode == 8) ? 256 : 128;
     if (d.zk_k % (2 * BK) == 0 && d.zk_k < d.K && d.zk_col % tw == 0 && d.zk_col < d.N) { p.zk_col = d.zk_col; p.zk_kt = d.zk_k / BK; }
   }
+#ifdef W2VS_ABLATION
+  p.stamps = g_nt_stamps; p.epi_dbg = g_epi_dbg;
+#endif
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
     if (mode == 8) {                /* 8-phase, persistent: (lc_h) x 256 tiles */              \

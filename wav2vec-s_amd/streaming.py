@@ -108,10 +108,14 @@ class BlockWiseWav2Vec2Model(Wav2Vec2Model):
     # seen ``graph_after`` times eagerly (fixed chunk schedules make later utterances repeat the shapes of the first; a shape
     # met once never pays for a capture), graphs are evicted least-recently-used, and both their number and the bytes they
     # hold are bounded.
-    graph_calls = os.environ.get("W2VS_STREAM_GRAPH", "1") != "0"
+    # Measured (profiles/round5_stream_encoder_bench.json): a replay is no faster than the eager call on the GPU (1.39 ms either
+    # way at a 10 s prefix - the chain of ~150 dependent kernels is what a call costs), a capture costs ~4 ms and a graph holds
+    # ~170 MB of activations.  What a replay saves is the HOST's issue time (~1.1 ms of one core per call).  So replay is
+    # opt-in (``graph_calls = True`` or W2VS_STREAM_GRAPH=1), for deployments whose host thread is the scarce resource.
+    graph_calls = os.environ.get("W2VS_STREAM_GRAPH", "0") == "1"
     graph_after = 2                 # eager calls of a shape before it is captured
     max_graphs = 128                # captured shapes kept (30 s at 320 ms chunks = 94 shapes)
-    max_graph_bytes = 6 << 30       # device bytes the kept graphs may hold (~40 MB each at a 10 s prefix)
+    max_graph_bytes = 32 << 30      # device bytes the kept graphs may hold (of 288 GB; ~170 MB each at a 10 s prefix)
 
     def _graph_key(self):
         return tuple((p.data_ptr(), p._version, p.dtype) for p in self._named_params_cached()[1])
