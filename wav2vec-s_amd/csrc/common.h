@@ -94,28 +94,38 @@ __device__ __forceinline__ float u01(uint32_t h) {  // (0,1]
   return ((float)(h >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
-// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution): one v_rcp, one
-// v_exp and a 5-term Horner chain instead of libm's branchy erff.  Hundreds of millions of GELUs per
-// step sit in GEMM / conv epilogues, so this is a first-order cost.  Returns erf(x) and exp(-x^2).
-__device__ __forceinline__ float fast_erf(float x, float& ex2) {
+// GELU(x) = x Phi(x) (exact-erf form, fs/modules/gelu.py:24-25 = torch.nn.functional.gelu) through the normal TAIL
+//   q(a) = 1 - Phi(a) = 0.5 erfc(a / sqrt 2),  a = |x|:   Phi(x) = x >= 0 ? 1 - q : q,   gelu(x) = max(x, 0) - a q(a).
+// q is ONE v_exp_f32 of a degree-6 polynomial in a (minimax fit of log2 q on [0, 6], constant term -1 = log2 q(0)): its error
+// is RELATIVE (< 5e-5 of q), so the small negative-side values x q keep their leading digits, and gelu is within 7.4e-6
+// absolute / 5e-5 relative of the erf form everywhere, gelu' within 2e-5 (bf16 resolves 4e-3) - tools/fit_gelu_tail.py
+// re-derives the coefficients and these bounds in float32 arithmetic.  Beyond a = 6, q < 1e-9 and a is clamped.
+// Round 5: this replaces Abramowitz-Stegun 7.1.26 (v_rcp + v_exp + a 5-term chain): hundreds of millions of GELUs per step
+// sit in conv / GEMM epilogues that in-kernel stamps show VALU-bound (profiles/round5_nt_anatomy_probe.txt); the forward-only
+// form drops from 15 vector instructions with two transcendentals to 10 with one.
+__device__ __forceinline__ float normal_tail(float ax) {   // ax = |x| >= 0
+  const float a = fminf(ax, 6.0f);
+  float p = fmaf(2.3433251092e-05f, a, -6.1973935318e-04f);
+  p = fmaf(p, a, 7.2603524696e-03f);
+  p = fmaf(p, a, -5.1418609203e-02f);
+  p = fmaf(p, a, -4.6086354093e-01f);
+  p = fmaf(p, a, -1.1504803413f);
+  return __builtin_amdgcn_exp2f(fmaf(p, a, -1.0f));
+}
+__device__ __forceinline__ float gelu_exact(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  ex2 = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float r = 1.0f - poly * t * ex2;
-  return copysignf(r, x);
+  return fmaf(-ax, normal_tail(ax), fmaxf(x, 0.f));
 }
-__device__ __forceinline__ float gelu_exact(float x) {  // 0.5 x (1 + erf(x / sqrt 2))
-  float e;
-  return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f, e));
+// Phi(x) and the density term exp(-x^2 / 2) (one more v_exp_f32)
+__device__ __forceinline__ float normal_cdf(float x, float& ex2) {
+  const float q = normal_tail(fabsf(x));
+  ex2 = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  return x >= 0.f ? 1.0f - q : q;
 }
-__device__ __forceinline__ float gelu_grad(float x) {  // Phi(x) + x phi(x); exp(-x^2/2) comes with the erf
+__device__ __forceinline__ float gelu_grad(float x) {  // Phi(x) + x phi(x)
   float e;
-  const float er = fast_erf(x * 0.70710678118654752440f, e);
-  return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
+  const float cdf = normal_cdf(x, e);
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 }  // namespace w2vs

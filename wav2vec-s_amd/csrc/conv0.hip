@@ -3,10 +3,10 @@
 //
 // A wave owns 16 consecutive output frames ("rows") at a time.  The conv is a [16 x 16] . [16 x 512] product
 // (K = 16: the k taps, one all-ones column that carries the conv bias, zero padding) = 32 MFMA 16x16x16 tiles.
-// Tile t, accumulator lane (n = lane & 15, rg = lane >> 4) holds rows rg*4..rg*4+3 of channel n*32 + t, so a
-// lane owns 32 CONSECUTIVE channels of 4 rows:
+// Tile t, accumulator lane (n = lane & 15, rg = lane >> 4) holds rows rg*4..rg*4+3 of channel ch_of(t, n), so a
+// lane owns 4 x 8 consecutive channels of 4 rows:
 //   * LayerNorm statistics are an in-lane sum over the 32 tiles + a 16-lane butterfly,
-//   * y / dy move as 16-byte pieces (a row's 1 KiB is written by its 16 lanes, 64 B each),
+//   * y / dy move as 16-byte pieces, 256 contiguous bytes of a row per instruction and row group,
 //   * gamma/beta and their gradients are 32 registers per lane,
 //   * the backward's dconv (4 rows of one channel, bf16) is ALREADY the A fragment of the weight-gradient
 //     MFMA  dW[ch][tap] += dconv[rows][ch]^T . x[rows][tap]  - no transpose, no LDS round trip.
@@ -21,6 +21,14 @@ namespace w2vs {
 namespace {
 
 constexpr int CC = 512, NT = 32;   // channels, 16-channel MFMA tiles
+// Channel of column n (= lane & 15) of MFMA tile t.  Round 5: tile t = 8u + e takes channel u*128 + n*8 + e, so for a fixed u a
+// lane's eight tiles are 8 CONSECUTIVE channels (one 16-byte piece) and the 16 lanes of a row group cover 256 contiguous
+// bytes of the row: every y store / dy load instruction moves whole 128-byte lines.  (Rounds 1-4 gave a lane 32 consecutive
+// channels, n*32 + t: the same instruction then touched 16 pieces of 16 bytes at a 64-byte stride per row - four times the
+// lines through the address path for the same bytes; the statistics and the MFMAs do not care which channel sits where.)
+__device__ __forceinline__ constexpr int ch_of(int t, int n) { return (t >> 3) * 128 + n * 8 + (t & 7); }
+// MAP 0: the layout above; MAP 1: the rounds 1-4 layout (a lane owns 32 consecutive channels) - kept for the A/B of the backward
+template <int MAP> __device__ __forceinline__ constexpr int ch_map(int t, int n) { return MAP == 0 ? ch_of(t, n) : n * 32 + t; }
 constexpr int BIAS_TAP = 10;       // K index of the all-ones column (needs k <= 10)
 
 struct Conv0M {
@@ -77,10 +85,11 @@ __device__ __forceinline__ long frame_base(const Conv0M& p, long row) {
   return (long)b * p.L + (long)t * p.s;
 }
 // W fragments, B operand of the conv MFMA: lane (n = lane&15, kg = lane>>4) of tile t holds
-// W[n*32 + t][kg*4 .. kg*4+3]; K index BIAS_TAP carries the conv bias.
+// W[ch_of(t, n)][kg*4 .. kg*4+3]; K index BIAS_TAP carries the conv bias.
+template <int MAP = 0>
 __device__ __forceinline__ void build_w_frags(const Conv0M& p, s16x4* wl, int tid) {
   for (int idx = tid; idx < NT * 64; idx += 256) {
-    const int t = idx >> 6, l = idx & 63, n = l & 15, kg = l >> 4, ch = n * 32 + t;
+    const int t = idx >> 6, l = idx & 63, n = l & 15, kg = l >> 4, ch = ch_map<MAP>(t, n);
     s16x4 f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_fwd_kernel(Conv0M p) {
   build_w_frags(p, wl, tid);
   float g[NT], be[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { g[t] = bf2f(p.lnw[lm * 32 + t]); be[t] = bf2f(p.lnb[lm * 32 + t]); }
+  for (int t = 0; t < NT; ++t) { g[t] = bf2f(p.lnw[ch_of(t, lm)]); be[t] = bf2f(p.lnb[ch_of(t, lm)]); }
   __syncthreads();
   const long nsteps = (p.rows + 15) / 16;
   const long wave_id = (long)blockIdx.x * 4 + (tid >> 6), nwaves = (long)gridDim.x * 4;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_fwd_kernel(Conv0M p) {
       const long row = r0 + lg * 4 + i;
       if (row < p.rows) {
         if (lm == 0) { p.mean[row] = mean[i]; p.rstd[row] = rstd[i]; }
-        bf16* yr = p.y + row * CC + lm * 32;
+        bf16* yr = p.y + row * CC + lm * 8;
         const float mr = -mean[i] * rstd[i];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_fwd_kernel(Conv0M p) {
             const float xh = fmaf(acc[t][i], rstd[i], mr);
             o[e] = f2bf(gelu_exact(fmaf(xh, g[t], be[t])));
           }
-          *(bf16x8*)(yr + 8 * u) = o;
+          *(bf16x8*)(yr + 128 * u) = o;
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -173,6 +182,13 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_fwd_kernel(Conv0M p) {
 // =================================================================================================
 // backward: dW, dbias, dgamma, dbeta (the waveform needs no gradient)
 // =================================================================================================
+// MAP: channel layout (ch_map).  Round 5 measured, same box, three interleaved rounds (tools/conv0_sweep.sh): the rounds 1-4
+// layout (MAP 1: a lane owns 32 consecutive channels) 248-257 us, the forward's new layout (MAP 0) 260-264 us - the dy loads
+// are prefetched a whole step ahead, their instruction count does not matter here and four loads of one 64-byte run hit L1 -
+// wider scheduling windows (a barrier every 2 / 4 tile pairs instead of every pair) 251-262 us: no effect; a form with 2 or 4
+// waves sharing a 16-row step (two waves per SIMD; tools/probes/conv0_bwd_split_round5.diff) 250-256 us / 298-321 us.
+// Counters (tools/conv0_pmc.sh): this kernel issues vector instructions 47 % of its wave-cycles and waits 40 %.
+template <int MAP>
 __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
   __shared__ s16x4 wl[NT * 64];
   __shared__ s16x4 dzs[4][NT * 64];      // per wave: dz fragments of the current 16 rows (pass 1 -> pass 2)
@@ -183,21 +199,21 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
   // after the row loop the dz buffers are dead and hold the block reductions instead
   float* slab = (float*)&dzs[0][0];                       // dW/dbias sums [ch][16 taps] (+16 floats of skew per 128 ch)
   float (*gsl)[2][CC] = (float (*)[2][CC])((float*)&dzs[0][0] + CC * 16 + 64);   // per-wave dgamma / dbeta
-  build_w_frags(p, wl, tid);
+  build_w_frags<MAP>(p, wl, tid);
   for (int i = tid; i < 2 * G::N; i += 256) gdtab[i] = gelu_grad(G::arg(i));
   // gamma (low half) and beta (high half) of channel lm*32 + t as bf16 bits: 32 registers instead of 64
   uint32_t gb[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    bf16x2 v; v[0] = p.lnw[lm * 32 + t]; v[1] = p.lnb[lm * 32 + t];
+    bf16x2 v; v[0] = p.lnw[ch_map<MAP>(t, lm)]; v[1] = p.lnb[ch_map<MAP>(t, lm)];
     gb[t] = __builtin_bit_cast(uint32_t, v);
   }
-  f32x4 dwacc[NT];   // tile t: lane (tap = lm, rg) holds channels (rg*4+i)*32 + t
+  f32x4 dwacc[NT];   // tile t: lane (tap = lm, rg) holds channels ch_of(t, rg*4+i)
 #pragma unroll
   for (int t = 0; t < NT; ++t) dwacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // dgamma / dbeta also ride the matrix cores: tile t's row sums go to column (t & 15) of accumulator (t >> 4)
   // through a one-hot B operand, so 512 channels cost 8 accumulator registers each instead of 32 + 32 VGPRs.
-  // Lane (n = lm, rg) of accumulator h then holds channels (rg*4+i)*32 + h*16 + lm.
+  // Lane (n = lm, rg) of accumulator h then holds channels ch_of(h*16 + lm, rg*4+i).
   f32x4 dgacc[2], dbacc[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) { dgacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; dbacc[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
   // Operands of one 16-row step.  They are fetched one step ahead: dy right after pass 1 (its registers are free
   // from there on), the rest into a second set, so a wave (alone on its SIMD) never waits on HBM at a step's top.
   //   xa: A operand of the conv MFMA;  xb: B operand of the dW MFMA - lane (n = tap = lm, kg = lg) holds
-  //   x[row lg*4+i][tap], tap BIAS_TAP = 1 -> dbias;  dyb[u][i]: channels lm*32 + 8u .. +7 of row lg*4+i
+  //   x[row lg*4+i][tap], tap BIAS_TAP = 1 -> dbias;  dyb[u][i]: channels u*128 + lm*8 .. +7 of row lg*4+i
   s16x4 xa = {0, 0, 0, 0}, xb = {0, 0, 0, 0}, nxa = {0, 0, 0, 0}, nxb = {0, 0, 0, 0};
   float mr[4], rstd[4], nmr[4], nrstd[4];
   u32x4 dyb[4][4];
@@ -231,9 +247,9 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long row = r0 + lg * 4 + i;
-      const bf16* dyr = p.dy + row * CC + lm * 32;
+      const bf16* dyr = p.dy + row * CC + (MAP == 0 ? lm * 8 : lm * 32);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dyb[u][i] = row < p.rows ? *(const u32x4*)(dyr + 8 * u) : u32x4{0u, 0u, 0u, 0u};
+      for (int u = 0; u < 4; ++u) dyb[u][i] = row < p.rows ? *(const u32x4*)(dyr + (MAP == 0 ? 128 : 8) * u) : u32x4{0u, 0u, 0u, 0u};
     }
   };
   if (wave_id < nsteps) {
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int ch = (lg * 4 + i) * 32 + h * 16 + lm;
+      const int ch = ch_map<MAP>(h * 16 + lm, lg * 4 + i);
       gsl[wid][0][ch] = dgacc[h][i];
       gsl[wid][1][ch] = dbacc[h][i];
     }
@@ -332,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int ch = (lg * 4 + i) * 32 + t;
+          const int ch = ch_map<MAP>(t, lg * 4 + i);
           float* a = slab + ch * 16 + (ch >> 7) * 16 + lm;
           *a = (w == 0 ? 0.f : *a) + dwacc[t][i];
         }
@@ -349,6 +365,7 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
     atomicAdd(&p.dw[i], slab[ch * 16 + (ch >> 7) * 16 + tap]);
   }
 }
+
 
 }  // namespace
 
@@ -377,7 +394,9 @@ int conv0_mfma_bwd(const void* wave, const void* w, const void* cbias, const voi
   p.rows = (long)B * p.L0;
   const long nsteps = (p.rows + 15) / 16;
   const int grid = (int)std::min<long>((nsteps + 3) / 4, 256);
-  hipLaunchKernelGGL(conv0_mfma_bwd_kernel, dim3(grid), dim3(256), 0, st, p);
+  static const int map_env = W2VS_ENV_INT("W2VS_CONV0_BWD_MAP", 1);     // tuning build: 0 = the forward's channel layout (A/B)
+  if (map_env == 0) hipLaunchKernelGGL(conv0_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(conv0_mfma_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "conv0_bwd");
 }
 

@@ -87,13 +87,12 @@ constexpr bool epi_has_bias(int e) { return e == EPI_BIAS || e == EPI_BIAS_GELU 
 constexpr bool epi_is_gelu(int e) { return e == EPI_BIAS_GELU || e == EPI_BIAS_GELU_SAVE || e == EPI_BIAS_GELU_SAVEG; }
 constexpr bool epi_is_save(int e) { return e == EPI_BIAS_GELU_SAVE || e == EPI_BIAS_GELU_SAVEG; }
 constexpr bool epi_is_dact(int e) { return e == EPI_DGELU || e == EPI_MUL; }
-// gelu(x) and gelu'(x) from one erf / exp
+// gelu(x) and gelu'(x) from one evaluation of the normal tail (common.h)
 __device__ __forceinline__ void gelu_pair(float x, float& gv, float& dv) {
   float e;
-  const float er = fast_erf(x * 0.70710678118654752440f, e);
-  const float cdf = 0.5f * (1.0f + er);
+  const float cdf = normal_cdf(x, e);
   gv = x * cdf;
-  dv = cdf + x * 0.3989422804014327f * e;
+  dv = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // ---- register-direct epilogue of the DMA kernels (operands swapped: the accumulators hold C^T fragments) --------------
