@@ -77,8 +77,8 @@ for name, N, K in (("fc1 fwd", 3072, 768), ("qkv fwd", 2304, 768), ("fc2 fwd", 7
     for fname, fn in forms.items():
         for cold in (False, True):
             print("%-8s %-10s %-4s %6.1f us   %s" % (name, fname, "cold" if cold else "warm", t_us(fn, cold=cold), anatomy(fn, cold)), flush=True)
-    if K == 768 and N == 3072:
-        for dbg, what in ((1, "no GELU arithmetic"), (2, "no gelu' store"), (3, "neither"), (4, "no store at all"), (5, "no arithmetic, no store")):
+    if K == 768:
+        for dbg, what in ((0, "as shipped"), (8, "half-line stores (rounds 3-4 pattern)"), (1, "no GELU arithmetic"), (2, "no gelu' store"), (3, "neither"), (4, "no store at all"), (5, "no arithmetic, no store")):
             lib.w2vs_dbg_nt_stamps(None, dbg)
             print("%-8s gelu+saveg ablation %d (%s): warm %6.1f us  cold %6.1f us" % (name, dbg, what, t_us(forms["gelu+saveg"]), t_us(forms["gelu+saveg"], cold=True)), flush=True)
         lib.w2vs_dbg_nt_stamps(None, 0)
