@@ -47,7 +47,14 @@ def test_quantize_and_sample_negatives():
     B, T = feats.shape[:2]
     assert tuple(q.shape) == (B, T, qr.shape[-1]) and tuple(idx.shape) == (B, T, ocfg.latent_groups)
     same = (idx.cpu().view(-1, ocfg.latent_groups) == idxr).all(-1)
-    assert float(same.float().mean()) > 0.97                             # near-ties of bf16 features may flip
+    # near-ties of the bf16 features may flip (48 rows: one flip is 2 %): every disagreement must BE a near-tie in the oracle's
+    # own logits - margin between its best code and the HIP choice below 5 % of the logit spread (~5 steps of the features' bf16 noise) - as tests/test_model_gpu.py asks
+    G, V = ocfg.latent_groups, ocfg.latent_vars
+    ql = torch.nn.functional.linear(feats.reshape(-1, feats.shape[-1]), P["quantizer.weight_proj.weight"],
+                                    P["quantizer.weight_proj.bias"]).view(-1, V)
+    hv = ql.gather(1, idx.cpu().long().view(-1, 1)).view(-1)
+    assert float((ql.max(-1).values - hv).max()) < 0.05 * float(ql.std())
+    assert float(same.float().mean()) > 0.9
     assert rel(q.view(B * T, -1)[same.cuda()], qr.view(B * T, -1)[same]) < 1e-2
     # sample_negatives: same torch.randint draws as the reference helper, rows gathered on the GPU
     y = torch.randn(2, 31, 128).to(BF).cuda()

@@ -279,7 +279,11 @@ def _assert_parity(rep, grads, *, loss=1e-3, loss_free=None, act=2e-2, bar_scale
     # error, `features` above), i.e. ~0.1-0.2 on logits of std 22.8 whose top-2 gap is ~6.6 on average: 1-2 % of the
     # argmaxes sit closer than that and may flip.  Every disagreement must be such a near-tie in the ORACLE's logits.
     assert rep["code_idx_equal"] >= 0.975, rep
-    assert rep["code_flip_margin_max"] < 0.03 * rep["code_logit_std"], rep
+    # "near-tie" in units of the logit noise the bf16 features cause: a relative feature error e (measured: rep["features"])
+    # moves a logit by ~e x the logit spread, so a flip needs a top-2 margin of a few such steps.  The worst margin over the
+    # ~4 000 decisions of the bench batch is an extreme-value statistic (measured 0.08 ... 0.88 from case to case and build to
+    # build): the bar is 5 steps (exceeded by chance in ~1 % of the runs), never below 3 % of the spread.
+    assert rep["code_flip_margin_max"] < max(0.03, 5.0 * rep["features"]) * rep["code_logit_std"], rep
     assert not rep["grad_nonfinite"], rep["grad_nonfinite"]
     over = {g: e for g, e in rep["grad_by_group"].items() if not e <= GRAD_BARS[g] * bar_scale}
     assert not over, (over, rep["grad_worst"])
