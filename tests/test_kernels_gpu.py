@@ -184,6 +184,40 @@ def test_layernorm_fwd_bwd(ops, Cc):
     assert rel(dg, gr.grad) < 5e-3 and rel(db, br.grad) < 5e-3
 
 
+@pytest.mark.parametrize("Cc,use_dsum,p_drop", [(768, False, 0.1), (768, True, 0.0), (1024, True, 0.1), (512, False, 0.0), (1024, False, 0.1)])
+def test_layernorm_bwd_lean_one_row_per_wave(ops, Cc, use_dsum, p_drop):
+    """The encoder layers' backward at activation sizes (rows >= 1024: ln_bwd_lean_kernel, one row per wave, 8-byte pieces,
+    row sums folded through LDS into the partial slab): dx with the dropout decisions of the row kernels' hash applied, dres
+    without them, the pre-LN form's extra stream gradient (dsum), dgamma / dbeta - against autograd of F.layer_norm.  2 501
+    rows: the last workgroup is ragged (fs/modules/layer_norm.py:30-35, wav2vec2.py:955-976)."""
+    rows = 2501
+    x, r = rnd(rows, Cc, seed=1), rnd(rows, Cc, seed=2)
+    g, b = (1 + 0.1 * torch.randn(Cc)).to(BF), (0.1 * torch.randn(Cc)).to(BF)
+    y, s_out, mean, rstd = ops.ln_fwd(dev(x), dev(g), dev(b), res=dev(r), want_sum=True)
+    sr = s_out.float().cpu().requires_grad_(True)
+    gr, br = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = F.layer_norm(sr, (Cc,), gr, br, 1e-5)
+    assert rel(y, ref) < 4e-3
+    dy = rnd(rows, Cc, seed=3)
+    ds = rnd(rows, Cc, seed=4) if use_dsum else None
+    ref.backward(dy.float())
+    want_res = sr.grad + (ds.float() if use_dsum else 0.0)
+    dg = torch.zeros(Cc, device="cuda")
+    db = torch.zeros(Cc, device="cuda")
+    dx, dres = ops.ln_bwd(s_out, dev(g), dev(b), mean, rstd, dg, db, dy=dev(dy), dsum=dev(ds) if use_dsum else None,
+                          want_dres=True, p_drop=p_drop, seed=77)
+    assert rel(dres, want_res) < 5e-3
+    if p_drop > 0:
+        keep = (ops.dropout(torch.ones(rows, Cc, device="cuda", dtype=BF), p_drop, 77).float() > 0).float().cpu()
+        thr16 = int(float(np.float32(p_drop)) * 4294967296.0) >> 16
+        want_dx = want_res * keep * (65536.0 / (65536.0 - thr16))
+        assert 0.85 < float(keep.mean()) < 0.95
+    else:
+        want_dx = want_res
+    assert rel(dx, want_dx) < 5e-3
+    assert rel(dg, gr.grad) < 5e-3 and rel(db, br.grad) < 5e-3
+
+
 def test_layernorm_gelu_penalty_scale(ops):
     """feat-LN backward: GradMultiply scale, features_pen term and the producer's GELU chained."""
     rows, Cc = 500, 512
