@@ -622,6 +622,45 @@ def test_nonfinite_gradient_skips_the_update_and_raises(clip):
     ops.ARENA.deactivate()
 
 
+def test_two_skipped_updates_in_a_row_are_both_taken_out_of_the_step_count():
+    """Round-4 advisor finding: the host used to subtract a stale copy of the device's skip counter and then zero the counter -
+    a skip that happened after that copy was lost and Adam's bias correction / the LR schedule drifted by one.  The device
+    counter is sticky now and the host remembers how many skips it has reported: two poisoned updates in a row, one report,
+    both out of the step count; a caller that catches the error starts a fresh update (micro = 0, no overwrite flag pending)."""
+    from wav2vec_s_amd import trainer, ops
+    B, L = 2, 16000
+    src = torch.randn(B, L, generator=torch.Generator().manual_seed(4)).to(BF).cuda()
+    w, cfg, model, crit = _build(SMALL)
+    step = trainer.TrainStep(model, crit, lr=1e-3, arena_gib=1.0)
+    mk = _draws(cfg, B, L)
+    model.inject_draws(mk())
+    step({"net_input": {"source": src}})
+    torch.cuda.synchronize()
+    assert step.flat.step == 1
+
+    def plant(ts):
+        ts.flat.arena.flat[777] = float("nan")
+    step._before_optimizer = plant
+    step._flag_event = None                              # (whatever copy the first update enqueued is not the one under test)
+    for _ in range(2):                                   # two poisoned updates before anybody looks
+        step._flag_event = None                          # (no report from the start of the second call: check() below makes it)
+        model.inject_draws(mk())
+        step({"net_input": {"source": src}})
+    step._before_optimizer = None
+    torch.cuda.synchronize()
+    assert step.flat.step == 3                            # the host counted all three
+    with pytest.raises(FloatingPointError):
+        step.check()
+    assert step.flat.step == 1 and step._bad_reported == 2 and step.micro == 0
+    step.check()                                         # reported once
+    model.inject_draws(mk())
+    step({"net_input": {"source": src}})                 # and training goes on from a clean update
+    torch.cuda.synchronize()
+    step.check()
+    assert step.flat.step == 2
+    ops.ARENA.deactivate()
+
+
 @pytest.mark.parametrize("clip", [25.0, 0.0])
 def test_trainstep_follows_the_reference_optimizer_trajectory(clip):
     """Row f2 pinned at the level a trainer sees: TrainStep (sample_size division, device-side clip_grad_norm_, polynomial-decay
