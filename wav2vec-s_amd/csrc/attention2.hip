@@ -50,8 +50,29 @@ constexpr int MAXT2 = 256;   // 32-row tiles per sequence (N <= 8192; longer seq
 struct Attn2P {
   AttnP a;
   int ntiles;                 // query tiles (fwd, dq) or key tiles (dkv)
+#ifdef W2VS_ABLATION
+  // tuning build only: in-kernel time stamps (s_memrealtime, 100 MHz), 8 words per wave: 0 entry, 1 loop entry, 2 loop exit,
+  // 3 behind the merge barrier, 4 end, 5 list length, 6 HW_ID, 7 XCC_ID (tools/attn_anatomy_probe.py); null = off
+  unsigned long long* stamps;
+#endif
   uint64_t rec[MAXT2];
 };
+#ifdef W2VS_ABLATION
+#define W2VS_ASTAMP_V(slot, v)                                                                                         \
+  do {                                                                                                                 \
+    if (pp.stamps && lane == 0) pp.stamps[(((long)blockIdx.y * gridDim.x + blockIdx.x) * NW + wid) * 8 + (slot)] = (v);   \
+  } while (0)
+#define W2VS_ASTAMP(slot) W2VS_ASTAMP_V(slot, __builtin_amdgcn_s_memrealtime())
+#define W2VS_ASTAMP_IDS(n)                                                                                             \
+  do {                                                                                                                 \
+    W2VS_ASTAMP_V(5, (unsigned long long)(n));                                                                         \
+    W2VS_ASTAMP_V(6, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   /* HW_ID */    \
+    W2VS_ASTAMP_V(7, (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));  /* XCC_ID */   \
+  } while (0)
+#else
+#define W2VS_ASTAMP(slot) do { } while (0)
+#define W2VS_ASTAMP_IDS(n) do { } while (0)
+#endif
 
 struct SubList { int nM, rc0, nT; };   // sub-tiles [0, nM) then rc0, rc0 + 1, ... : nT in all
 
@@ -181,6 +202,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
+  W2VS_ASTAMP(0);
   const uint64_t rec = pp.rec[blockIdx.y];       // grid (B*H, tiles): x runs fastest, rows are dispatched longest first
   const int qt = (int)(rec & 1023), bh = blockIdx.x;
   const int b = fdiv(bh, p.mg_H), h = bh - b * p.H;
@@ -241,6 +263,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qs + uswz(r32, (2 * s + hh) * 8));
+  W2VS_ASTAMP(1);
+  W2VS_ASTAMP_IDS(tl.nT);
   while (pos < tl.nT && !(W2VS_AABL & 8)) {
     const int k0 = tile_of(pos) * 32;
     const int nxt = pos + NW;
@@ -331,6 +355,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
     pos = nxt;
   }
   // ---- merge the four partial softmaxes ----
+  W2VS_ASTAMP(2);
   float ltot = lrun + other_half(lrun);
   __syncthreads();                       // every wave is done with its V tile: the memory becomes the merge buffer
   if (wid > 0) {
@@ -341,6 +366,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
     rw[33 * 64 + lane] = ltot;
   }
   __syncthreads();
+  W2VS_ASTAMP(3);
   if (wid != 0) return;
   float mw[NW - 1], mall = mrun;
 #pragma unroll
@@ -372,6 +398,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_fwd_kernel(Attn2P pp) {
     }
     if (hh == 0 && p.lse) p.lse[((long)(b * p.H + h)) * p.Ns + q] = ltot > 0.f ? (mall + log2f(ltot)) * LN2 : INFINITY;
   }
+  W2VS_ASTAMP(4);
 }
 
 // =================================================================================================
@@ -390,6 +417,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_dq_kernel(Attn2P pp) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
+  W2VS_ASTAMP(0);
   const uint64_t rec = pp.rec[blockIdx.y];       // grid (B*H, tiles): x runs fastest, rows are dispatched longest first
   const int qt = (int)(rec & 1023), bh = blockIdx.x;
   const int b = fdiv(bh, p.mg_H), h = bh - b * p.H;
@@ -466,6 +494,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_dq_kernel(Attn2P pp) {
   bf16* Kw = (bf16*)red_mem + wid * (2 * 32 * HD);
   bf16* Vw = Kw + 32 * HD;
   const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  W2VS_ASTAMP(1);
+  W2VS_ASTAMP_IDS(tl.nT);
   while (pos < tl.nT) {
     const int k0 = tile_of(pos) * 32;
     const int nxt = pos + NW;
@@ -524,12 +554,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_dq_kernel(Attn2P pp) {
     }
     pos = nxt;
   }
+  W2VS_ASTAMP(2);
   __syncthreads();
   if (wid > 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { red[wid - 1][i][lane] = D0[i]; red[wid - 1][16 + i][lane] = D1[i]; }
   }
   __syncthreads();
+  W2VS_ASTAMP(3);
   if (wid != 0) return;
 #pragma unroll
   for (int w = 0; w < NW - 1; ++w)
@@ -546,6 +578,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn2_dq_kernel(Attn2P pp) {
       *(bf16x4*)(drow_p + 32 + 8 * gq + 4 * hh) = v1;
     }
   }
+  W2VS_ASTAMP(4);
 }
 
 // =================================================================================================
@@ -566,6 +599,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_dkv_kernel(Attn2P pp) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r32 = lane & 31, hh = lane >> 5;
+  W2VS_ASTAMP(0);
   const uint64_t rec = pp.rec[blockIdx.y];
   const int kt = (int)(rec & 1023), bh = blockIdx.x;
   const int b = fdiv(bh, p.mg_H), h = bh - b * p.H;
@@ -641,6 +675,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_dkv_kernel(Attn2P pp) {
     kf[s] = *(const bf16x8*)(KVs + uswz(r32, (2 * s + hh) * 8));
     vf[s] = *(const bf16x8*)(KVs + 32 * HD + uswz(r32, (2 * s + hh) * 8));
   }
+  W2VS_ASTAMP(1);
+  W2VS_ASTAMP_IDS(ql.nT);
   while (pos < ql.nT) {
     const int q0 = tile_of(pos) * 32;
     const int nxt = pos + NW;
@@ -747,6 +783,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_dkv_kernel(Attn2P pp) {
     }
     pos = nxt;
   }
+  W2VS_ASTAMP(2);
   __syncthreads();                       // every wave is done with its tiles: the memory becomes the reduction buffer
   if (wid > 0) {
     float* rw = smem + (wid - 1) * 64 * 64;
@@ -757,6 +794,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_dkv_kernel(Attn2P pp) {
     }
   }
   __syncthreads();
+  W2VS_ASTAMP(3);
   if (wid != 0) return;
 #pragma unroll
   for (int w = 0; w < NW - 1; ++w) {
@@ -784,6 +822,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn2_dkv_kernel(Attn2P pp) {
       *(bf16x4*)(dvr + 32 + 8 * gq + 4 * hh) = b1;
     }
   }
+  W2VS_ASTAMP(4);
 }
 
 // the launch's record table (host): one record per 32-row tile with its visible sub-tile list, longest list first - the
@@ -856,9 +895,19 @@ bool attn2_ok(const AttnP& p) {
          ldmax < (1l << 24) && (long)std::max(p.N, p.Nq) * ldmax < (1l << 32);
 }
 
+#ifdef W2VS_ABLATION
+static unsigned long long* g_attn_stamps = nullptr;
+static int g_attn_stamp_pass = 0;      // which launch writes: 0 forward, 1 dQ pass, 2 dK/dV pass
+extern "C" void w2vs_dbg_attn_stamps(void* buf, int pass) { g_attn_stamps = (unsigned long long*)buf; g_attn_stamp_pass = pass; }
+#define W2VS_SET_STAMPS(pp, pass) (pp).stamps = g_attn_stamp_pass == (pass) ? g_attn_stamps : nullptr
+#else
+#define W2VS_SET_STAMPS(pp, pass) do { } while (0)
+#endif
+
 int attn2_fwd(const AttnP& p, hipStream_t st) {
   Attn2P pp;
   pp.a = p;
+  W2VS_SET_STAMPS(pp, 0);
   pp.a.nQT = (p.Nq + 31) / 32; pp.a.nKT = (p.N + 31) / 32;
   const int nqt = (p.Nq + 31) / 32;
   // a launch carries at most MAXT2 tile records in its kernel argument: the cross mode (queries = G x U joiner rows, up to
@@ -879,9 +928,11 @@ int attn2_bwd(const AttnP& p, hipStream_t st) {
   for (int t0 = 0; t0 < nqt; t0 += MAXT2) {
     const int cnt = std::min(MAXT2, nqt - t0);
     query_tile_table(pp, p, t0, cnt);
+    W2VS_SET_STAMPS(pp, 1);
     W2VS_LAUNCH_DM_NW(attn2_dq_kernel, cnt)     // dq rows >= Nq are not written
   }
   key_tile_table(pp, p, nkt);
+  W2VS_SET_STAMPS(pp, 2);
   {
     static const int dkv_nw_env = W2VS_ENV_INT("W2VS_ATTN_DKV_NW", 0);
     const int longest_k = (int)(pp.rec[0] >> 10) & 1023;
