@@ -338,6 +338,7 @@ def main():
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
     ms_median = float(np.median(per_step_ms)) if per_step_ms else None
+    ms_min_max = [round(min(per_step_ms), 3), round(max(per_step_ms), 3)] if per_step_ms else None
     audio_s = audio_done[0] / args.steps        # per step and GPU (== B * L / SR unless --length-mix)
     value = world * audio_s * args.steps / elapsed
     roof = ops.GEMM_TIMER.report(PEAK_BF16_TFLOPS)
@@ -410,6 +411,7 @@ def main():
         "metric": "audio-seconds/s/GPU, wav2vec-S %s pretrain step, 1/2/4/8 MI355X" % ("large" if large else "base"),
         "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": None if ms_median is None else round(ms_median, 3),
+        "ms_per_step_min_max": ms_min_max,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("wav2vec-S large (24L d1024 pre-LN, 315M params, BASELINE configs[3]) pretrain step: fwd + InfoNCE/"
