@@ -41,8 +41,8 @@ def t_us(fn, iters=20, cold=False):
     return tot / iters * 1e3
 
 
-def anatomy(fn, cold):
-    lib.w2vs_dbg_nt_stamps(stamps.data_ptr(), 0)
+def anatomy(fn, cold, dbg=0):
+    lib.w2vs_dbg_nt_stamps(stamps.data_ptr(), dbg)
     rows = []
     for _ in range(6):
         stamps.zero_()
@@ -59,10 +59,13 @@ def anatomy(fn, cold):
         u = (s - t0) / 100.0                      # 100 MHz ticks -> us
         u[~live] = np.nan
         rows.append([np.nanmedian(u[:, :, 0]), np.nanmax(u[:, :, 0]), np.nanmedian(u[:, :, 1] - u[:, :, 0]), np.nanmedian(u[:, :, 2] - u[:, :, 1]),
-                     np.nanmedian(u[:, :, 3] - u[:, :, 2]), np.nanmedian(u[:, :, 6] - u[:, :, 3]), np.nanmedian(u[:, :, 6]), np.nanmax(u[:, :, 6])])
+                     np.nanmedian(u[:, :, 3] - u[:, :, 2]), np.nanmedian(u[:, :, 6] - u[:, :, 3]), np.nanmedian(u[:, :, 6]), np.nanmax(u[:, :, 6]),
+                     np.nanmedian(u[:, 0, 2] - u[:, 0, 1]), np.nanmedian(u[:, 1, 2] - u[:, 1, 1]),
+                     np.nanmedian(u[:, 0, 3] - u[:, 0, 2]), np.nanmedian(u[:, 1, 3] - u[:, 1, 2])])
     lib.w2vs_dbg_nt_stamps(None, 0)
     r = np.median(np.array(rows[1:]), axis=0)
-    return ("start med %.1f max %.1f | first K tile %.1f | K loop %.1f | epilogue issue %.1f | drain %.1f | end med %.1f max %.1f" % tuple(r))
+    return ("start med %.1f max %.1f | first K tile %.1f | K loop %.1f | epilogue issue %.1f | drain %.1f | end med %.1f max %.1f"
+            " | per wave group: K loop %.1f / %.1f, epilogue issue %.1f / %.1f" % tuple(r))
 
 
 for name, N, K in (("fc1 fwd", 3072, 768), ("qkv fwd", 2304, 768), ("fc2 fwd", 768, 3072)):
@@ -78,7 +81,7 @@ for name, N, K in (("fc1 fwd", 3072, 768), ("qkv fwd", 2304, 768), ("fc2 fwd", 7
         for cold in (False, True):
             print("%-8s %-10s %-4s %6.1f us   %s" % (name, fname, "cold" if cold else "warm", t_us(fn, cold=cold), anatomy(fn, cold)), flush=True)
     if K == 768:
-        for dbg, what in ((0, "as shipped"), (8, "half-line stores (rounds 3-4 pattern)"), (1, "no GELU arithmetic"), (2, "no gelu' store"), (3, "neither"), (4, "no store at all"), (5, "no arithmetic, no store")):
+        for dbg, what in ((0, "as shipped"), (1, "no GELU arithmetic"), (2, "no gelu' store"), (3, "neither"), (4, "no store at all"), (5, "no arithmetic, no store")):
             lib.w2vs_dbg_nt_stamps(None, dbg)
             print("%-8s gelu+saveg ablation %d (%s): warm %6.1f us  cold %6.1f us" % (name, dbg, what, t_us(forms["gelu+saveg"]), t_us(forms["gelu+saveg"], cold=True)), flush=True)
         lib.w2vs_dbg_nt_stamps(None, 0)
