@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_fwd_kernel(Conv0M p) {
 // wider scheduling windows (a barrier every 2 / 4 tile pairs instead of every pair) 251-262 us: no effect; a form with 2 or 4
 // waves sharing a 16-row step (two waves per SIMD; tools/probes/conv0_bwd_split_round5.diff) 250-256 us / 298-321 us.
 // Counters (tools/conv0_pmc.sh): this kernel issues vector instructions 47 % of its wave-cycles and waits 40 %.
-template <int MAP>
+// PIPE (round 5, the product's choice): pass 1 as a software pipeline over tile pairs inside the wave - 252-257 -> 239-242 us on
+// the same box (tools/conv0_sweep.sh).  One stage deeper (MFMAs two pairs ahead) 243-245 us; the same treatment of pass 2: nothing.
+template <int MAP, int PIPE>
 __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
   __shared__ s16x4 wl[NT * 64];
   __shared__ s16x4 dzs[4][NT * 64];      // per wave: dz fragments of the current 16 rows (pass 1 -> pass 2)
@@ -207,6 +209,14 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
   for (int t = 0; t < NT; ++t) {
     bf16x2 v; v[0] = p.lnw[ch_map<MAP>(t, lm)]; v[1] = p.lnb[ch_map<MAP>(t, lm)];
     gb[t] = __builtin_bit_cast(uint32_t, v);
+  }
+  // the pipelined pass 1 has no registers for them: the same words as a [tile][lm] table in LDS (2 KiB), read with the W fragments
+  __shared__ uint32_t gbl[PIPE ? NT * 16 : 1];
+  if constexpr (PIPE) {
+    if (tid < 16) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) gbl[t * 16 + tid] = gb[t];
+    }
   }
   f32x4 dwacc[NT];   // tile t: lane (tap = lm, rg) holds channels ch_of(t, rg*4+i)
 #pragma unroll
@@ -268,6 +278,59 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
     // (16 KiB per wave; pass 2 reads it back both as floats and, unchanged, as an MFMA A operand);
     // row sums of dxhat and dxhat*xhat
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PIPE) {
+      // The wave is alone on its SIMD: nothing covers its LDS and MFMA latencies but its own instructions.  Three tile pairs
+      // are in flight: while the vector work of pair t is issued (F), the gelu' lookups of pair t+2 are on their way (L, behind
+      // its conv MFMAs M) and the W fragments and gamma / beta words of pair t+4 are being read (R).
+      s16x4 wa[2];
+      uint32_t gv[3][2];
+      float xh[2][2][4], gd[2][2][4];
+      auto R = [&](int t, uint32_t (&g)[2]) {
+        wa[0] = wl[t * 64 + lane]; wa[1] = wl[(t + 1) * 64 + lane];
+        g[0] = gbl[t * 16 + lm]; g[1] = gbl[(t + 1) * 16 + lm];
+      };
+      auto ML = [&](const uint32_t (&g)[2], float (&x)[2][4], float (&d)[2][4], int t_next, uint32_t (&g_next)[2], bool rd) {
+        const f32x4 c0 = mfma16(xa, wa[0], f32x4{0.f, 0.f, 0.f, 0.f});
+        const f32x4 c1 = mfma16(xa, wa[1], f32x4{0.f, 0.f, 0.f, 0.f});
+        if (rd) R(t_next, g_next);                       // into the registers the MFMAs have just read
+        const float g0 = __uint_as_float(g[0] << 16), b0 = __uint_as_float(g[0] & 0xFFFF0000u);
+        const float g1 = __uint_as_float(g[1] << 16), b1 = __uint_as_float(g[1] & 0xFFFF0000u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[0][i] = fmaf(c0[i], rstd[i], mr[i]); x[1][i] = fmaf(c1[i], rstd[i], mr[i]);
+          d[0][i] = gdtab[G::index(G::key(fmaf(x[0][i], g0, b0)))];
+          d[1][i] = gdtab[G::index(G::key(fmaf(x[1][i], g1, b1)))];
+        }
+      };
+      auto F = [&](int t, const uint32_t (&g)[2], const float (&x)[2][4], const float (&d)[2][4]) {
+        const int u = t >> 3, rgi = (t & 7) >> 1;
+        const float g0 = __uint_as_float(g[0] << 16), g1 = __uint_as_float(g[1] << 16);
+        s16x4 z0, z1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t pk = dyb[u][i][rgi];
+          const float dz0 = bf2f(f2bf(__uint_as_float(pk << 16) * d[0][i]));
+          const float dz1 = bf2f(f2bf(__uint_as_float(pk & 0xFFFF0000u) * d[1][i]));
+          const float dx0 = dz0 * g0, dx1 = dz1 * g1;
+          s1[i] += dx0 + dx1;
+          s2[i] = fmaf(dx0, x[0][i], fmaf(dx1, x[1][i], s2[i]));
+          z0[i] = bf_bits(dz0); z1[i] = bf_bits(dz1);
+        }
+        dzl[t * 64 + lane] = z0;
+        dzl[(t + 1) * 64 + lane] = z1;
+      };
+      R(0, gv[0]);
+      ML(gv[0], xh[0], gd[0], 2, gv[1], true);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; t += 2) {
+        const int k = (t >> 1) & 1, q = (t >> 1) % 3;
+        if (t + 2 < NT) ML(gv[(q + 1) % 3], xh[k ^ 1], gd[k ^ 1], t + 4, gv[(q + 2) % 3], t + 4 < NT);
+        __builtin_amdgcn_sched_barrier(0);
+        F(t, gv[q], xh[k], gd[k]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < NT; t += 2) {
       const f32x4 c0 = mfma16(xa, wl[t * 64 + lane], f32x4{0.f, 0.f, 0.f, 0.f});
@@ -297,6 +360,7 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
       dzl[(t + 1) * 64 + lane] = z1;
       __builtin_amdgcn_sched_barrier(0);   // keep tile pairs in program order: hoisting MFMAs blows the register budget
     }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s1[i] = reduce16(s1[i]) * (1.f / CC); s2[i] = reduce16(s2[i]) * (1.f / CC); }
     asm volatile("" ::: "memory");
@@ -306,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void conv0_mfma_bwd_kernel(Conv0M p) {
     for (int t = 0; t < NT; ++t) {
       const f32x4 c = mfma16(xa, wl[t * 64 + lane], f32x4{0.f, 0.f, 0.f, 0.f});
       const s16x4 za = dzl[t * 64 + lane];
-      uint32_t gv = gb[t];
+      uint32_t gv = PIPE ? gbl[t * 16 + lm] : gb[t];
       asm volatile("" : "+v"(gv));
       const float gt = __uint_as_float(gv << 16);
       s16x4 dc, ph, pl;
@@ -395,8 +459,10 @@ int conv0_mfma_bwd(const void* wave, const void* w, const void* cbias, const voi
   const long nsteps = (p.rows + 15) / 16;
   const int grid = (int)std::min<long>((nsteps + 3) / 4, 256);
   static const int map_env = W2VS_ENV_INT("W2VS_CONV0_BWD_MAP", 1);     // tuning build: 0 = the forward's channel layout (A/B)
-  if (map_env == 0) hipLaunchKernelGGL(conv0_mfma_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(conv0_mfma_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+  static const int pipe_env = W2VS_ENV_INT("W2VS_CONV0_BWD_PIPE", 1);   // tuning build: 0 = pass 1 one tile pair at a time (A/B)
+  if (map_env == 0) hipLaunchKernelGGL((conv0_mfma_bwd_kernel<0, 0>), dim3(grid), dim3(256), 0, st, p);
+  else if (pipe_env == 0) hipLaunchKernelGGL((conv0_mfma_bwd_kernel<1, 0>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv0_mfma_bwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, p);
   return hip_check(hipGetLastError(), "conv0_bwd");
 }
 
