@@ -915,10 +915,13 @@ __global__ __launch_bounds__(256) void enc_prologue_fwd_kernel(EncProP p) {
   }
 }
 
-// one wave per source frame (b, t): gathers the gradient of the frame and of all its copies
-__global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
+// one wave per source frame (b, t): gathers the gradient of the frame and of all its copies.  EPB_NW waves per block: the
+// number of BLOCKS is what the closing atomics cost (2 304 per block), the number of WAVES what covers a frame's dependent
+// loads (copy list -> gradient rows -> source row -> position row: ~5 us per frame for a wave alone on its SIMD)
+constexpr int EPB_NW = 8;
+__global__ __launch_bounds__(EPB_NW * 64) void enc_prologue_bwd_kernel(EncProP p) {
   const int lane = threadIdx.x & 63;
-  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int wave_id = blockIdx.x * EPB_NW + (threadIdx.x >> 6), nwaves = gridDim.x * EPB_NW;
   const int C = p.C;
   const Drop Din = make_drop(p.p_in, p.seed_in), Denc = make_drop(p.p_enc, p.seed_enc);
   Row g, me, dgm, dbt, dme;
@@ -1005,7 +1008,7 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
   }
   // per-wave slabs red[w][kind][e][chunk] (pitch 136), folded by column afterwards - see ln_bwd_kernel
   constexpr int RP = 136, KIND = 8 * RP, SLAB = 3 * KIND;
-  __shared__ float red[4 * SLAB];
+  __shared__ float red[EPB_NW * SLAB];
   {
     float* mine = red + (threadIdx.x >> 6) * SLAB;
 #pragma unroll
@@ -1022,11 +1025,13 @@ __global__ __launch_bounds__(256) void enc_prologue_bwd_kernel(EncProP p) {
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+  for (int i = threadIdx.x; i < 3 * C; i += EPB_NW * 64) {
     const int kind = i / C, col = i - kind * C;
     if (kind < 2 && !p.apply_ln) continue;
     const int off = kind * KIND + (col & 7) * RP + (col >> 3);
-    const float sum = (red[off] + red[SLAB + off]) + (red[2 * SLAB + off] + red[3 * SLAB + off]);
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < EPB_NW; ++w) sum += red[w * SLAB + off];
     atomicAdd(kind == 0 ? &p.dg[col] : (kind == 1 ? &p.db[col] : &p.dmask_emb[col]), sum);
   }
 }
@@ -1061,8 +1066,8 @@ int enc_prologue_bwd(const EncPrologueDesc& d, hipStream_t st) {
   if (!p.dout || !p.dx || !p.dmask_emb || !p.dg || !p.db || !p.copy_start || !p.copy_list)
     return set_error("enc_prologue_bwd: null pointer");
   long rows = (long)p.B * p.T;
-  int grid = (int)std::min<long>((rows + 3) / 4, 256);
-  hipLaunchKernelGGL(enc_prologue_bwd_kernel, dim3(grid), dim3(256), 0, st, p);
+  int grid = (int)std::min<long>((rows + EPB_NW - 1) / EPB_NW, 256);
+  hipLaunchKernelGGL(enc_prologue_bwd_kernel, dim3(grid), dim3(EPB_NW * 64), 0, st, p);
   return hip_check(hipGetLastError(), "enc_prologue_bwd");
 }
 
