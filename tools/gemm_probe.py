@@ -41,8 +41,10 @@ for name, N, K, *rest in SHAPES:
     aux = torch.randn(R, N, device="cuda", generator=g).to(BF)
     ref = (x.float() @ w.float().t() + b.float())
     for cfg_name, tune in (("default", (-1, 0)), ("8ph 256x256", (8, 256)), ("8ph 320x256", (8, 320)), ("128^2 dma", (2, 0)), ("lc 256x128", (3, 256)), ("lc 160x128", (3, 160)), ("lc 160x256", (3, 1160)), ("persist 256x128", (5, 256)), ("persist 192x128", (5, 192)), ("lc 192x128", (3, 192)), ("128^2 regs", (0, 0)), ("128^2 mode1", (1, 0)), ("persist 160x128", (5, 160)),
-                           ("persist 160x256", (5, 1160))):
-        if tune[1] == 1160 and N % 256:
+                           ("persist 160x256", (5, 1160)), ("persist 160x256 / 4 consumer waves (tuning build)", (5, 2160))):
+        if tune[1] in (1160, 2160) and N % 256:
+            continue
+        if tune[1] == 2160 and "tuning" not in os.environ.get("W2VS_LIB", ""):
             continue
         ops.gemm_tune(*tune)
         y = ops.linear_fwd(x, w, b)

@@ -1969,7 +1969,12 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
   static const int lc_env = W2VS_ENV_INT("W2VS_LC_H", 0);
   if (lc_env > 0) lc_h = lc_env;
   if (g_force_lc_h > 0) lc_h = g_force_lc_h;
-  // lc_h = 1160 selects the 160 x 256 loader/consumer tile (WN = 4)
+  // lc_h = 1160 selects the 160 x 256 loader/consumer tile (WN = 4); tuning build: 2160 = the same tile on FOUR consumer waves
+  // (one per SIMD, 160 x 64 outputs each) - the price of a lone consumer wave per SIMD, what a ping-pong schedule would run on
+  bool lone4 = false;
+#ifdef W2VS_TUNING
+  if (lc_h == 2160) { lone4 = true; lc_h = 1160; }
+#endif
   const bool wide = (lc_h == 1160) || (wide_auto && lc_h == 160 && lc_env <= 0 && g_force_lc_h <= 0 && mode_env < 0 && g_force_nt_mode < 0);
   if (wide) { lc_h = 160; if (mode != 3 && mode != 5 && mode != 6) return set_error("gemm_nt: the 160 x 256 tile exists for the loader/consumer kernels only"); }
   if (mode != 8 && lc_h == 320) lc_h = 256;                  // a forced mode after the model picked the 8-phase tile
@@ -1993,6 +1998,11 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
 #ifdef W2VS_ABLATION
   p.stamps = g_nt_stamps; p.epi_dbg = g_epi_dbg;
 #endif
+#ifdef W2VS_TUNING
+#define W2VS_LONE4_LAUNCH(E) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 1, 10, 4>), gp, dim3(512), 0, s, p, ntm_, ntn_, tot_)
+#else
+#define W2VS_LONE4_LAUNCH(E) (void)0
+#endif
 #define NT_LAUNCH(E)                                                                          \
   do {                                                                                        \
     if (mode == 8) {                /* 8-phase, persistent: (lc_h) x 256 tiles */              \
@@ -2004,7 +2014,8 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     } else if (mode == 5 || mode == 6) {   /* 6: the same kernel with one workgroup per tile */ \
       const int ntm_ = grid8.y, ntn_ = grid8.x, tot_ = ntm_ * ntn_ * (int)grid8.z;            \
       const dim3 gp(mode == 6 ? tot_ : std::min(tot_, 256));                                  \
-      if (wide) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_);          \
+      if (lone4) { W2VS_LONE4_LAUNCH(E); }                                                    \
+      else if (wide) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_);     \
       else if (lc_h == 256) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 4, 4>), gp, dim3(768), 0, s, p, ntm_, ntn_, tot_); \
       else if (lc_h == 192) hipLaunchKernelGGL((gemm_nt_p_kernel<E, 3, 4>), gp, dim3(640), 0, s, p, ntm_, ntn_, tot_); \
       else hipLaunchKernelGGL((gemm_nt_p_kernel<E, 2, 5>), gp, dim3(512), 0, s, p, ntm_, ntn_, tot_);                  \
@@ -2030,6 +2041,7 @@ int gemm_nt(const GemmDesc& d, hipStream_t s) {
     default: return set_error("gemm_nt: unknown epilogue");
   }
 #undef NT_LAUNCH
+#undef W2VS_LONE4_LAUNCH
   // profiling id = one kernel symbol family: 16 * form + epilogue (form 0: gemm_nt_kernel, 1: gemm_nt_lc_kernel, 2: gemm_nt_p_kernel);
   // the weight-gradient kernels use 10..12 (form 0 epilogues stop at 8)
   const int form = mode == 8 ? 3 : (mode == 5 || mode == 6) ? 2 : (mode == 3 ? 1 : 0);
