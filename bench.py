@@ -179,8 +179,9 @@ def main():
     ap.add_argument("--update-freq", type=int, default=1,
                     help="micro-batches per optimizer update (BASELINE configs[2] quotes 8); a timed 'step' stays ONE micro-batch "
                          "pass, so K steps = K micro-batches and K / update_freq updates + gradient exchanges")
-    ap.add_argument("--wire", default=os.environ.get("W2VS_WIRE", "fp32"), choices=["fp32", "bf16"],
-                    help="N > 1: dtype the gradient all-reduce moves (bf16 = half the xGMI bytes, the reference's model-dtype exchange)")
+    ap.add_argument("--wire", default=os.environ.get("W2VS_WIRE", "bf16"), choices=["fp32", "bf16"],
+                    help="N > 1: dtype the gradient all-reduce moves.  bf16 (default) = the reference's model-dtype exchange, 180.6 MB "
+                         "per update (SURVEY.md section 8e); fp32 = the arena in place, exact sums, twice the xGMI bytes")
     ap.add_argument("--no-gemm-peak", action="store_true",
                     help="skip the 8192^3 calibration GEMM behind the timed region (profiler passes: its launches would be "
                          "pooled with the step's own launches of the same kernel symbol)")
