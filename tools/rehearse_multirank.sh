@@ -6,7 +6,7 @@ set -e
 mkdir -p gpurun_out
 export W2VS_REHEARSE_ONE_GPU=1 HSA_ENABLE_IPC_MODE_LEGACY=0
 unset WORLD_SIZE RANK LOCAL_RANK
-timeout -k 10 500 python bench.py --gpus 2 --steps 6 --warmup 2 --wire ${1:-fp32} > gpurun_out/rehearse_2rank.out 2> gpurun_out/rehearse_2rank.err
+timeout -k 10 500 python bench.py --gpus 2 --steps 6 --warmup 2 --wire ${1:-bf16} > gpurun_out/rehearse_2rank.out 2> gpurun_out/rehearse_2rank.err
 grep -c '^{"metric"' gpurun_out/rehearse_2rank.out
 grep '^{"metric"' gpurun_out/rehearse_2rank.out | tail -1 > gpurun_out/rehearse_2rank.json
 cut -c1-400 gpurun_out/rehearse_2rank.json
