@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of a Python-level switch in the step: bench.py alternately with $1=0 and $1=1, $2 rounds (default 3), extra flags behind.
-#   bash tools/ab_env.sh W2VS_WT_ASYNC 3 [--workload large]
+#   bash tools/ab_env.sh W2VS_OVERWRITE_WGRADS 3 [--workload large]
 V=${1:?env var}; N=${2:-3}; shift 2
 for i in $(seq $N); do
   for x in 0 1; do
