@@ -122,6 +122,37 @@ __device__ __forceinline__ float normal_cdf(float x, float& ex2) {
   ex2 = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
   return x >= 0.f ? 1.0f - q : q;
 }
+// Two values at a time, the same arithmetic operation for operation (results are bit-identical to the scalar forms): written
+// on 2-vectors so that the compiler emits v_pk_fma_f32 / v_pk_mul_f32 - one issue slot per PAIR.  Left to itself hipcc keeps the
+// Horner chain scalar (v_fmaak_f32 with its literal).  Round 5: conv layer 0's forward uses the pairs (110 -> 105 us alone, 103.7 ->
+// 100.8 in the step); in the GEMM epilogues they cut the fc1 forward's epilogue from 15.7 to 12.4 us in the probe and NOTHING in
+// the step (the packed constants cost the 8-phase kernel 33 more spilled SGPRs: 53.9 -> 54.8 us per launch) - not used there.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 normal_tail2(f32x2 ax) {
+  const f32x2 a = {fminf(ax.x, 6.0f), fminf(ax.y, 6.0f)};
+  f32x2 p = pk_fma(splat2(2.3433251092e-05f), a, splat2(-6.1973935318e-04f));
+  p = pk_fma(p, a, splat2(7.2603524696e-03f));
+  p = pk_fma(p, a, splat2(-5.1418609203e-02f));
+  p = pk_fma(p, a, splat2(-4.6086354093e-01f));
+  p = pk_fma(p, a, splat2(-1.1504803413f));
+  p = pk_fma(p, a, splat2(-1.0f));
+  return f32x2{__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+}
+__device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
+  const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+  return pk_fma(-ax, normal_tail2(ax), f32x2{fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)});
+}
+// gelu(x) and gelu'(x) of a pair from one evaluation of the tail each
+__device__ __forceinline__ void gelu_pair2(f32x2 x, f32x2& gv, f32x2& dv) {
+  const f32x2 q = normal_tail2(f32x2{fabsf(x.x), fabsf(x.y)});
+  const f32x2 t = (splat2(-0.72134752044448170368f) * x) * x;
+  const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  const f32x2 cdf = {x.x >= 0.f ? 1.0f - q.x : q.x, x.y >= 0.f ? 1.0f - q.y : q.y};
+  gv = x * cdf;
+  dv = pk_fma(x * splat2(0.3989422804014327f), e, cdf);
+}
 __device__ __forceinline__ float gelu_grad(float x) {  // Phi(x) + x phi(x)
   float e;
   const float cdf = normal_cdf(x, e);

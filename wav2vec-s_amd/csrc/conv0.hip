@@ -166,10 +166,11 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_fwd_kernel(Conv0M p) {
         for (int u = 0; u < 4; ++u) {
           bf16x8 o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
+          for (int e = 0; e < 8; e += 2) {              // two channels at a time: packed FMAs (common.h, gelu_exact2)
             const int t = 8 * u + e;
-            const float xh = fmaf(acc[t][i], rstd[i], mr);
-            o[e] = f2bf(gelu_exact(fmaf(xh, g[t], be[t])));
+            const f32x2 xh = pk_fma(f32x2{acc[t][i], acc[t + 1][i]}, splat2(rstd[i]), splat2(mr));
+            const f32x2 y = gelu_exact2(pk_fma(xh, f32x2{g[t], g[t + 1]}, f32x2{be[t], be[t + 1]}));
+            o[e] = f2bf(y.x); o[e + 1] = f2bf(y.y);
           }
           *(bf16x8*)(yr + 128 * u) = o;
           __builtin_amdgcn_sched_barrier(0);
